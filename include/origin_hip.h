@@ -1,0 +1,184 @@
+/*
+ * origin_hip.h -- C ABI of liborigin_hip.so, the MI355X (gfx950) implementation of
+ * ORIGIN's dense hot path.
+ *
+ * The reference (musevlt/origin) has no FFI: its hot path is four Python functions in
+ * muse_origin/lib_origin.py that Step.run bodies in muse_origin/steps.py resolve by
+ * name (steps.py:19-41).  This ABI is what those functions are re-implemented on; each
+ * entry point cites the reference interface it replaces.  The Python binding is
+ * origin_amd/_capi.py (ctypes); INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative ORIGIN_E_* code; the message of
+ *     the last failure on the calling thread is origin_last_error().  Nothing aborts.
+ *   - cubes are C-order (Nz, Ny, Nx), x fastest, float32; masks / profile indices uint8.
+ *   - pointers named d_* are DEVICE pointers obtained from origin_malloc (or any HIP
+ *     allocation on the context's device); h_* are host pointers.  The library never
+ *     keeps a caller pointer after the call returns, except plan objects that own
+ *     private device copies of what they were given.
+ *   - all work is enqueued on the context's stream; calls that return host values
+ *     synchronise, the others are asynchronous (origin_sync to wait).
+ *   - one host thread per context; a context is not re-entrant.
+ */
+#ifndef ORIGIN_HIP_H
+#define ORIGIN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORIGIN_OK 0
+#define ORIGIN_E_ARG (-1)      /* bad argument / unsupported size            */
+#define ORIGIN_E_NOMEM (-2)    /* device allocation failed                    */
+#define ORIGIN_E_HIP (-3)      /* a HIP runtime call or kernel launch failed  */
+#define ORIGIN_E_NODEVICE (-4) /* no usable GPU                               */
+#define ORIGIN_E_STATE (-5)    /* call order / plan mismatch                  */
+
+typedef struct origin_ctx origin_ctx;
+typedef struct origin_glr_plan origin_glr_plan;
+
+/* ---- context, memory, timing ------------------------------------------------------ */
+const char *origin_last_error(void);
+int origin_abi_version(void);
+int origin_device_count(int *count);
+int origin_ctx_create(int device, origin_ctx **out);
+int origin_ctx_destroy(origin_ctx *ctx);
+int origin_sync(origin_ctx *ctx);
+int origin_device_name(origin_ctx *ctx, char *buf, int buflen);
+int origin_mem_info(origin_ctx *ctx, size_t *free_bytes, size_t *total_bytes);
+/* the hipStream_t of the context, as an opaque pointer (for interop / RCCL) */
+int origin_stream(origin_ctx *ctx, void **stream);
+
+int origin_malloc(origin_ctx *ctx, size_t bytes, void **d_ptr);
+int origin_free(origin_ctx *ctx, void *d_ptr);
+int origin_memset(origin_ctx *ctx, void *d_ptr, int byte, size_t bytes);
+int origin_h2d(origin_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int origin_d2h(origin_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+int origin_d2d(origin_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
+/* strided 3-D box copy of `elem`-byte elements between (Nz, Ny, Nx)-shaped arrays; kind:
+ * 0 = host->device, 1 = device->host, 2 = device->device.  Pitches in elements.  Used
+ * for tile upload/download and halo strips. */
+int origin_copy_box(origin_ctx *ctx, int kind, void *dst, long dst_pitch_y, long dst_pitch_z,
+                    const void *src, long src_pitch_y, long src_pitch_z, int nz, int ny,
+                    int nx, int elem);
+
+/* HIP-event timers on the context's stream: slot in [0, 64). */
+int origin_timer_start(origin_ctx *ctx, int slot);
+int origin_timer_stop(origin_ctx *ctx, int slot);
+int origin_timer_ms(origin_ctx *ctx, int slot, float *ms); /* synchronises on the stop */
+
+/* ---- A. DCT continuum + standardisation -------------------------------------------
+ * Replaces dct_residual (lib_origin.py:150-240) and the dense lines of
+ * Preprocessing.run (steps.py:431-450, :463-465). */
+
+/* Per-spaxel fit of order+1 DCT-II atoms (lib_origin.py:127-146): weighted LSQ
+ * D (D^T S^-1 D)^-1 D^T S^-1 s for spaxels without masked voxels (:226-235), plain
+ * D D^T s otherwise or when approx != 0 (:191-194, :237).  d_coef: float64 [(order+1)][S]. */
+int origin_dct_fit(origin_ctx *ctx, const float *d_raw, const float *d_var,
+                   const uint8_t *d_mask, int Nz, int Ny, int Nx, int order, int approx,
+                   double *d_coef);
+/* Continuum cube D c (what dct_residual returns), float32. */
+int origin_dct_continuum(origin_ctx *ctx, const double *d_coef, int Nz, int Ny, int Nx,
+                         int order, float *d_cont);
+/* Per-channel sum and count over unmasked spaxels of (raw - cont): the two halves of
+ * nanmean(data, axis=(1,2)) (steps.py:434-442).  d_zsum, d_zcnt: float64 [Nz].  Across
+ * GPUs these are all-reduced by the host before origin_dct_standardize. */
+int origin_dct_resid_sums(origin_ctx *ctx, const float *d_raw, const uint8_t *d_mask,
+                          const double *d_coef, int Nz, int Ny, int Nx, int order,
+                          double *d_zsum, double *d_zcnt);
+/* cube_std = (raw - cont - zsum/zcnt) / sqrt(var), 0 where masked; cont_dct = cont / sqrt(var)
+ * (steps.py:439-446, :463); optional per-spaxel images (may be NULL): ima_std = mean_z
+ * cube_std (:450), ima_dct = mean_z cont_dct (:465), o2 = mean_z cube_std^2 (O2test,
+ * lib_origin.py:957-974).  d_cont_dct may be NULL. */
+int origin_dct_standardize(origin_ctx *ctx, const float *d_raw, const float *d_var,
+                           const uint8_t *d_mask, const double *d_coef,
+                           const double *d_zsum, const double *d_zcnt, int Nz, int Ny,
+                           int Nx, int order, float *d_cube_std, float *d_cont_dct,
+                           float *d_ima_std, float *d_ima_dct, double *d_o2);
+
+/* ---- B. O2 test and greedy PCA ---------------------------------------------------- */
+
+/* O2test (lib_origin.py:957-974): out[s] = mean_z cube[z, s]^2, float64 [S]. */
+int origin_o2(origin_ctx *ctx, const float *d_cube, int Nz, long S, double *d_out);
+
+/* Building blocks of one Compute_GreedyPCA iteration (lib_origin.py:899-949), batched
+ * over `na` areas.  The cube is updated in place; spaxels are addressed by flat index
+ * s = y*Nx + x.  List arrays are concatenated per area with int64 offsets [na+1]; every
+ * array below is a DEVICE array built by the host driver (origin_amd/pca.py).
+ *
+ * bmean   : b_a[z] = mean_{s in bg_a} F[z, s]           (float64 [na][Nz])        (:917)
+ * build_xp: Xp_a = F[:, nuis_a] - b_a (b_a^T F[:, nuis_a])                    (:920-923)
+ *           float64, row-major [Nz][ld_a] at d_Xp + xp_off[a], ld_a = n_a rounded up to
+ *           16 (pad columns are zero); d_c receives b_a^T F[:, nuis_a] at c_off[a].
+ *           (the reference's extra division by sum(b^2), :924, only rescales Xp and does
+ *           not change its singular vectors.)
+ * gram    : G_a = Xp_a^T Xp_a with v_mfma_f64_16x16x4_f64; float64 [ld_a][ld_a] at
+ *           d_G + g_off[a].  The host lists the 32x32 upper-triangle tiles to compute
+ *           (tile_i <= tile_j, area tile_a); g_total = sum_a ld_a^2.       -- Gram form
+ *           of the svds(k=1) call at :940: its leading eigenvector v gives
+ * uvec    : u_a = Xp_a v_a / ||Xp_a v_a||               (float64 [na][Nz])        (:940)
+ * deflate : F[:, s] -= u_a (u_a^T F[:, s]) for every spaxel s of area a, and
+ *           test[s] = mean_z F[z, s]^2                                        (:943-946)
+ *           ntot = total list length, nsmax = longest per-area list.
+ */
+int origin_pca_bmean(origin_ctx *ctx, const float *d_F, int Nz, long S, const int *d_bg,
+                     const long *d_bg_off, int na, double *d_b);
+int origin_pca_build_xp(origin_ctx *ctx, const float *d_F, int Nz, long S, const int *d_nuis,
+                        const long *d_nuis_off, int na, int ldmax, const double *d_b,
+                        double *d_Xp, const long *d_xp_off, const int *d_ld, double *d_c,
+                        const long *d_c_off);
+int origin_pca_gram(origin_ctx *ctx, const double *d_Xp, const long *d_xp_off,
+                    const int *d_ld, int Nz, int ntiles, const int *d_tile_i,
+                    const int *d_tile_j, const int *d_tile_a, long g_total, double *d_G,
+                    const long *d_g_off);
+int origin_pca_uvec(origin_ctx *ctx, const double *d_Xp, const long *d_xp_off, const int *d_ld,
+                    const int *d_n, int na, int Nz, const double *d_v, const long *d_v_off,
+                    double *d_u);
+int origin_pca_deflate(origin_ctx *ctx, float *d_F, int Nz, long S, const int *d_spx,
+                       const long *d_spx_off, int na, long ntot, int nsmax, const double *d_u,
+                       double *d_test);
+
+/* ---- C. GLR correlation ------------------------------------------------------------
+ * Replaces Correlation_GLR_test (lib_origin.py:1070-1217) and the dense lines of
+ * ComputeTGLR.run (steps.py:781-793).
+ *
+ * A plan owns device copies of the zero-mean PSFs k_fz = PSF_fz - mean (lib :1033-1034),
+ * the optional field weights, the prepared profiles (trimmed / normalised / mean
+ * subtracted by the host exactly as lib :1155-1165) and the derived normalisation
+ * tables.  h_psf: float64 [nfields][Nz][P][P] (P odd, as the reference holds them);
+ * h_weights: float64 [nfields][Ny][Nx] or NULL (weights=None); h_taps: float64
+ * concatenated taps of the K prepared profiles, h_tap_off: int [K+1]. */
+int origin_glr_plan_create(origin_ctx *ctx, int Nz, int Ny, int Nx, int nfields, int P,
+                           const double *h_psf, const double *h_weights, int K,
+                           const double *h_taps, const int *h_tap_off,
+                           origin_glr_plan **out);
+int origin_glr_plan_destroy(origin_glr_plan *plan);
+/* bytes of device memory the plan holds */
+int origin_glr_plan_bytes(origin_glr_plan *plan, size_t *bytes);
+
+/* correl = max_k T_k, profile = first argmax_k, correl_min = min_k T_k (lib :1205-1212).
+ * If d_mask != NULL the ComputeTGLR glue is fused: correl[mask] = 0, profile[mask] = 0
+ * (steps.py:781, :788) before maxmap = amax_z correl, minmap = amin_z correl_min (:792-793).
+ * d_maxmap / d_minmap may be NULL.  d_work: float32 workspace of
+ * origin_glr_work_elems(plan) elements. */
+int origin_glr_work_elems(origin_glr_plan *plan, size_t *elems);
+int origin_glr_run(origin_ctx *ctx, origin_glr_plan *plan, const float *d_cube,
+                   const uint8_t *d_mask, float *d_work, float *d_correl,
+                   uint8_t *d_profile, float *d_correl_min, float *d_maxmap,
+                   float *d_minmap);
+
+/* ---- D. local maxima ---------------------------------------------------------------
+ * compute_local_max (lib_origin.py:1220-1256): size^3 maximum_filter (scipy 'reflect'
+ * border == clamped window for a max), keep voxels equal to their window maximum and
+ * not masked, zero elsewhere; same on -correl_min. */
+int origin_local_max(origin_ctx *ctx, const float *d_correl, const float *d_correl_min,
+                     const uint8_t *d_mask, int Nz, int Ny, int Nx, int size,
+                     float *d_local_max, float *d_local_min);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORIGIN_HIP_H */

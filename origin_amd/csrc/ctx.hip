@@ -1,0 +1,219 @@
+// Context, device memory, copies and HIP-event timers of liborigin_hip.so.
+#include "common.h"
+
+static thread_local char g_err[1024] = "";
+
+void origin_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int origin_scratch(origin_ctx *ctx, size_t bytes, void **out) {
+  if (bytes > ctx->scratch_bytes) {
+    if (ctx->scratch) {
+      ORIGIN_HIP(hipStreamSynchronize(ctx->stream));
+      ORIGIN_HIP(hipFree(ctx->scratch));
+      ctx->scratch = nullptr;
+      ctx->scratch_bytes = 0;
+    }
+    size_t want = bytes + bytes / 4 + (1 << 20);
+    ORIGIN_HIP(hipMalloc(&ctx->scratch, want));
+    ctx->scratch_bytes = want;
+  }
+  *out = ctx->scratch;
+  return ORIGIN_OK;
+}
+
+extern "C" {
+
+const char *origin_last_error(void) { return g_err; }
+
+int origin_abi_version(void) { return 1; }
+
+int origin_device_count(int *count) {
+  ORIGIN_CHECK_ARG(count, "count is null");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    origin_set_error("hipGetDeviceCount: %s", hipGetErrorString(e));
+    return ORIGIN_E_NODEVICE;
+  }
+  *count = n;
+  return ORIGIN_OK;
+}
+
+int origin_ctx_create(int device, origin_ctx **out) {
+  ORIGIN_CHECK_ARG(out, "out is null");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    origin_set_error("no HIP device visible");
+    return ORIGIN_E_NODEVICE;
+  }
+  ORIGIN_CHECK_ARG(device >= 0 && device < n, "device %d out of range [0,%d)", device, n);
+  ORIGIN_HIP(hipSetDevice(device));
+  origin_ctx *ctx = new origin_ctx();
+  memset(ctx, 0, sizeof(*ctx));
+  ctx->device = device;
+  hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete ctx;
+    origin_set_error("hipStreamCreate: %s", hipGetErrorString(e));
+    return ORIGIN_E_HIP;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
+  if (ctx->num_cu <= 0) ctx->num_cu = 256;
+  *out = ctx;
+  return ORIGIN_OK;
+}
+
+int origin_ctx_destroy(origin_ctx *ctx) {
+  if (!ctx) return ORIGIN_OK;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  for (int i = 0; i < 64; ++i)
+    if (ctx->ev_made[i]) {
+      hipEventDestroy(ctx->ev_start[i]);
+      hipEventDestroy(ctx->ev_stop[i]);
+    }
+  if (ctx->scratch) hipFree(ctx->scratch);
+  if (ctx->ctab) hipFree(ctx->ctab);
+  hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return ORIGIN_OK;
+}
+
+int origin_sync(origin_ctx *ctx) {
+  ORIGIN_USE(ctx);
+  ORIGIN_HIP(hipStreamSynchronize(ctx->stream));
+  return ORIGIN_OK;
+}
+
+int origin_device_name(origin_ctx *ctx, char *buf, int buflen) {
+  ORIGIN_USE(ctx);
+  ORIGIN_CHECK_ARG(buf && buflen > 0, "bad buffer");
+  hipDeviceProp_t prop;
+  ORIGIN_HIP(hipGetDeviceProperties(&prop, ctx->device));
+  snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+  return ORIGIN_OK;
+}
+
+int origin_mem_info(origin_ctx *ctx, size_t *free_bytes, size_t *total_bytes) {
+  ORIGIN_USE(ctx);
+  size_t f = 0, t = 0;
+  ORIGIN_HIP(hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = f;
+  if (total_bytes) *total_bytes = t;
+  return ORIGIN_OK;
+}
+
+int origin_stream(origin_ctx *ctx, void **stream) {
+  ORIGIN_USE(ctx);
+  ORIGIN_CHECK_ARG(stream, "stream is null");
+  *stream = (void *)ctx->stream;
+  return ORIGIN_OK;
+}
+
+int origin_malloc(origin_ctx *ctx, size_t bytes, void **d_ptr) {
+  ORIGIN_USE(ctx);
+  ORIGIN_CHECK_ARG(d_ptr, "d_ptr is null");
+  *d_ptr = nullptr;
+  if (bytes == 0) bytes = 16;
+  ORIGIN_HIP(hipMalloc(d_ptr, bytes));
+  return ORIGIN_OK;
+}
+
+int origin_free(origin_ctx *ctx, void *d_ptr) {
+  ORIGIN_USE(ctx);
+  if (!d_ptr) return ORIGIN_OK;
+  ORIGIN_HIP(hipStreamSynchronize(ctx->stream));
+  ORIGIN_HIP(hipFree(d_ptr));
+  return ORIGIN_OK;
+}
+
+int origin_memset(origin_ctx *ctx, void *d_ptr, int byte, size_t bytes) {
+  ORIGIN_USE(ctx);
+  ORIGIN_HIP(hipMemsetAsync(d_ptr, byte, bytes, ctx->stream));
+  return ORIGIN_OK;
+}
+
+int origin_h2d(origin_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
+  ORIGIN_USE(ctx);
+  if (bytes == 0) return ORIGIN_OK;
+  ORIGIN_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  ORIGIN_HIP(hipStreamSynchronize(ctx->stream));
+  return ORIGIN_OK;
+}
+
+int origin_d2h(origin_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
+  ORIGIN_USE(ctx);
+  if (bytes == 0) return ORIGIN_OK;
+  ORIGIN_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  ORIGIN_HIP(hipStreamSynchronize(ctx->stream));
+  return ORIGIN_OK;
+}
+
+int origin_d2d(origin_ctx *ctx, void *d_dst, const void *d_src, size_t bytes) {
+  ORIGIN_USE(ctx);
+  if (bytes == 0) return ORIGIN_OK;
+  ORIGIN_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return ORIGIN_OK;
+}
+
+int origin_copy_box(origin_ctx *ctx, int kind, void *dst, long dst_pitch_y, long dst_pitch_z,
+                    const void *src, long src_pitch_y, long src_pitch_z, int nz, int ny,
+                    int nx, int elem) {
+  ORIGIN_USE(ctx);
+  ORIGIN_CHECK_ARG(kind >= 0 && kind <= 2, "kind must be 0 (h2d), 1 (d2h) or 2 (d2d)");
+  ORIGIN_CHECK_ARG(elem == 1 || elem == 2 || elem == 4 || elem == 8, "elem must be 1,2,4,8");
+  ORIGIN_CHECK_ARG(nz >= 0 && ny >= 0 && nx >= 0, "negative extent");
+  ORIGIN_CHECK_ARG(dst_pitch_y >= nx && src_pitch_y >= nx, "row pitch smaller than nx");
+  ORIGIN_CHECK_ARG(dst_pitch_z >= dst_pitch_y * (long)(ny > 0 ? 1 : 0) &&
+                       src_pitch_z >= src_pitch_y * (long)(ny > 0 ? 1 : 0),
+                   "plane pitch smaller than a row");
+  if (nz == 0 || ny == 0 || nx == 0) return ORIGIN_OK;
+  hipMemcpyKind k = kind == 0   ? hipMemcpyHostToDevice
+                    : kind == 1 ? hipMemcpyDeviceToHost
+                                : hipMemcpyDeviceToDevice;
+  // one 2-D copy per plane: rows of nx*elem bytes at the given pitches
+  for (int z = 0; z < nz; ++z) {
+    const char *s = (const char *)src + (size_t)z * src_pitch_z * elem;
+    char *d = (char *)dst + (size_t)z * dst_pitch_z * elem;
+    ORIGIN_HIP(hipMemcpy2DAsync(d, (size_t)dst_pitch_y * elem, s, (size_t)src_pitch_y * elem,
+                                (size_t)nx * elem, ny, k, ctx->stream));
+  }
+  if (kind != 2) ORIGIN_HIP(hipStreamSynchronize(ctx->stream));
+  return ORIGIN_OK;
+}
+
+int origin_timer_start(origin_ctx *ctx, int slot) {
+  ORIGIN_USE(ctx);
+  ORIGIN_CHECK_ARG(slot >= 0 && slot < 64, "timer slot out of range");
+  if (!ctx->ev_made[slot]) {
+    ORIGIN_HIP(hipEventCreate(&ctx->ev_start[slot]));
+    ORIGIN_HIP(hipEventCreate(&ctx->ev_stop[slot]));
+    ctx->ev_made[slot] = true;
+  }
+  ORIGIN_HIP(hipEventRecord(ctx->ev_start[slot], ctx->stream));
+  return ORIGIN_OK;
+}
+
+int origin_timer_stop(origin_ctx *ctx, int slot) {
+  ORIGIN_USE(ctx);
+  ORIGIN_CHECK_ARG(slot >= 0 && slot < 64 && ctx->ev_made[slot], "timer slot not started");
+  ORIGIN_HIP(hipEventRecord(ctx->ev_stop[slot], ctx->stream));
+  return ORIGIN_OK;
+}
+
+int origin_timer_ms(origin_ctx *ctx, int slot, float *ms) {
+  ORIGIN_USE(ctx);
+  ORIGIN_CHECK_ARG(slot >= 0 && slot < 64 && ctx->ev_made[slot] && ms, "timer slot not started");
+  ORIGIN_HIP(hipEventSynchronize(ctx->ev_stop[slot]));
+  ORIGIN_HIP(hipEventElapsedTime(ms, ctx->ev_start[slot], ctx->ev_stop[slot]));
+  return ORIGIN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,605 @@
+// DCT continuum fit + standardisation + O2 test  (SURVEY.md 2.2 rows k1-k3).
+//
+// Replaces dct_residual (reference muse_origin/lib_origin.py:150-240) and the dense
+// lines of Preprocessing.run (steps.py:431-450, :463-465) and O2test (lib :957-974).
+//
+// Data layout: cubes are (Nz, S) with S = Ny*Nx spaxels, x fastest.  A wavefront owns 64
+// consecutive spaxels and marches along z, so every global access of the march is one
+// fully coalesced 256-B line; all per-spaxel state lives in VGPRs.  Quantities that are
+// uniform across a wave (the cosine table row of the current channel) are fetched with
+// scalar loads.
+//
+// Algebra.  With theta_z = (z + 1/2) pi / Nz the DCT-II atoms of DCTMAT (lib :127-146)
+// are D[z][a] = s_a sqrt(2/Nz) cos(a theta_z), s_0 = 1/sqrt 2.  Because
+// cos(a t) cos(b t) = (cos((a-b) t) + cos((a+b) t)) / 2, the 66 distinct entries of the
+// weighted Gram matrix D^T S^-1 D collapse onto 2*order+1 moments
+//      M_k = sum_z w_z cos(k theta_z),          w_z = 1 / var_z,
+// and the continuum  D (D^T S^-1 D)^-1 D^T S^-1 s  (lib :233-235) becomes
+//      cont[z] = sum_a y_a cos(a theta_z),   H y = 2 Rw,
+//      H_ab = M_|a-b| + M_(a+b),   Rw_a = sum_z w_z s_z cos(a theta_z),
+// (the s_a factors cancel).  The unweighted fit D D^T s (lib :191-194, :237) is
+//      y_0 = R0_0 / Nz,  y_a = 2 R0_a / Nz,   R0_a = sum_z s_z cos(a theta_z).
+// So one z-march accumulates (2*order+1) + 2*(order+1) float64 moments per spaxel instead
+// of 77 Gram/RHS entries, then solves the (order+1)^2 SPD system by an in-register
+// Cholesky.  Everything is accumulated in float64: the fit is HBM-bound (9 B/voxel
+// against 43 DFMA/voxel), so exact-ish arithmetic is free.
+#include <cmath>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxOrder = 12;
+
+// ------------------------------------------------------------------------------------
+// cosine table  ctab[z][k] = cos(k theta_z), k = 0 .. 2*order     (float64, device)
+// ------------------------------------------------------------------------------------
+int make_ctab(origin_ctx *ctx, int Nz, int order, double **d_tab) {
+  if (ctx->ctab && ctx->ctab_nz == Nz && ctx->ctab_order == order) {
+    *d_tab = ctx->ctab;
+    return ORIGIN_OK;
+  }
+  const int NK = 2 * order + 1;
+  std::vector<double> h((size_t)Nz * NK);
+  for (int z = 0; z < Nz; ++z)
+    for (int k = 0; k < NK; ++k) h[(size_t)z * NK + k] = std::cos((z + 0.5) * (M_PI / Nz) * k);
+  if (ctx->ctab) {
+    ORIGIN_HIP(hipStreamSynchronize(ctx->stream));
+    ORIGIN_HIP(hipFree(ctx->ctab));
+    ctx->ctab = nullptr;
+  }
+  void *p = nullptr;
+  ORIGIN_HIP(hipMalloc(&p, h.size() * sizeof(double)));
+  hipError_t e = hipMemcpyAsync(p, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice,
+                                ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    hipFree(p);
+    origin_set_error("ctab upload: %s", hipGetErrorString(e));
+    return ORIGIN_E_HIP;
+  }
+  ctx->ctab = (double *)p;
+  ctx->ctab_nz = Nz;
+  ctx->ctab_order = order;
+  *d_tab = ctx->ctab;
+  return ORIGIN_OK;
+}
+
+struct CtabGuard {  // the table is cached in the context; nothing to release per call
+  double *p = nullptr;
+  explicit CtabGuard(origin_ctx *) {}
+};
+
+// ------------------------------------------------------------------------------------
+// pass 1: moments + solve.  block = (64 lanes, ZS waves); wave w marches z = w, w+ZS, ...
+// ------------------------------------------------------------------------------------
+template <int ORDER>
+__global__ __launch_bounds__(512) void dct_fit_kernel(const float *__restrict__ raw,
+                                                      const float *__restrict__ var,
+                                                      const uint8_t *__restrict__ mask,
+                                                      const double *__restrict__ ctab, int Nz,
+                                                      long S, int approx,
+                                                      double *__restrict__ coef) {
+  constexpr int NA = ORDER + 1;
+  constexpr int NK = 2 * ORDER + 1;
+  constexpr int NACC = NK + 2 * NA;
+  extern __shared__ double lds[];  // [ZS-1][NACC+1][64]
+
+  const int lane = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  const int ZS = blockDim.y;
+  const long s = (long)blockIdx.x * 64 + lane;
+  const bool live = s < S;
+  const long sc = live ? s : S - 1;  // clamp: dead lanes redo the last spaxel, never store
+
+  double M[NK], Rw[NA], R0[NA];
+#pragma unroll
+  for (int k = 0; k < NK; ++k) M[k] = 0.0;
+#pragma unroll
+  for (int a = 0; a < NA; ++a) Rw[a] = R0[a] = 0.0;
+  int anymask = 0;
+
+#pragma unroll 2
+  for (int z = wave; z < Nz; z += ZS) {
+    const long idx = (long)z * S + sc;
+    const float r = raw[idx];
+    const float v = var[idx];
+    anymask |= mask[idx];
+    const double *ct = ctab + (long)z * NK;  // wave-uniform -> scalar loads
+    const double rd = (double)r;
+    const double wd = (double)(1.0f / v);  // var = inf (masked) -> weight 0
+    const double wr = wd * rd;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) M[k] = fma(wd, ct[k], M[k]);
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+      Rw[a] = fma(wr, ct[a], Rw[a]);
+      R0[a] = fma(rd, ct[a], R0[a]);
+    }
+  }
+
+  // cross-wave reduction (fixed order -> deterministic)
+  if (ZS > 1) {
+    if (wave > 0) {
+      double *dst = lds + (long)(wave - 1) * (NACC + 1) * 64 + lane;
+#pragma unroll
+      for (int k = 0; k < NK; ++k) dst[k * 64] = M[k];
+#pragma unroll
+      for (int a = 0; a < NA; ++a) {
+        dst[(NK + a) * 64] = Rw[a];
+        dst[(NK + NA + a) * 64] = R0[a];
+      }
+      dst[NACC * 64] = (double)anymask;
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    for (int w = 1; w < ZS; ++w) {
+      const double *src = lds + (long)(w - 1) * (NACC + 1) * 64 + lane;
+#pragma unroll
+      for (int k = 0; k < NK; ++k) M[k] += src[k * 64];
+#pragma unroll
+      for (int a = 0; a < NA; ++a) {
+        Rw[a] += src[(NK + a) * 64];
+        R0[a] += src[(NK + NA + a) * 64];
+      }
+      anymask |= (int)src[NACC * 64];
+    }
+  }
+
+  double y[NA];
+  bool weighted = !approx && !anymask;  // valid = ~any(mask, axis=0)   (lib :226)
+  if (weighted) {
+    // H = L L^T, in place (lower triangle), fully unrolled -> registers
+    double L[NA][NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+      for (int b = 0; b <= a; ++b) L[a][b] = M[a - b] + M[a + b];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      double d = L[j][j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) d = fma(-L[j][k], L[j][k], d);
+      ok = ok && (d > 0.0);
+      const double inv = 1.0 / sqrt(d);
+      L[j][j] = d * inv;
+#pragma unroll
+      for (int i = j + 1; i < NA; ++i) {
+        double t = L[i][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) t = fma(-L[i][k], L[j][k], t);
+        L[i][j] = t * inv;
+      }
+    }
+    // L q = 2 Rw ;  L^T y = q
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      double t = 2.0 * Rw[i];
+#pragma unroll
+      for (int k = 0; k < i; ++k) t = fma(-L[i][k], y[k], t);
+      y[i] = t / L[i][i];
+    }
+#pragma unroll
+    for (int i = NA - 1; i >= 0; --i) {
+      double t = y[i];
+#pragma unroll
+      for (int k = i + 1; k < NA; ++k) t = fma(-L[k][i], y[k], t);
+      y[i] = t / L[i][i];
+    }
+    weighted = ok;  // singular weights (reference: LinAlgError) -> unweighted fit
+  }
+  if (!weighted) {
+    const double inl = 1.0 / (double)Nz;
+    y[0] = R0[0] * inl;
+#pragma unroll
+    for (int a = 1; a < NA; ++a) y[a] = 2.0 * R0[a] * inl;
+  }
+  if (live) {
+#pragma unroll
+    for (int a = 0; a < NA; ++a) coef[(long)a * S + s] = y[a];
+  }
+}
+
+// cont[z, s] = sum_a coef[a][s] cos(a theta_z)
+template <int ORDER>
+__device__ __forceinline__ double eval_cont(const double (&c)[ORDER + 1], const double *ct) {
+  double acc = c[0] * ct[0];
+#pragma unroll
+  for (int a = 1; a <= ORDER; ++a) acc = fma(c[a], ct[a], acc);
+  return acc;
+}
+
+template <int ORDER>
+__global__ __launch_bounds__(256) void dct_continuum_kernel(const double *__restrict__ coef,
+                                                            const double *__restrict__ ctab,
+                                                            int Nz, long S, int zchunk,
+                                                            float *__restrict__ cont) {
+  constexpr int NA = ORDER + 1;
+  constexpr int NK = 2 * ORDER + 1;
+  const long s = (long)blockIdx.x * 256 + threadIdx.x;
+  if (s >= S) return;
+  double c[NA];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) c[a] = coef[(long)a * S + s];
+  const int z0 = blockIdx.y * zchunk;
+  const int z1 = min(Nz, z0 + zchunk);
+  for (int z = z0; z < z1; ++z)
+    cont[(long)z * S + s] = (float)eval_cont<ORDER>(c, ctab + (long)z * NK);
+}
+
+// ------------------------------------------------------------------------------------
+// pass 2: per-channel sum / count of (raw - cont) over unmasked spaxels.
+//   sum_s (raw - cont) = sum_{s unmasked} raw[z,s]
+//                        - sum_a cos(a theta_z) (Ctot_a - sum_{s masked at z} coef[a][s])
+// so the plane reduction only touches raw + mask (5 B/voxel); coefficients are gathered
+// for masked voxels only.  One block reduces `SPB` spaxels of one channel.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+template <int ORDER>
+__global__ __launch_bounds__(256) void dct_plane_sums_kernel(
+    const float *__restrict__ raw, const uint8_t *__restrict__ mask,
+    const double *__restrict__ coef, const double *__restrict__ ctab, long S, int spb,
+    double *__restrict__ part /* [Nz][nchunk][2] */) {
+  constexpr int NA = ORDER + 1;
+  constexpr int NK = 2 * ORDER + 1;
+  __shared__ double red[2][4];
+  const int z = blockIdx.y;
+  const long s0 = (long)blockIdx.x * spb;
+  const long s1 = min(S, s0 + spb);
+  const float *r = raw + (long)z * S;
+  const uint8_t *m = mask + (long)z * S;
+  const double *ct = ctab + (long)z * NK;
+  double sum = 0.0, cnt = 0.0;
+  for (long s = s0 + threadIdx.x; s < s1; s += 256) {
+    const float v = r[s];
+    if (m[s]) {
+      // masked voxel: remove its continuum from the "all spaxels" term
+      double c = coef[s] * ct[0];
+#pragma unroll
+      for (int a = 1; a < NA; ++a) c = fma(coef[(long)a * S + s], ct[a], c);
+      sum += c;
+    } else {
+      sum += (double)v;
+      cnt += 1.0;
+    }
+  }
+  sum = wave_sum(sum);
+  cnt = wave_sum(cnt);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    red[0][wave] = sum;
+    red[1][wave] = cnt;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double *p = part + ((long)z * gridDim.x + blockIdx.x) * 2;
+    p[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    p[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+
+// Ctot_a = sum_s coef[a][s]: one block per a, fixed-order tree
+__global__ __launch_bounds__(1024) void coef_total_kernel(const double *__restrict__ coef, long S,
+                                                          double *__restrict__ ctot) {
+  __shared__ double red[16];
+  const int a = blockIdx.x;
+  double acc = 0.0;
+  for (long s = threadIdx.x; s < S; s += 1024) acc += coef[(long)a * S + s];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < 16; ++i) t += red[i];
+    ctot[a] = t;
+  }
+}
+
+template <int ORDER>
+__global__ __launch_bounds__(256) void dct_zsum_final_kernel(const double *__restrict__ part,
+                                                             const double *__restrict__ ctot,
+                                                             const double *__restrict__ ctab,
+                                                             int Nz, int nchunk,
+                                                             double *__restrict__ zsum,
+                                                             double *__restrict__ zcnt) {
+  constexpr int NA = ORDER + 1;
+  constexpr int NK = 2 * ORDER + 1;
+  const int z = blockIdx.x * 256 + threadIdx.x;
+  if (z >= Nz) return;
+  double sum = 0.0, cnt = 0.0;
+  for (int c = 0; c < nchunk; ++c) {
+    sum += part[((long)z * nchunk + c) * 2];
+    cnt += part[((long)z * nchunk + c) * 2 + 1];
+  }
+  const double *ct = ctab + (long)z * NK;
+  double call = 0.0;
+#pragma unroll
+  for (int a = 0; a < NA; ++a) call = fma(ctot[a], ct[a], call);
+  zsum[z] = sum - call;
+  zcnt[z] = cnt;
+}
+
+// ------------------------------------------------------------------------------------
+// pass 3: standardise.  grid (spaxel blocks, z chunks); per-spaxel sums go to partials.
+// ------------------------------------------------------------------------------------
+template <int ORDER>
+__global__ __launch_bounds__(256) void dct_standardize_kernel(
+    const float *__restrict__ raw, const float *__restrict__ var,
+    const uint8_t *__restrict__ mask, const double *__restrict__ coef,
+    const double *__restrict__ ctab, const double *__restrict__ zsum,
+    const double *__restrict__ zcnt, int Nz, long S, int zchunk,
+    float *__restrict__ cube_std, float *__restrict__ cont_dct,
+    double *__restrict__ part /* [nzc][3][S] or null */) {
+  constexpr int NA = ORDER + 1;
+  constexpr int NK = 2 * ORDER + 1;
+  const long s = (long)blockIdx.x * 256 + threadIdx.x;
+  if (s >= S) return;
+  double c[NA];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) c[a] = coef[(long)a * S + s];
+  const int z0 = blockIdx.y * zchunk;
+  const int z1 = min(Nz, z0 + zchunk);
+  double a_std = 0.0, a_dct = 0.0, a_o2 = 0.0;
+#pragma unroll 2
+  for (int z = z0; z < z1; ++z) {
+    const long idx = (long)z * S + s;
+    const float r = raw[idx];
+    const float v = var[idx];
+    const bool mk = mask[idx] != 0;
+    const double cont = eval_cont<ORDER>(c, ctab + (long)z * NK);
+    const double mean = zsum[z] / zcnt[z];  // nanmean over unmasked spaxels (steps.py:442)
+    const float sd = sqrtf(v);              // std = sqrt(var)               (steps.py:439)
+    const float t = (float)(((double)r - cont) - mean);
+    const float o = mk ? 0.0f : t / sd;     // data[mask] = 0                (steps.py:446)
+    const float cd = (float)cont / sd;      // cont_dct /= std ; astype(f32) (:440, :463)
+    cube_std[idx] = o;
+    if (cont_dct) cont_dct[idx] = cd;
+    a_std += (double)o;
+    a_dct += (double)cd;
+    a_o2 = fma((double)o, (double)o, a_o2);
+  }
+  if (part) {
+    double *p = part + (long)blockIdx.y * 3 * S + s;
+    p[0] = a_std;
+    p[S] = a_dct;
+    p[2 * S] = a_o2;
+  }
+}
+
+__global__ __launch_bounds__(256) void std_images_final_kernel(const double *__restrict__ part,
+                                                               int nzc, long S, int Nz,
+                                                               float *__restrict__ ima_std,
+                                                               float *__restrict__ ima_dct,
+                                                               double *__restrict__ o2) {
+  const long s = (long)blockIdx.x * 256 + threadIdx.x;
+  if (s >= S) return;
+  double a = 0.0, b = 0.0, c = 0.0;
+  for (int k = 0; k < nzc; ++k) {
+    const double *p = part + (long)k * 3 * S + s;
+    a += p[0];
+    b += p[S];
+    c += p[2 * S];
+  }
+  const double inv = 1.0 / (double)Nz;
+  if (ima_std) ima_std[s] = (float)(a * inv);
+  if (ima_dct) ima_dct[s] = (float)(b * inv);
+  if (o2) o2[s] = c * inv;
+}
+
+// ------------------------------------------------------------------------------------
+// O2 test on any cube
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void o2_partial_kernel(const float *__restrict__ cube, int Nz,
+                                                         long S, int zchunk,
+                                                         double *__restrict__ part) {
+  const long s = (long)blockIdx.x * 256 + threadIdx.x;
+  if (s >= S) return;
+  const int z0 = blockIdx.y * zchunk;
+  const int z1 = min(Nz, z0 + zchunk);
+  double acc = 0.0;
+#pragma unroll 4
+  for (int z = z0; z < z1; ++z) {
+    const double v = (double)cube[(long)z * S + s];
+    acc = fma(v, v, acc);
+  }
+  part[(long)blockIdx.y * S + s] = acc;
+}
+
+__global__ __launch_bounds__(256) void o2_final_kernel(const double *__restrict__ part, int nzc,
+                                                       long S, int Nz, double *__restrict__ out) {
+  const long s = (long)blockIdx.x * 256 + threadIdx.x;
+  if (s >= S) return;
+  double acc = 0.0;
+  for (int k = 0; k < nzc; ++k) acc += part[(long)k * S + s];
+  out[s] = acc / (double)Nz;
+}
+
+int pick_zchunks(origin_ctx *ctx, long S, int Nz) {
+  // aim for >= 8 blocks of 256 threads per CU
+  const long blocks = (S + 255) / 256;
+  long want = ((long)ctx->num_cu * 8 + blocks - 1) / blocks;
+  if (want < 1) want = 1;
+  if (want > 64) want = 64;
+  if (want > Nz) want = Nz;
+  return (int)want;
+}
+
+#define DISPATCH_ORDER(order, CALL)              \
+  switch (order) {                               \
+    case 1: { CALL(1); } break;                  \
+    case 2: { CALL(2); } break;                  \
+    case 3: { CALL(3); } break;                  \
+    case 4: { CALL(4); } break;                  \
+    case 5: { CALL(5); } break;                  \
+    case 6: { CALL(6); } break;                  \
+    case 7: { CALL(7); } break;                  \
+    case 8: { CALL(8); } break;                  \
+    case 9: { CALL(9); } break;                  \
+    case 10: { CALL(10); } break;                \
+    case 11: { CALL(11); } break;                \
+    case 12: { CALL(12); } break;                \
+    default:                                     \
+      origin_set_error("dct order %d unsupported (1..%d)", order, kMaxOrder); \
+      return ORIGIN_E_ARG;                       \
+  }
+
+int check_dims(int Nz, int Ny, int Nx, int order) {
+  ORIGIN_CHECK_ARG(Nz > 0 && Ny > 0 && Nx > 0, "bad cube shape (%d,%d,%d)", Nz, Ny, Nx);
+  ORIGIN_CHECK_ARG(order >= 1 && order <= kMaxOrder, "dct order %d unsupported (1..%d)", order,
+                   kMaxOrder);
+  ORIGIN_CHECK_ARG(order + 1 <= Nz, "dct order %d needs at least %d channels", order, order + 1);
+  return ORIGIN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int origin_dct_fit(origin_ctx *ctx, const float *d_raw, const float *d_var,
+                   const uint8_t *d_mask, int Nz, int Ny, int Nx, int order, int approx,
+                   double *d_coef) {
+  ORIGIN_USE(ctx);
+  int rc = check_dims(Nz, Ny, Nx, order);
+  if (rc) return rc;
+  ORIGIN_CHECK_ARG(d_raw && d_var && d_mask && d_coef, "null pointer");
+  const long S = (long)Ny * Nx;
+  CtabGuard tab(ctx);
+  rc = make_ctab(ctx, Nz, order, &tab.p);
+  if (rc) return rc;
+  // z-split so that small fields still fill the chip: waves = S/64 * ZS >= ~4 per SIMD
+  const long waves = (S + 63) / 64;
+  int ZS = 1;
+  while (ZS < 8 && waves * ZS < (long)ctx->num_cu * 16) ZS *= 2;
+  const int NACC = (2 * order + 1) + 2 * (order + 1);
+  const size_t lds = (size_t)(ZS - 1) * (NACC + 1) * 64 * sizeof(double);
+  dim3 grid((unsigned)waves), block(64, ZS);
+#define CALL(O)                                                                             \
+  hipLaunchKernelGGL(dct_fit_kernel<O>, grid, block, lds, ctx->stream, d_raw, d_var, d_mask, \
+                     tab.p, Nz, S, approx, d_coef)
+  DISPATCH_ORDER(order, CALL)
+#undef CALL
+  ORIGIN_LAUNCH_CHECK();
+  return ORIGIN_OK;
+}
+
+int origin_dct_continuum(origin_ctx *ctx, const double *d_coef, int Nz, int Ny, int Nx,
+                         int order, float *d_cont) {
+  ORIGIN_USE(ctx);
+  int rc = check_dims(Nz, Ny, Nx, order);
+  if (rc) return rc;
+  ORIGIN_CHECK_ARG(d_coef && d_cont, "null pointer");
+  const long S = (long)Ny * Nx;
+  CtabGuard tab(ctx);
+  rc = make_ctab(ctx, Nz, order, &tab.p);
+  if (rc) return rc;
+  const int nzc = pick_zchunks(ctx, S, Nz);
+  const int zchunk = cdiv(Nz, nzc);
+  dim3 grid(cdiv(S, 256), cdiv(Nz, zchunk));
+#define CALL(O)                                                                                \
+  hipLaunchKernelGGL(dct_continuum_kernel<O>, grid, dim3(256), 0, ctx->stream, d_coef, tab.p, \
+                     Nz, S, zchunk, d_cont)
+  DISPATCH_ORDER(order, CALL)
+#undef CALL
+  ORIGIN_LAUNCH_CHECK();
+  return ORIGIN_OK;
+}
+
+int origin_dct_resid_sums(origin_ctx *ctx, const float *d_raw, const uint8_t *d_mask,
+                          const double *d_coef, int Nz, int Ny, int Nx, int order,
+                          double *d_zsum, double *d_zcnt) {
+  ORIGIN_USE(ctx);
+  int rc = check_dims(Nz, Ny, Nx, order);
+  if (rc) return rc;
+  ORIGIN_CHECK_ARG(d_raw && d_mask && d_coef && d_zsum && d_zcnt, "null pointer");
+  const long S = (long)Ny * Nx;
+  CtabGuard tab(ctx);
+  rc = make_ctab(ctx, Nz, order, &tab.p);
+  if (rc) return rc;
+  const int spb = 4096;
+  const int nchunk = cdiv(S, spb);
+  void *scr = nullptr;
+  const size_t part_bytes = (size_t)Nz * nchunk * 2 * sizeof(double);
+  rc = origin_scratch(ctx, part_bytes + 64 * sizeof(double), &scr);
+  if (rc) return rc;
+  double *part = (double *)scr;
+  double *ctot = (double *)((char *)scr + part_bytes);
+  hipLaunchKernelGGL(coef_total_kernel, dim3(order + 1), dim3(1024), 0, ctx->stream, d_coef, S,
+                     ctot);
+  dim3 grid(nchunk, Nz);
+#define CALL(O)                                                                                \
+  hipLaunchKernelGGL(dct_plane_sums_kernel<O>, grid, dim3(256), 0, ctx->stream, d_raw, d_mask, \
+                     d_coef, tab.p, S, spb, part);                                             \
+  hipLaunchKernelGGL(dct_zsum_final_kernel<O>, dim3(cdiv(Nz, 256)), dim3(256), 0, ctx->stream, \
+                     part, ctot, tab.p, Nz, nchunk, d_zsum, d_zcnt)
+  DISPATCH_ORDER(order, CALL)
+#undef CALL
+  ORIGIN_LAUNCH_CHECK();
+  return ORIGIN_OK;
+}
+
+int origin_dct_standardize(origin_ctx *ctx, const float *d_raw, const float *d_var,
+                           const uint8_t *d_mask, const double *d_coef,
+                           const double *d_zsum, const double *d_zcnt, int Nz, int Ny,
+                           int Nx, int order, float *d_cube_std, float *d_cont_dct,
+                           float *d_ima_std, float *d_ima_dct, double *d_o2) {
+  ORIGIN_USE(ctx);
+  int rc = check_dims(Nz, Ny, Nx, order);
+  if (rc) return rc;
+  ORIGIN_CHECK_ARG(d_raw && d_var && d_mask && d_coef && d_zsum && d_zcnt && d_cube_std,
+                   "null pointer");
+  const long S = (long)Ny * Nx;
+  CtabGuard tab(ctx);
+  rc = make_ctab(ctx, Nz, order, &tab.p);
+  if (rc) return rc;
+  const int nzc0 = pick_zchunks(ctx, S, Nz);
+  const int zchunk = cdiv(Nz, nzc0);
+  const int nzc = cdiv(Nz, zchunk);
+  const bool want = d_ima_std || d_ima_dct || d_o2;
+  double *part = nullptr;
+  if (want) {
+    void *scr = nullptr;
+    rc = origin_scratch(ctx, (size_t)nzc * 3 * S * sizeof(double), &scr);
+    if (rc) return rc;
+    part = (double *)scr;
+  }
+  dim3 grid(cdiv(S, 256), nzc);
+#define CALL(O)                                                                               \
+  hipLaunchKernelGGL(dct_standardize_kernel<O>, grid, dim3(256), 0, ctx->stream, d_raw, d_var, \
+                     d_mask, d_coef, tab.p, d_zsum, d_zcnt, Nz, S, zchunk, d_cube_std,        \
+                     d_cont_dct, part)
+  DISPATCH_ORDER(order, CALL)
+#undef CALL
+  ORIGIN_LAUNCH_CHECK();
+  if (want) {
+    hipLaunchKernelGGL(std_images_final_kernel, dim3(cdiv(S, 256)), dim3(256), 0, ctx->stream,
+                       part, nzc, S, Nz, d_ima_std, d_ima_dct, d_o2);
+    ORIGIN_LAUNCH_CHECK();
+  }
+  return ORIGIN_OK;
+}
+
+int origin_o2(origin_ctx *ctx, const float *d_cube, int Nz, long S, double *d_out) {
+  ORIGIN_USE(ctx);
+  ORIGIN_CHECK_ARG(Nz > 0 && S > 0 && d_cube && d_out, "bad arguments");
+  const int nzc0 = pick_zchunks(ctx, S, Nz);
+  const int zchunk = cdiv(Nz, nzc0);
+  const int nzc = cdiv(Nz, zchunk);
+  void *scr = nullptr;
+  int rc = origin_scratch(ctx, (size_t)nzc * S * sizeof(double), &scr);
+  if (rc) return rc;
+  hipLaunchKernelGGL(o2_partial_kernel, dim3(cdiv(S, 256), nzc), dim3(256), 0, ctx->stream,
+                     d_cube, Nz, S, zchunk, (double *)scr);
+  hipLaunchKernelGGL(o2_final_kernel, dim3(cdiv(S, 256)), dim3(256), 0, ctx->stream,
+                     (const double *)scr, nzc, S, Nz, d_out);
+  ORIGIN_LAUNCH_CHECK();
+  return ORIGIN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,578 @@
+// GLR matched-filter correlation  (SURVEY.md 2.2 rows k8-k12).
+//
+// Replaces Correlation_GLR_test (reference muse_origin/lib_origin.py:1070-1217, helpers
+// _convolve_fsf :1027-1043 and _convolve_profile :1046-1060) and the dense lines of
+// ComputeTGLR.run (steps.py:781-793).  The reference evaluates everything with FFTs; the
+// kernels below evaluate the same algebra directly (verified against the
+// reference to 1e-15 by oracle/gen_golden.py "direct algebra"):
+//
+//   cube_fsf[z,y,x] = sum_f sum_{dy,dx} k_fz[dy,dx] (w_f cube)[z, y+dy-c, x+dx-c]
+//   norm_fsf[z,y,x] = sum_f sum_{dy,dx} k_fz[dy,dx]^2 w_f[y+dy-c, x+dx-c]
+//   num_k[z] = sum_j p_k[j] cube_fsf[z + lw_k - j]
+//   den_k[z] = sum_j p_k[j]^2 norm_fsf[z + lw_k - j]
+//   T_k = num_k / sqrt(den_k)   (den_k <= 0 -> 0);  correl = max_k, correl_min = min_k,
+//   profile = first argmax_k
+//
+// with k = PSF - mean(PSF), c = P/2 and zeros outside the cube.
+//
+// Normalisation.  With weights=None, norm_fsf[z,y,x] depends on (y,x) only through how the
+// PSF window is clipped by the field border: P*P "border classes" (class (c,c) = interior).
+// The plan tabulates 1/sqrt(den_k[z]) per class once, so the hot kernel never touches a
+// second cube.  With field weights (or fields smaller than the PSF) norm_fsf is a real
+// cube, produced by the same stencil kernel, and den_k is convolved next to num_k.
+#include <cmath>
+#include <vector>
+
+#include "common.h"
+
+struct origin_glr_plan {
+  origin_ctx *ctx;
+  int Nz, Ny, Nx, nfields, P, K;
+  int mode;   // 0 = border-class table (weights=None), 1 = explicit norm cube
+  int lwmax;  // largest profile half width
+  float *d_k;     // [F][Nz][P][P]  zero-mean PSF
+  float *d_k2;    // [F][Nz][P][P]  its square
+  float *d_w;     // [F][Ny][Nx] or null
+  float *d_taps;  // concatenated profiles (odd lengths; even ones padded with a 0 tap)
+  float *d_taps2; // squares
+  int *d_tap_off; // [K+1]
+  float *d_rden;  // mode 0: [P*P][K][Nz]
+  size_t bytes;
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------------
+// spatial stage: out[z] (+)= corr2(A[z] * B, taps[z]),  zero padded, 'same'
+// block (64,4): tile 64 x 16 outputs, each thread 4 rows (ty, ty+4, ty+8, ty+12)
+// ------------------------------------------------------------------------------------
+constexpr int TX = 64, TY = 16;
+
+__global__ __launch_bounds__(256) void spatial_kernel(const float *__restrict__ A,
+                                                      const float *__restrict__ B,
+                                                      const float *__restrict__ taps, int Ny,
+                                                      int Nx, int P, int accumulate,
+                                                      float *__restrict__ out) {
+  extern __shared__ float tile[];  // [(TY+P-1)][pitch]
+  const int c = P / 2;
+  const int pitch = TX + P - 1;
+  const int rows = TY + P - 1;
+  const int z = blockIdx.z;
+  const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
+  const long S = (long)Ny * Nx;
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  for (int i = tid; i < rows * pitch; i += 256) {
+    const int ry = i / pitch, rx = i - ry * pitch;
+    const int y = y0 + ry - c, x = x0 + rx - c;
+    float v = 0.0f;
+    if (y >= 0 && y < Ny && x >= 0 && x < Nx) {
+      const long p = (long)y * Nx + x;
+      v = A ? A[(long)z * S + p] : 1.0f;
+      if (B) v *= B[p];
+    }
+    tile[i] = v;
+  }
+  __syncthreads();
+  const float *kz = taps + (long)z * P * P;  // uniform -> scalar loads
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  for (int dy = 0; dy < P; ++dy) {
+    const float *r0 = tile + (ty + dy) * pitch + tx;
+    for (int dx = 0; dx < P; ++dx) {
+      const float kv = kz[dy * P + dx];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = fmaf(kv, r0[(4 * r) * pitch + dx], acc[r]);
+    }
+  }
+  const int x = x0 + tx;
+  if (x < Nx) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int y = y0 + ty + 4 * r;
+      if (y < Ny) {
+        const long o = (long)z * S + (long)y * Nx + x;
+        out[o] = accumulate ? out[o] + acc[r] : acc[r];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// border-class normalisation tables (mode 0)
+// ------------------------------------------------------------------------------------
+// normcls[z][cy][cx] = sum over the in-field part of the window of k_z^2
+__global__ __launch_bounds__(256) void norm_classes_kernel(const float *__restrict__ k2, int Nz,
+                                                           int P, double *__restrict__ ncls) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long n = (long)Nz * P * P;
+  if (i >= n) return;
+  const int z = (int)(i / (P * P));
+  const int cls = (int)(i - (long)z * P * P);
+  const int cy = cls / P, cx = cls - cy * P;
+  const int c = P / 2;
+  // class id t <-> window clipped to dy in [max(0,c-t), min(P-1, P-1+c-t)]
+  const int dy0 = max(0, c - cy), dy1 = min(P - 1, P - 1 + c - cy);
+  const int dx0 = max(0, c - cx), dx1 = min(P - 1, P - 1 + c - cx);
+  const float *kz = k2 + (long)z * P * P;
+  double acc = 0.0;
+  for (int dy = dy0; dy <= dy1; ++dy)
+    for (int dx = dx0; dx <= dx1; ++dx) acc += (double)kz[dy * P + dx];
+  ncls[i] = acc;
+}
+
+// rden[cls][k][z] = 1/sqrt(sum_j p_k[j]^2 normcls[z + lw - j][cls])   (0 if den <= 0)
+__global__ __launch_bounds__(256) void rden_kernel(const double *__restrict__ ncls,
+                                                   const float *__restrict__ taps2,
+                                                   const int *__restrict__ tap_off, int K, int Nz,
+                                                   int PP, float *__restrict__ rden) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long n = (long)PP * K * Nz;
+  if (i >= n) return;
+  const int z = (int)(i % Nz);
+  const int k = (int)((i / Nz) % K);
+  const int cls = (int)(i / ((long)Nz * K));
+  const int off = tap_off[k], L = tap_off[k + 1] - off, lw = (L - 1) / 2;
+  double den = 0.0;
+  for (int j = 0; j < L; ++j) {
+    const int zz = z + lw - j;
+    if (zz >= 0 && zz < Nz) den += (double)taps2[off + j] * ncls[(long)zz * PP + cls];
+  }
+  rden[i] = den > 0.0 ? (float)(1.0 / sqrt(den)) : 0.0f;
+}
+
+// ------------------------------------------------------------------------------------
+// spectral stage.  One lane per spaxel, marching z with a register window of the last
+// 2*LWMAX+1 channels; the taps of a profile are wave-uniform (scalar loads), the window
+// index of every FMA is a compile-time constant (switch on the half width).
+// ------------------------------------------------------------------------------------
+template <int LWMAX, int LW>
+__device__ __forceinline__ float conv_lw(const float (&w)[2 * LWMAX + 1],
+                                         const float *__restrict__ p) {
+  float acc = 0.0f;
+#pragma unroll
+  for (int j = 0; j <= 2 * LW; ++j) acc = fmaf(p[j], w[LWMAX + LW - j], acc);
+  return acc;
+}
+
+#define CASE_LW(N)                   \
+  case N:                            \
+    if constexpr (N <= LWMAX) return conv_lw<LWMAX, (N <= LWMAX ? N : 0)>(w, p); \
+    break;
+
+template <int LWMAX>
+__device__ __forceinline__ float conv_sel(const float (&w)[2 * LWMAX + 1],
+                                          const float *__restrict__ p, int lw) {
+  switch (lw) {
+    CASE_LW(0) CASE_LW(1) CASE_LW(2) CASE_LW(3) CASE_LW(4) CASE_LW(5) CASE_LW(6) CASE_LW(7)
+    CASE_LW(8) CASE_LW(9) CASE_LW(10) CASE_LW(11) CASE_LW(12) CASE_LW(13) CASE_LW(14)
+    CASE_LW(15) CASE_LW(16) CASE_LW(17) CASE_LW(18) CASE_LW(19) CASE_LW(20) CASE_LW(21)
+    CASE_LW(22) CASE_LW(23) CASE_LW(24) CASE_LW(25) CASE_LW(26) CASE_LW(27) CASE_LW(28)
+    CASE_LW(29) CASE_LW(30) CASE_LW(31) CASE_LW(32)
+    default:
+      break;
+  }
+  return 0.0f;
+}
+#undef CASE_LW
+
+__device__ __forceinline__ int border_class(int t, int N, int P) {
+  const int c = P / 2;
+  return t < c ? t : (t > N - 1 - c ? P - 1 - (N - 1 - t) : c);
+}
+
+template <int LWMAX, bool GENERAL>
+__global__ __launch_bounds__(256) void spectral_kernel(
+    const float *__restrict__ fsf, const float *__restrict__ norm,
+    const float *__restrict__ rden, const float *__restrict__ taps,
+    const float *__restrict__ taps2, const int *__restrict__ tap_off, int K, int Nz, int Ny,
+    int Nx, int P, int zchunk, const uint8_t *__restrict__ mask, float *__restrict__ correl,
+    uint8_t *__restrict__ profile, float *__restrict__ correl_min,
+    float *__restrict__ part_max, float *__restrict__ part_min) {
+  constexpr int W = 2 * LWMAX + 1;
+  const long S = (long)Ny * Nx;
+  const long s = (long)blockIdx.x * 256 + threadIdx.x;
+  const bool live = s < S;
+  const long sc = live ? s : S - 1;
+  const int z0 = blockIdx.y * zchunk;
+  const int z1 = min(Nz, z0 + zchunk);
+
+  const float *rd = nullptr;
+  if constexpr (!GENERAL) {
+    const int y = (int)(sc / Nx), x = (int)(sc - (long)y * Nx);
+    const int cls = border_class(y, Ny, P) * P + border_class(x, Nx, P);
+    rd = rden + (long)cls * K * Nz;
+  }
+
+  float w[W];
+  float wn[GENERAL ? W : 1];
+#pragma unroll
+  for (int i = 0; i < W; ++i) {
+    const int zz = z0 - LWMAX + i;
+    const bool in = zz >= 0 && zz < Nz;
+    w[i] = in ? fsf[(long)zz * S + sc] : 0.0f;
+    if constexpr (GENERAL) wn[i] = in ? norm[(long)zz * S + sc] : 0.0f;
+  }
+
+  float vmax = -INFINITY, vmin = INFINITY;
+  for (int z = z0; z < z1; ++z) {
+    float best = -INFINITY, worst = INFINITY;
+    int bk = 0;
+    for (int k = 0; k < K; ++k) {
+      const int off = tap_off[k];
+      const int lw = (tap_off[k + 1] - off - 1) >> 1;
+      const float num = conv_sel<LWMAX>(w, taps + off, lw);
+      float T;
+      if constexpr (GENERAL) {
+        const float den = conv_sel<LWMAX>(wn, taps2 + off, lw);
+        T = den > 0.0f ? num / sqrtf(den) : 0.0f;  // den <= 0 -> inf -> T = 0  (lib :1057)
+      } else {
+        T = num * rd[(long)k * Nz + z];
+      }
+      if (T > best) {  // strict '>' : first maximum wins                      (lib :1210)
+        best = T;
+        bk = k;
+      }
+      worst = fminf(worst, T);
+    }
+    const long idx = (long)z * S + sc;
+    if (mask && mask[idx]) {  // correl[mask] = 0 ; profile[mask] = 0   (steps.py:781,788)
+      best = 0.0f;
+      bk = 0;
+    }
+    if (live) {
+      correl[idx] = best;
+      profile[idx] = (uint8_t)bk;
+      correl_min[idx] = worst;
+    }
+    vmax = fmaxf(vmax, best);
+    vmin = fminf(vmin, worst);
+    // slide the window by one channel
+#pragma unroll
+    for (int i = 0; i < W - 1; ++i) {
+      w[i] = w[i + 1];
+      if constexpr (GENERAL) wn[i] = wn[i + 1];
+    }
+    const int zn = z + 1 + LWMAX;
+    const bool in = zn < Nz;
+    w[W - 1] = in ? fsf[(long)zn * S + sc] : 0.0f;
+    if constexpr (GENERAL) wn[W - 1] = in ? norm[(long)zn * S + sc] : 0.0f;
+  }
+  if (live && part_max) {
+    part_max[(long)blockIdx.y * S + s] = vmax;
+    part_min[(long)blockIdx.y * S + s] = vmin;
+  }
+}
+
+// fallback for profiles wider than the register window: plain loops over global memory
+template <bool GENERAL>
+__global__ __launch_bounds__(256) void spectral_generic_kernel(
+    const float *__restrict__ fsf, const float *__restrict__ norm,
+    const float *__restrict__ rden, const float *__restrict__ taps,
+    const float *__restrict__ taps2, const int *__restrict__ tap_off, int K, int Nz, int Ny,
+    int Nx, int P, int zchunk, const uint8_t *__restrict__ mask, float *__restrict__ correl,
+    uint8_t *__restrict__ profile, float *__restrict__ correl_min,
+    float *__restrict__ part_max, float *__restrict__ part_min) {
+  const long S = (long)Ny * Nx;
+  const long s = (long)blockIdx.x * 256 + threadIdx.x;
+  if (s >= S) return;
+  const int z0 = blockIdx.y * zchunk;
+  const int z1 = min(Nz, z0 + zchunk);
+  const float *rd = nullptr;
+  if constexpr (!GENERAL) {
+    const int y = (int)(s / Nx), x = (int)(s - (long)y * Nx);
+    rd = rden + (long)(border_class(y, Ny, P) * P + border_class(x, Nx, P)) * K * Nz;
+  }
+  float vmax = -INFINITY, vmin = INFINITY;
+  for (int z = z0; z < z1; ++z) {
+    float best = -INFINITY, worst = INFINITY;
+    int bk = 0;
+    for (int k = 0; k < K; ++k) {
+      const int off = tap_off[k], L = tap_off[k + 1] - off, lw = (L - 1) >> 1;
+      float num = 0.0f, den = 0.0f;
+      for (int j = 0; j < L; ++j) {
+        const int zz = z + lw - j;
+        if (zz >= 0 && zz < Nz) {
+          num = fmaf(taps[off + j], fsf[(long)zz * S + s], num);
+          if constexpr (GENERAL) den = fmaf(taps2[off + j], norm[(long)zz * S + s], den);
+        }
+      }
+      float T;
+      if constexpr (GENERAL)
+        T = den > 0.0f ? num / sqrtf(den) : 0.0f;
+      else
+        T = num * rd[(long)k * Nz + z];
+      if (T > best) {
+        best = T;
+        bk = k;
+      }
+      worst = fminf(worst, T);
+    }
+    const long idx = (long)z * S + s;
+    if (mask && mask[idx]) {
+      best = 0.0f;
+      bk = 0;
+    }
+    correl[idx] = best;
+    profile[idx] = (uint8_t)bk;
+    correl_min[idx] = worst;
+    vmax = fmaxf(vmax, best);
+    vmin = fminf(vmin, worst);
+  }
+  if (part_max) {
+    part_max[(long)blockIdx.y * S + s] = vmax;
+    part_min[(long)blockIdx.y * S + s] = vmin;
+  }
+}
+
+__global__ __launch_bounds__(256) void maxmap_final_kernel(const float *__restrict__ part_max,
+                                                           const float *__restrict__ part_min,
+                                                           int nzc, long S,
+                                                           float *__restrict__ maxmap,
+                                                           float *__restrict__ minmap) {
+  const long s = (long)blockIdx.x * 256 + threadIdx.x;
+  if (s >= S) return;
+  float a = -INFINITY, b = INFINITY;
+  for (int k = 0; k < nzc; ++k) {
+    a = fmaxf(a, part_max[(long)k * S + s]);
+    b = fminf(b, part_min[(long)k * S + s]);
+  }
+  if (maxmap) maxmap[s] = a;
+  if (minmap) minmap[s] = b;
+}
+
+int spectral_zchunks(origin_ctx *ctx, long S, int Nz, int lwmax) {
+  const long blocks = (S + 255) / 256;
+  long want = ((long)ctx->num_cu * 8 + blocks - 1) / blocks;
+  // the window warm-up reads 2*lwmax extra channels per chunk: keep chunks >= 4 windows
+  const long maxc = std::max(1L, (long)Nz / (8L * lwmax + 8));
+  if (want > maxc) want = maxc;
+  if (want < 1) want = 1;
+  return (int)want;
+}
+
+template <typename T>
+int upload(origin_ctx *ctx, const std::vector<T> &h, T **d, size_t *bytes) {
+  void *p = nullptr;
+  const size_t n = std::max<size_t>(h.size(), 1) * sizeof(T);
+  ORIGIN_HIP(hipMalloc(&p, n));
+  *d = (T *)p;
+  *bytes += n;
+  if (!h.empty()) {
+    ORIGIN_HIP(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice,
+                              ctx->stream));
+    ORIGIN_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  return ORIGIN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int origin_glr_plan_destroy(origin_glr_plan *plan) {
+  if (!plan) return ORIGIN_OK;
+  (void)hipSetDevice(plan->ctx->device);
+  (void)hipStreamSynchronize(plan->ctx->stream);
+  for (void *p : {(void *)plan->d_k, (void *)plan->d_k2, (void *)plan->d_w, (void *)plan->d_taps,
+                  (void *)plan->d_taps2, (void *)plan->d_tap_off, (void *)plan->d_rden})
+    if (p) (void)hipFree(p);
+  delete plan;
+  return ORIGIN_OK;
+}
+
+int origin_glr_plan_create(origin_ctx *ctx, int Nz, int Ny, int Nx, int nfields, int P,
+                           const double *h_psf, const double *h_weights, int K,
+                           const double *h_taps, const int *h_tap_off,
+                           origin_glr_plan **out) {
+  ORIGIN_USE(ctx);
+  ORIGIN_CHECK_ARG(out, "out is null");
+  *out = nullptr;
+  ORIGIN_CHECK_ARG(Nz > 0 && Ny > 0 && Nx > 0, "bad cube shape (%d,%d,%d)", Nz, Ny, Nx);
+  ORIGIN_CHECK_ARG(nfields >= 1 && h_psf, "need at least one PSF");
+  ORIGIN_CHECK_ARG(P >= 1 && (P & 1) && P <= 63, "PSF size %d unsupported (odd, <= 63)", P);
+  ORIGIN_CHECK_ARG(K >= 1 && K <= 255 && h_taps && h_tap_off,
+                   "need 1..255 profiles (profile index is uint8)");
+  ORIGIN_CHECK_ARG(h_weights || nfields == 1, "several fields need weight maps");
+  for (int k = 0; k < K; ++k)
+    ORIGIN_CHECK_ARG(h_tap_off[k + 1] > h_tap_off[k], "profile %d is empty", k);
+
+  origin_glr_plan *pl = new origin_glr_plan();
+  memset(pl, 0, sizeof(*pl));
+  pl->ctx = ctx;
+  pl->Nz = Nz, pl->Ny = Ny, pl->Nx = Nx, pl->nfields = nfields, pl->P = P, pl->K = K;
+  pl->mode = (h_weights == nullptr && Ny >= P && Nx >= P) ? 0 : 1;
+  int rc = ORIGIN_OK;
+#define TRY(x)                       \
+  do {                               \
+    rc = (x);                        \
+    if (rc != ORIGIN_OK) {           \
+      origin_glr_plan_destroy(pl);   \
+      return rc;                     \
+    }                                \
+  } while (0)
+
+  // zero-mean PSF per channel and field: psf -= psf.mean()      (lib_origin.py:1033-1034)
+  const size_t PP = (size_t)P * P;
+  std::vector<float> k((size_t)nfields * Nz * PP), k2(k.size());
+  for (size_t i = 0; i < (size_t)nfields * Nz; ++i) {
+    const double *src = h_psf + i * PP;
+    double m = 0.0;
+    for (size_t j = 0; j < PP; ++j) m += src[j];
+    m /= (double)PP;
+    for (size_t j = 0; j < PP; ++j) {
+      const double v = src[j] - m;
+      k[i * PP + j] = (float)v;
+      k2[i * PP + j] = (float)(v * v);  // psf **= 2                            (lib :1040)
+    }
+  }
+  TRY(upload(ctx, k, &pl->d_k, &pl->bytes));
+  TRY(upload(ctx, k2, &pl->d_k2, &pl->bytes));
+  if (h_weights) {
+    std::vector<float> w((size_t)nfields * Ny * Nx);
+    for (size_t i = 0; i < w.size(); ++i) w[i] = (float)h_weights[i];
+    TRY(upload(ctx, w, &pl->d_w, &pl->bytes));
+  }
+  // profiles: even lengths get a trailing zero tap so that every length is 2*lw+1 with the
+  // reference's centring  startind = (L-1)//2                              (lib :1179-1181)
+  std::vector<float> taps, taps2;
+  std::vector<int> off(K + 1, 0);
+  int lwmax = 0;
+  for (int kk = 0; kk < K; ++kk) {
+    const int L = h_tap_off[kk + 1] - h_tap_off[kk];
+    for (int j = 0; j < L; ++j) {
+      const double v = h_taps[h_tap_off[kk] + j];
+      taps.push_back((float)v);
+      taps2.push_back((float)(v * v));
+    }
+    if (!(L & 1)) {
+      taps.push_back(0.f);
+      taps2.push_back(0.f);
+    }
+    off[kk + 1] = (int)taps.size();
+    lwmax = std::max(lwmax, (off[kk + 1] - off[kk] - 1) / 2);
+  }
+  pl->lwmax = lwmax;
+  // scalar loads may read a few taps past the end of a profile row: pad
+  for (int i = 0; i < 64; ++i) {
+    taps.push_back(0.f);
+    taps2.push_back(0.f);
+  }
+  TRY(upload(ctx, taps, &pl->d_taps, &pl->bytes));
+  TRY(upload(ctx, taps2, &pl->d_taps2, &pl->bytes));
+  TRY(upload(ctx, off, &pl->d_tap_off, &pl->bytes));
+
+  if (pl->mode == 0) {
+    double *ncls = nullptr;
+    const size_t ncls_n = (size_t)Nz * PP;
+    hipError_t e = hipMalloc((void **)&ncls, ncls_n * sizeof(double));
+    if (e != hipSuccess) {
+      origin_set_error("hipMalloc(norm classes): %s", hipGetErrorString(e));
+      origin_glr_plan_destroy(pl);
+      return ORIGIN_E_NOMEM;
+    }
+    const size_t rn = PP * (size_t)K * Nz;
+    e = hipMalloc((void **)&pl->d_rden, rn * sizeof(float));
+    if (e != hipSuccess) {
+      (void)hipFree(ncls);
+      origin_set_error("hipMalloc(rden, %zu bytes): %s", rn * sizeof(float), hipGetErrorString(e));
+      origin_glr_plan_destroy(pl);
+      return ORIGIN_E_NOMEM;
+    }
+    pl->bytes += rn * sizeof(float);
+    hipLaunchKernelGGL(norm_classes_kernel, dim3(cdiv((long)ncls_n, 256)), dim3(256), 0,
+                       ctx->stream, pl->d_k2, Nz, P, ncls);
+    hipLaunchKernelGGL(rden_kernel, dim3(cdiv((long)rn, 256)), dim3(256), 0, ctx->stream, ncls,
+                       pl->d_taps2, pl->d_tap_off, K, Nz, (int)PP, pl->d_rden);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(ncls);
+    if (e != hipSuccess) {
+      origin_set_error("rden kernels: %s", hipGetErrorString(e));
+      origin_glr_plan_destroy(pl);
+      return ORIGIN_E_HIP;
+    }
+  }
+#undef TRY
+  *out = pl;
+  return ORIGIN_OK;
+}
+
+int origin_glr_plan_bytes(origin_glr_plan *plan, size_t *bytes) {
+  ORIGIN_CHECK_ARG(plan && bytes, "null argument");
+  *bytes = plan->bytes;
+  return ORIGIN_OK;
+}
+
+int origin_glr_work_elems(origin_glr_plan *plan, size_t *elems) {
+  ORIGIN_CHECK_ARG(plan && elems, "null argument");
+  const size_t cube = (size_t)plan->Nz * plan->Ny * plan->Nx;
+  const size_t S = (size_t)plan->Ny * plan->Nx;
+  // cube_fsf (+ norm_fsf in mode 1) + maxmap/minmap partials (<= 64 chunks each)
+  *elems = cube * (plan->mode == 1 ? 2 : 1) + 2 * 64 * S;
+  return ORIGIN_OK;
+}
+
+int origin_glr_run(origin_ctx *ctx, origin_glr_plan *pl, const float *d_cube,
+                   const uint8_t *d_mask, float *d_work, float *d_correl,
+                   uint8_t *d_profile, float *d_correl_min, float *d_maxmap,
+                   float *d_minmap) {
+  ORIGIN_USE(ctx);
+  ORIGIN_CHECK_ARG(pl && pl->ctx == ctx, "plan does not belong to this context");
+  ORIGIN_CHECK_ARG(d_cube && d_work && d_correl && d_profile && d_correl_min, "null pointer");
+  const int Nz = pl->Nz, Ny = pl->Ny, Nx = pl->Nx, P = pl->P, K = pl->K;
+  const long S = (long)Ny * Nx;
+  const size_t cube = (size_t)Nz * S;
+  float *fsf = d_work;
+  float *norm = pl->mode == 1 ? d_work + cube : nullptr;
+  float *part = d_work + cube * (pl->mode == 1 ? 2 : 1);
+
+  // ---- spatial stage
+  dim3 sgrid(cdiv(Nx, TX), cdiv(Ny, TY), Nz), sblock(64, 4);
+  const size_t lds = (size_t)(TY + P - 1) * (TX + P - 1) * sizeof(float);
+  for (int f = 0; f < pl->nfields; ++f) {
+    const float *kf = pl->d_k + (size_t)f * Nz * P * P;
+    const float *wf = pl->d_w ? pl->d_w + (size_t)f * S : nullptr;
+    hipLaunchKernelGGL(spatial_kernel, sgrid, sblock, lds, ctx->stream, d_cube, wf, kf, Ny, Nx, P,
+                       f > 0, fsf);
+    if (pl->mode == 1) {
+      const float *k2f = pl->d_k2 + (size_t)f * Nz * P * P;
+      hipLaunchKernelGGL(spatial_kernel, sgrid, sblock, lds, ctx->stream, (const float *)nullptr,
+                         wf, k2f, Ny, Nx, P, f > 0, norm);
+    }
+  }
+  ORIGIN_LAUNCH_CHECK();
+
+  // ---- spectral stage
+  const bool want_maps = d_maxmap || d_minmap;
+  int nzc = spectral_zchunks(ctx, S, Nz, std::max(pl->lwmax, 1));
+  if (nzc > 64) nzc = 64;
+  const int zchunk = cdiv(Nz, nzc);
+  nzc = cdiv(Nz, zchunk);
+  float *pmax = want_maps ? part : nullptr;
+  float *pmin = want_maps ? part + (size_t)nzc * S : nullptr;
+  dim3 grid(cdiv(S, 256), nzc), block(256);
+#define LAUNCH(KERNEL)                                                                        \
+  hipLaunchKernelGGL(KERNEL, grid, block, 0, ctx->stream, fsf, norm, pl->d_rden, pl->d_taps, \
+                     pl->d_taps2, pl->d_tap_off, K, Nz, Ny, Nx, P, zchunk, d_mask, d_correl, \
+                     d_profile, d_correl_min, pmax, pmin)
+  const bool gen = pl->mode == 1;
+  if (pl->lwmax <= 8) {
+    if (gen) LAUNCH((spectral_kernel<8, true>)); else LAUNCH((spectral_kernel<8, false>));
+  } else if (pl->lwmax <= 16) {
+    if (gen) LAUNCH((spectral_kernel<16, true>)); else LAUNCH((spectral_kernel<16, false>));
+  } else if (pl->lwmax <= 32) {
+    if (gen) LAUNCH((spectral_kernel<32, true>)); else LAUNCH((spectral_kernel<32, false>));
+  } else {
+    if (gen) LAUNCH((spectral_generic_kernel<true>)); else LAUNCH((spectral_generic_kernel<false>));
+  }
+#undef LAUNCH
+  ORIGIN_LAUNCH_CHECK();
+  if (want_maps) {
+    hipLaunchKernelGGL(maxmap_final_kernel, dim3(cdiv(S, 256)), dim3(256), 0, ctx->stream, pmax,
+                       pmin, nzc, S, d_maxmap, d_minmap);
+    ORIGIN_LAUNCH_CHECK();
+  }
+  return ORIGIN_OK;
+}
+
+}  // extern "C"

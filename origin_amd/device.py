@@ -1,0 +1,174 @@
+"""Device context and arrays on top of the C ABI (no PyTorch, no numpy-on-GPU library)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+
+
+class Context:
+    """One GPU, one stream (include/origin_hip.h: origin_ctx)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _capi.call("origin_ctx_create", int(device), C.byref(self._h))
+        self.device = int(device)
+
+    # -- lifetime ----------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _capi.load().origin_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def name(self):
+        buf = C.create_string_buffer(256)
+        _capi.call("origin_device_name", self._h, buf, 256)
+        return buf.value.decode()
+
+    def mem_info(self):
+        f, t = C.c_size_t(), C.c_size_t()
+        _capi.call("origin_mem_info", self._h, C.byref(f), C.byref(t))
+        return f.value, t.value
+
+    def sync(self):
+        _capi.call("origin_sync", self._h)
+
+    def stream_ptr(self):
+        s = C.c_void_p()
+        _capi.call("origin_stream", self._h, C.byref(s))
+        return s.value or 0
+
+    # -- timers (HIP events on the context's stream) ---------------------------
+    def timer_start(self, slot):
+        _capi.call("origin_timer_start", self._h, slot)
+
+    def timer_stop(self, slot):
+        _capi.call("origin_timer_stop", self._h, slot)
+
+    def timer_ms(self, slot):
+        ms = C.c_float()
+        _capi.call("origin_timer_ms", self._h, slot, C.byref(ms))
+        return ms.value
+
+    # -- arrays ------------------------------------------------------------
+    def empty(self, shape, dtype):
+        return DeviceArray(self, shape, dtype)
+
+    def zeros(self, shape, dtype):
+        a = DeviceArray(self, shape, dtype)
+        a.fill_bytes(0)
+        return a
+
+    def to_device(self, host, dtype=None):
+        host = np.ascontiguousarray(host, dtype=dtype)
+        a = DeviceArray(self, host.shape, host.dtype)
+        a.upload(host)
+        return a
+
+
+class DeviceArray:
+    """A C-contiguous array in HBM owned by the library's allocator."""
+
+    def __init__(self, ctx, shape, dtype, ptr=None, owner=None):
+        self.ctx = ctx
+        self.shape = tuple(int(s) for s in (shape if np.iterable(shape) else (shape,)))
+        self.dtype = np.dtype(dtype)
+        self.size = int(np.prod(self.shape, dtype=np.int64)) if self.shape else 1
+        self.nbytes = self.size * self.dtype.itemsize
+        self._owner = owner
+        if ptr is None:
+            p = C.c_void_p()
+            _capi.call("origin_malloc", ctx.handle, max(self.nbytes, 16), C.byref(p))
+            self.ptr = p.value
+            self._owned = True
+        else:
+            self.ptr = int(ptr)
+            self._owned = False
+
+    def free(self):
+        if self._owned and self.ptr:
+            try:
+                _capi.call("origin_free", self.ctx.handle, C.c_void_p(self.ptr))
+            finally:
+                self.ptr = 0
+                self._owned = False
+
+    def __del__(self):
+        try:
+            if self._owned and self.ptr and self.ctx.handle.value:
+                self.free()
+        except Exception:
+            pass
+
+    @property
+    def p(self):
+        return C.c_void_p(self.ptr)
+
+    def view(self, offset_elems, shape, dtype=None):
+        """A non-owning view starting `offset_elems` elements into this array."""
+        dtype = self.dtype if dtype is None else np.dtype(dtype)
+        return DeviceArray(self.ctx, shape, dtype,
+                           ptr=self.ptr + int(offset_elems) * self.dtype.itemsize, owner=self)
+
+    def reshape(self, *shape):
+        shape = shape[0] if len(shape) == 1 and np.iterable(shape[0]) else shape
+        v = DeviceArray(self.ctx, shape, self.dtype, ptr=self.ptr, owner=self)
+        assert v.size == self.size
+        return v
+
+    def fill_bytes(self, byte):
+        _capi.call("origin_memset", self.ctx.handle, self.p, int(byte), self.nbytes)
+
+    def upload(self, host):
+        host = np.ascontiguousarray(host, dtype=self.dtype)
+        if host.size != self.size:
+            raise ValueError(f"upload of {host.shape} into {self.shape}")
+        _capi.call("origin_h2d", self.ctx.handle, self.p, host.ctypes.data_as(C.c_void_p),
+                   self.nbytes)
+        return self
+
+    def to_host(self, out=None):
+        if out is None:
+            out = np.empty(self.shape, dtype=self.dtype)
+        assert out.flags.c_contiguous and out.nbytes == self.nbytes
+        _capi.call("origin_d2h", self.ctx.handle, out.ctypes.data_as(C.c_void_p), self.p,
+                   self.nbytes)
+        return out
+
+    def copy_from(self, other):
+        assert other.nbytes == self.nbytes
+        _capi.call("origin_d2d", self.ctx.handle, self.p, other.p, self.nbytes)
+        return self
+
+    def copy(self):
+        return DeviceArray(self.ctx, self.shape, self.dtype).copy_from(self)
+
+    # interop: lets torch.as_tensor / cupy view the buffer without a copy (used for RCCL
+    # collectives through torch.distributed; never needed on a single GPU)
+    @property
+    def __cuda_array_interface__(self):
+        return dict(shape=self.shape, typestr=self.dtype.str, data=(self.ptr, False), version=3,
+                    strides=None)
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    """Process-wide context per device (the reference calls each step synchronously from one
+    thread)."""
+    ctx = _default_ctx.get(device)
+    if ctx is None:
+        ctx = _default_ctx[device] = Context(device)
+    return ctx

@@ -1,0 +1,165 @@
+"""Device-level stage functions: thin, typed wrappers over the C ABI working on
+``DeviceArray`` s.  Everything here is asynchronous on the context's stream unless it
+returns host values."""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from .device import DeviceArray
+
+NULL = C.c_void_p(0)
+
+
+def _p(a):
+    return NULL if a is None else a.p
+
+
+# ------------------------------------------------------------------------- DCT / O2
+def dct_fit(ctx, raw, var, mask, order=10, approx=False, coef=None):
+    Nz, Ny, Nx = raw.shape
+    if coef is None:
+        coef = ctx.empty((order + 1, Ny, Nx), np.float64)
+    _capi.call("origin_dct_fit", ctx.handle, raw.p, var.p, mask.p, Nz, Ny, Nx, int(order),
+               int(bool(approx)), coef.p)
+    return coef
+
+
+def dct_continuum(ctx, coef, Nz, out=None):
+    na, Ny, Nx = coef.shape
+    if out is None:
+        out = ctx.empty((Nz, Ny, Nx), np.float32)
+    _capi.call("origin_dct_continuum", ctx.handle, coef.p, Nz, Ny, Nx, na - 1, out.p)
+    return out
+
+
+def dct_resid_sums(ctx, raw, mask, coef, zsum=None, zcnt=None):
+    Nz, Ny, Nx = raw.shape
+    zsum = ctx.empty((Nz,), np.float64) if zsum is None else zsum
+    zcnt = ctx.empty((Nz,), np.float64) if zcnt is None else zcnt
+    _capi.call("origin_dct_resid_sums", ctx.handle, raw.p, mask.p, coef.p, Nz, Ny, Nx,
+               coef.shape[0] - 1, zsum.p, zcnt.p)
+    return zsum, zcnt
+
+
+def dct_standardize(ctx, raw, var, mask, coef, zsum, zcnt, cube_std=None, cont_dct=None,
+                    want_cont=True, want_images=True):
+    Nz, Ny, Nx = raw.shape
+    cube_std = ctx.empty((Nz, Ny, Nx), np.float32) if cube_std is None else cube_std
+    if cont_dct is None and want_cont:
+        cont_dct = ctx.empty((Nz, Ny, Nx), np.float32)
+    ima_std = ctx.empty((Ny, Nx), np.float32) if want_images else None
+    ima_dct = ctx.empty((Ny, Nx), np.float32) if want_images else None
+    o2 = ctx.empty((Ny, Nx), np.float64) if want_images else None
+    _capi.call("origin_dct_standardize", ctx.handle, raw.p, var.p, mask.p, coef.p, zsum.p,
+               zcnt.p, Nz, Ny, Nx, coef.shape[0] - 1, cube_std.p, _p(cont_dct), _p(ima_std),
+               _p(ima_dct), _p(o2))
+    return dict(cube_std=cube_std, cont_dct=cont_dct, ima_std=ima_std, ima_dct=ima_dct, o2=o2)
+
+
+def o2test(ctx, cube, out=None):
+    Nz = cube.shape[0]
+    S = cube.size // Nz
+    out = ctx.empty(cube.shape[1:], np.float64) if out is None else out
+    _capi.call("origin_o2", ctx.handle, cube.p, Nz, S, out.p)
+    return out
+
+
+# ------------------------------------------------------------------------- GLR
+def prepare_profiles(profiles, pcut=None, pmeansub=True):
+    """Trim / normalise / mean-subtract the dictionary exactly as the reference does
+    (lib_origin.py:1155-1165), in float64 on the host (K small vectors)."""
+    out = []
+    for prof in profiles:
+        prof = np.array(prof, dtype=np.float64)
+        if pcut is not None:
+            lpeak = prof.argmax()
+            lw = np.max(np.abs(np.where(prof >= pcut)[0][[0, -1]] - lpeak))
+            prof = prof[lpeak - lw: lpeak + lw + 1]
+        prof /= np.linalg.norm(prof)
+        if pmeansub:
+            prof -= prof.mean()
+        out.append(prof)
+    return out
+
+
+class GLRPlan:
+    """Device-side constants of a GLR run: zero-mean PSFs, weights, prepared profiles and
+    normalisation tables (include/origin_hip.h: origin_glr_plan)."""
+
+    def __init__(self, ctx, shape, fsf, weights, profiles, pcut=None, pmeansub=True):
+        Nz, Ny, Nx = (int(s) for s in shape)
+        self.ctx, self.shape = ctx, (Nz, Ny, Nx)
+        if weights is None:  # one FSF                         (lib_origin.py:1112-1114)
+            fsf_list, w = [fsf], None
+        else:
+            fsf_list, w = list(fsf), [np.asarray(x, dtype=np.float64) for x in weights]
+            if len(fsf_list) != len(w):
+                raise ValueError("need one weight map per FSF")
+        psf = np.ascontiguousarray(np.stack([np.asarray(f, dtype=np.float64) for f in fsf_list]))
+        if psf.ndim != 4 or psf.shape[1] != Nz or psf.shape[2] != psf.shape[3]:
+            raise ValueError(f"FSF must be (Nz, P, P) per field, got {psf.shape[1:]}")
+        self.P = psf.shape[2]
+        wptr = NULL
+        if w is not None:
+            warr = np.ascontiguousarray(np.stack(w))
+            if warr.shape != (len(fsf_list), Ny, Nx):
+                raise ValueError("weight maps must be (Ny, Nx)")
+            wptr = warr.ctypes.data_as(C.c_void_p)
+        prof = prepare_profiles(profiles, pcut, pmeansub)
+        self.K = len(prof)
+        self.tap_lengths = [len(p) for p in prof]
+        off = np.zeros(self.K + 1, dtype=np.int32)
+        off[1:] = np.cumsum(self.tap_lengths)
+        taps = np.ascontiguousarray(np.concatenate(prof))
+        self._h = C.c_void_p()
+        _capi.call("origin_glr_plan_create", ctx.handle, Nz, Ny, Nx, len(fsf_list), self.P,
+                   psf.ctypes.data_as(C.c_void_p), wptr, self.K,
+                   taps.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p),
+                   C.byref(self._h))
+        n = C.c_size_t()
+        _capi.call("origin_glr_work_elems", self._h, C.byref(n))
+        self.work_elems = n.value
+        _capi.call("origin_glr_plan_bytes", self._h, C.byref(n))
+        self.nbytes = n.value
+        self._work = None
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            _capi.load().origin_glr_plan_destroy(self._h)
+            self._h = C.c_void_p()
+        self._work = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def workspace(self):
+        if self._work is None:
+            self._work = self.ctx.empty((self.work_elems,), np.float32)
+        return self._work
+
+    def run(self, cube, mask=None, correl=None, profile=None, correl_min=None, want_maps=True):
+        ctx = self.ctx
+        Nz, Ny, Nx = self.shape
+        assert cube.shape == self.shape and cube.dtype == np.float32
+        correl = ctx.empty(self.shape, np.float32) if correl is None else correl
+        correl_min = ctx.empty(self.shape, np.float32) if correl_min is None else correl_min
+        profile = ctx.empty(self.shape, np.uint8) if profile is None else profile
+        maxmap = ctx.empty((Ny, Nx), np.float32) if want_maps else None
+        minmap = ctx.empty((Ny, Nx), np.float32) if want_maps else None
+        _capi.call("origin_glr_run", ctx.handle, self._h, cube.p, _p(mask), self.workspace().p,
+                   correl.p, profile.p, correl_min.p, _p(maxmap), _p(minmap))
+        return dict(correl=correl, profile=profile, correl_min=correl_min, maxmap=maxmap,
+                    minmap=minmap)
+
+
+def local_max(ctx, correl, correl_min, mask, size=3, out_max=None, out_min=None):
+    Nz, Ny, Nx = correl.shape
+    out_max = ctx.empty(correl.shape, np.float32) if out_max is None else out_max
+    out_min = ctx.empty(correl.shape, np.float32) if out_min is None else out_min
+    _capi.call("origin_local_max", ctx.handle, correl.p, correl_min.p, _p(mask), Nz, Ny, Nx,
+               int(size), out_max.p, out_min.p)
+    return out_max, out_min

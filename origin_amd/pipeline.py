@@ -1,0 +1,81 @@
+"""Device-resident stages of the hot path, in Step order:
+
+    preprocess  (steps.py:431-450)  ->  pca_threshold (steps.py:610-631)
+    -> greedy_pca (steps.py:681-704) -> tglr (steps.py:770-802)
+
+Cubes stay in HBM between stages (``DeviceArray``); only per-spaxel maps, thresholds and
+what a caller asks for cross PCIe.  ``origin_amd.steps`` wraps these behind the reference's
+Step API, ``bench.py`` times them directly.
+"""
+import numpy as np
+
+from . import kernels
+from .pca import GreedyPCA
+from .thresholds import compute_thresh_gaussfit
+
+
+def preprocess(ctx, raw, var, mask, dct_order=10, dct_approx=False, allreduce=None,
+               want_cont=True):
+    """DCT continuum + standardisation.  raw/var: float32 (Nz,Ny,Nx) DeviceArrays, mask
+    uint8.  ``allreduce``: callable summing a float64 host vector over all ranks (the
+    per-channel mean of steps.py:442 is over the *whole* field when the cube is tiled)."""
+    coef = kernels.dct_fit(ctx, raw, var, mask, dct_order, dct_approx)
+    zsum, zcnt = kernels.dct_resid_sums(ctx, raw, mask, coef)
+    if allreduce is not None:
+        both = np.concatenate([zsum.to_host(), zcnt.to_host()])
+        both = allreduce(both)
+        n = zsum.size
+        zsum.upload(both[:n])
+        zcnt.upload(both[n:])
+    out = kernels.dct_standardize(ctx, raw, var, mask, coef, zsum, zcnt, want_cont=want_cont)
+    coef.free()
+    return out
+
+
+def area_lists(areamap, nbAreas):
+    """Flat spaxel indices of each area, in the column order of ``cube[:, areamap == i]``."""
+    flat = np.asarray(areamap).reshape(-1)
+    order = np.argsort(flat, kind="stable")
+    sorted_lab = flat[order]
+    lo = np.searchsorted(sorted_lab, np.arange(1, nbAreas + 1), side="left")
+    hi = np.searchsorted(sorted_lab, np.arange(1, nbAreas + 1), side="right")
+    return [order[a:b].astype(np.int32) for a, b in zip(lo, hi)]
+
+
+def pca_threshold(o2_map, areamap, nbAreas, pfa_test=0.01, spx=None):
+    """``ComputePCAThreshold.run`` (steps.py:610-631) on the O2 map of cube_std."""
+    spx = area_lists(areamap, nbAreas) if spx is None else spx
+    flat = np.asarray(o2_map, dtype=np.float64).reshape(-1)
+    results = []
+    for s in spx:
+        test = flat[s]
+        results.append((test,) + tuple(compute_thresh_gaussfit(test, pfa_test)))
+    testO2, histO2, binO2, thresO2, meaO2, stdO2 = zip(*results)
+    return dict(testO2=testO2, histO2=histO2, binO2=binO2, thresO2=thresO2, meaO2=meaO2,
+                stdO2=stdO2)
+
+
+def greedy_pca(ctx, cube_std, areamap, nbAreas, thresholds, testO2, Noise_population=50,
+               itermax=100, spx=None, inplace=False):
+    """``Compute_GreedyPCA_area`` (lib_origin.py:769-821) on a device cube.  Returns
+    (cube_faint DeviceArray, mapO2 (Ny,Nx) float64, nstop, driver)."""
+    Nz, Ny, Nx = cube_std.shape
+    spx = area_lists(areamap, nbAreas) if spx is None else spx
+    F = cube_std if inplace else cube_std.copy()      # cube_faint = cube_std.copy() (:799)
+    drv = GreedyPCA(ctx)
+    maps, nstop = drv.run(F, spx, testO2, [float(t) for t in thresholds], Noise_population,
+                          itermax)
+    mapO2 = np.zeros(Ny * Nx)
+    for s, m in zip(spx, maps):
+        mapO2[s] = m
+    return F, mapO2.reshape(Ny, Nx), nstop, drv
+
+
+def tglr(ctx, plan, cube_faint, mask, size=3, want_local=True):
+    """``ComputeTGLR.run`` dense part (steps.py:770-802): GLR + mask glue + maps + local
+    maxima, all on the device."""
+    out = plan.run(cube_faint, mask=mask, want_maps=True)
+    if want_local:
+        lmax, lmin = kernels.local_max(ctx, out["correl"], out["correl_min"], mask, size)
+        out["local_max"], out["local_min"] = lmax, lmin
+    return out

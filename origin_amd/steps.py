@@ -1,0 +1,465 @@
+"""Step seam (tier B2): the four hot steps of the reference's
+``muse_origin/steps.py`` -- ``Preprocessing`` (:355), ``ComputePCAThreshold`` (:572),
+``ComputeGreedyPCA`` (:634), ``ComputeTGLR`` (:707) -- with the same ``name``, ``desc``,
+``require``, ``DataObj`` labels and ``run`` keyword names/defaults, running on the GPU.
+
+Two ways to use them:
+
+* ``register()``: when ``muse_origin`` is importable, subclasses of the reference's own
+  step classes (only ``run`` overridden) are swapped into ``muse_origin.steps.STEPS``
+  before ``ORIGIN(...)`` is constructed (origin.py:193 reads that list).
+* stand-alone: ``SimpleOrig`` carries exactly the attributes the four ``run`` bodies read
+   and the minimal ``Step`` machinery below (status, ``require`` check,
+  parameter recording, runtime) mirrors reference steps.py:101-352 so tests and the
+  benchmark drive the same code without mpdaf.
+
+Cubes produced by one step stay in HBM for the next one (``LazyCube``); a host float64
+copy is only made when somebody reads ``._data``.
+"""
+import inspect
+import logging
+import time
+from collections import OrderedDict
+from datetime import datetime
+from enum import Enum
+
+import numpy as np
+from scipy import ndimage as ndi
+from scipy.signal import fftconvolve
+
+from . import kernels, pipeline
+from .device import DeviceArray, default_context
+from .thresholds import compute_thresh_gaussfit
+
+__all__ = ('Preprocessing', 'ComputePCAThreshold', 'ComputeGreedyPCA', 'ComputeTGLR',
+           'Status', 'Step', 'DataObj', 'SimpleOrig', 'STEPS', 'register')
+
+
+# ----------------------------------------------------------------------------- containers
+class LazyCube:
+    """What a DataObj holds when mpdaf is absent: a device array plus an on-demand host
+    copy with the dtype the reference would have produced.  ``._data`` / ``.data`` mirror
+    the mpdaf attribute the ``run`` bodies read (e.g. steps.py:617, :688, :771)."""
+
+    def __init__(self, dev=None, host=None, dtype=np.float64):
+        self.dev, self._host, self._dtype = dev, host, dtype
+
+    @property
+    def _data(self):
+        if self._host is None:
+            self._host = self.dev.to_host().astype(self._dtype, copy=False)
+        return self._host
+
+    data = _data
+
+    @property
+    def shape(self):
+        return self.dev.shape if self.dev is not None else self._host.shape
+
+    def device(self, ctx, dtype=np.float32):
+        if self.dev is None:
+            self.dev = ctx.to_device(self._host, dtype)
+        return self.dev
+
+
+def _wrap(ctx, value, dtype=np.float32):
+    """DeviceArray for anything cube-like a step may be handed (LazyCube, mpdaf object with
+    ``_data``, ndarray)."""
+    if isinstance(value, LazyCube):
+        return value.device(ctx, dtype)
+    if isinstance(value, DeviceArray):
+        return value
+    data = getattr(value, "_data", value)
+    return ctx.to_device(np.asarray(data), dtype)
+
+
+# ----------------------------------------------------------------------------- framework
+class Status(Enum):
+    """Step processing status (reference steps.py:112-118)."""
+    NOTRUN = 'not run yet'
+    RUN = 'run'
+    DUMPED = 'dumped outputs'
+    FAILED = 'failed'
+
+
+class DataObj:
+    """Descriptor naming a step output and its kind (reference steps.py:121-163); lazy
+    reload from disk is the reference's job and is not reproduced here."""
+
+    def __init__(self, kind):
+        self.kind = kind
+
+    def __get__(self, obj, owner=None):
+        if obj is None:
+            return
+        return obj.__dict__.get(self.label)
+
+    def __set__(self, obj, val):
+        obj.__dict__[self.label] = val
+
+
+class StepMeta(type):
+    """Sets DataObj labels and collects them in ``_dataobjs`` (reference steps.py:166-185)."""
+
+    def __new__(cls, name, bases, attrs):
+        descr = []
+        for base in bases:
+            descr.extend(getattr(base, '_dataobjs', []))
+        for n, inst in attrs.items():
+            if isinstance(inst, DataObj):
+                inst.label = n
+                descr.append((n, inst.kind))
+        attrs['_dataobjs'] = descr
+        return super().__new__(cls, name, bases, attrs)
+
+
+class Step(metaclass=StepMeta):
+    """Processing step (reference steps.py:188-299): ``__call__`` records the parameters,
+    checks ``require``, runs, sets the status and the runtime."""
+
+    name = None
+    desc = None
+    require = None
+
+    def __init__(self, orig, idx, param):
+        self.logger = logging.getLogger(__name__)
+        self.orig = orig
+        self.idx = idx
+        self.method_name = 'step%02d_%s' % (idx, self.name)
+        self.meta = param.setdefault(self.name, {})
+        self.meta.setdefault('stepidx', idx)
+        self.param = self.meta.setdefault('params', {})
+
+    def __repr__(self):
+        return 'Step {:02d}: <{}(status: {})>'.format(self.idx, self.__class__.__name__,
+                                                      self.status.name)
+
+    def _loginfo(self, *args):
+        self.logger.info(*args)
+
+    def _logdebug(self, *args):
+        self.logger.debug(*args)
+
+    def _logwarning(self, *args):
+        self.logger.warning(*args)
+
+    @property
+    def status(self):
+        return self.meta.get('status', Status.NOTRUN)
+
+    @status.setter
+    def status(self, val):
+        self.meta['status'] = val
+
+    def __call__(self, *args, **kwargs):
+        t0 = time.time()
+        self._loginfo('Step %02d - %s', self.idx, self.desc)
+        sig = inspect.signature(self.run)
+        for name, p in sig.parameters.items():
+            if name == 'orig':
+                continue
+            self.param[name] = kwargs.get(name, p.default)
+        if self.require is not None:
+            for req in self.require:
+                step = self.orig.steps[req]
+                if step.status not in (Status.RUN, Status.DUMPED):
+                    raise RuntimeError(f'step {step.idx:02d} must be run before')
+        try:
+            self.run(self.orig, *args, **kwargs)
+        except Exception:
+            self.status = Status.FAILED
+            raise
+        else:
+            self.status = Status.RUN
+        self.meta['runtime'] = tot = time.time() - t0
+        self.meta['execution_date'] = datetime.now().isoformat()
+        self._loginfo('%02d Done - %.2f sec.', self.idx, tot)
+
+    # without mpdaf the outputs stay LazyCube / ndarray
+    def store_cube(self, name, data, **kwargs):
+        setattr(self, name, data)
+
+    def store_image(self, name, data, **kwargs):
+        setattr(self, name, data)
+
+
+# ----------------------------------------------------------------------------- helpers
+def compute_segmap_gauss(data, pfa, fwhm_fsf=0, bins='fd'):
+    """2-D host heuristic of reference lib_origin.py:243-280 (outside the hot path; kept so
+    that ``Preprocessing`` still fills ``segmap_cont`` / ``segmap_merged``)."""
+    histO2, frecO2, gamma, mea, std = compute_thresh_gaussfit(data, pfa, bins=bins)
+    mask = data > gamma
+    mask = ndi.binary_erosion(mask, border_value=1, iterations=1)
+    mask = ndi.binary_dilation(mask, iterations=1)
+    if fwhm_fsf > 0:
+        fwhm_pix = int(fwhm_fsf) // 2
+        size = fwhm_pix * 2 + 1
+        disc = np.hypot(*list(np.mgrid[:size, :size] - fwhm_pix)) < fwhm_pix
+        mask = fftconvolve(mask, disc, mode='same')
+        mask = mask > 1e-9
+    return gamma, ndi.label(mask)[0]
+
+
+def _ctx_of(orig):
+    ctx = getattr(orig, 'hip_ctx', None)
+    if ctx is None:
+        ctx = default_context(0)
+        try:
+            orig.hip_ctx = ctx
+        except Exception:
+            pass
+    return ctx
+
+
+def _cache(orig):
+    c = orig.__dict__.get('_hip_cache')
+    if c is None:
+        c = orig.__dict__['_hip_cache'] = {}
+    return c
+
+
+def _inputs_on_device(orig, ctx):
+    """cube_raw / var / mask uploaded once per session (origin.py:262-274)."""
+    c = _cache(orig)
+    if 'raw' not in c:
+        c['raw'] = _wrap(ctx, orig.cube_raw)
+        c['var'] = _wrap(ctx, orig.var)
+        m = orig.mask
+        m = np.zeros(c['raw'].shape, np.uint8) if m is None or m is np.ma.nomask else m
+        c['mask'] = _wrap(ctx, np.asarray(m, dtype=np.uint8), np.uint8)
+    return c['raw'], c['var'], c['mask']
+
+
+# ----------------------------------------------------------------------------- run bodies
+class _HipStepMixin:
+    """Store / fetch cubes so that they stay in HBM between steps.  Under the stand-alone
+    ``Step`` the DataObj holds a ``LazyCube``; under the reference's ``Step`` (register())
+    ``store_cube`` builds an mpdaf Cube from a host array as usual."""
+
+    def _put_cube(self, orig, name, dev, dtype=np.float64):
+        _cache(orig)[name] = dev
+        if isinstance(self, Step):
+            self.store_cube(name, LazyCube(dev, dtype=dtype))
+        else:
+            self.store_cube(name, dev.to_host().astype(dtype, copy=False))
+
+    def _get_cube(self, orig, ctx, name):
+        dev = _cache(orig).get(name)
+        if dev is not None:
+            return dev
+        return _wrap(ctx, getattr(orig, name))
+
+
+class _PreprocessingRun(_HipStepMixin):
+    name = 'preprocessing'
+    desc = 'Preprocessing'
+
+    def run(self, orig, dct_order=10, dct_approx=False, pfasegcont=0.01, pfasegres=0.01,
+            local_max_size=3, bins='fd'):
+        ctx = _ctx_of(orig)
+        raw, var, mask = _inputs_on_device(orig, ctx)
+        self._loginfo('DCT computation')
+        out = pipeline.preprocess(ctx, raw, var, mask, dct_order, dct_approx,
+                                  allreduce=getattr(orig, 'allreduce', None))
+        self._loginfo('Std signal saved in self.cube_std and self.ima_std')
+        self._put_cube(orig, 'cube_std', out['cube_std'])
+        ima_std = out['ima_std'].to_host().astype(np.float64)
+        self.store_image('ima_std', ima_std)
+
+        self._loginfo('Compute local maximum of std cube values')
+        lmax, lmin = kernels.local_max(ctx, out['cube_std'], out['cube_std'], mask,
+                                       local_max_size)
+        self._put_cube(orig, 'cube_std_local_max', lmax)
+        self._put_cube(orig, 'cube_std_local_min', lmin)
+
+        self._loginfo('DCT continuum saved in self.cont_dct and self.ima_dct')
+        self._put_cube(orig, 'cont_dct', out['cont_dct'], np.float32)
+        self.store_image('ima_dct', out['ima_dct'].to_host())
+        o2 = out['o2'].to_host()
+        _cache(orig)['o2_std'] = o2
+
+        mean_fwhm = int(np.ceil(np.mean(orig.FWHM_PSF)))
+        self._loginfo('Segmentation based on the continuum')
+        # sum_z cont_dct^2 is a per-spaxel reduction of the device cube
+        map1 = np.log10(kernels.o2test(ctx, out['cont_dct']).to_host() * raw.shape[0])
+        thresh, map_cont = compute_segmap_gauss(map1, pfasegcont, mean_fwhm, bins=bins)
+        self.store_image('segmap_cont', map_cont)
+        self._loginfo('Segmentation based on the residual')
+        thresh, map_res = compute_segmap_gauss(o2, pfasegres, mean_fwhm, bins=bins)
+        self._loginfo('Merging both maps')
+        segmap, nlabels = ndi.label((map_cont > 0) | (map_res > 0))
+        self.store_image('segmap_merged', segmap)
+
+
+class _ComputePCAThresholdRun(_HipStepMixin):
+    name = 'compute_PCA_threshold'
+    desc = 'PCA threshold computation'
+    require = ('preprocessing', 'areas')
+
+    def run(self, orig, pfa_test=0.01):
+        ctx = _ctx_of(orig)
+        o2 = _cache(orig).get('o2_std')
+        if o2 is None:  # session reloaded: recompute the O2 map from cube_std
+            o2 = kernels.o2test(ctx, self._get_cube(orig, ctx, 'cube_std')).to_host()
+        areamap = getattr(orig.areamap, '_data', orig.areamap)
+        res = pipeline.pca_threshold(o2, areamap, orig.nbAreas, pfa_test)
+        for i in range(orig.nbAreas):
+            self._loginfo('Area %d, estimation mean/std/threshold: %f/%f/%f', i + 1,
+                          res['meaO2'][i], res['stdO2'][i], res['thresO2'][i])
+        orig.testO2, orig.histO2, orig.binO2 = res['testO2'], res['histO2'], res['binO2']
+        self.thresO2, self.meaO2, self.stdO2 = res['thresO2'], res['meaO2'], res['stdO2']
+
+
+class _ComputeGreedyPCARun(_HipStepMixin):
+    name = 'compute_greedy_PCA'
+    desc = 'Greedy PCA computation'
+    require = ('preprocessing', 'areas', 'compute_PCA_threshold')
+
+    def run(self, orig, Noise_population=50, itermax=100, threshold_list=None):
+        ctx = _ctx_of(orig)
+        thr = orig.thresO2 if threshold_list is None else threshold_list
+        orig.param['threshold_list'] = thr
+        self._loginfo('   - List of threshold = %s', ' '.join("%.2f" % x for x in thr))
+        self._loginfo('Compute greedy PCA on each zone')
+        areamap = getattr(orig.areamap, '_data', orig.areamap)
+        faint, mapO2, nstop, drv = pipeline.greedy_pca(
+            ctx, self._get_cube(orig, ctx, 'cube_std'), areamap, orig.nbAreas, thr, orig.testO2,
+            Noise_population, itermax)
+        if nstop > 0:
+            self._logwarning('The iterations have been reached the limit of %d in %d cases',
+                             itermax, nstop)
+        self._put_cube(orig, 'cube_faint', faint)
+        self.store_image('mapO2', mapO2)
+
+
+class _ComputeTGLRRun(_HipStepMixin):
+    name = 'compute_TGLR'
+    desc = 'GLR test'
+    require = ('compute_greedy_PCA',)
+
+    def run(self, orig, size=3, ncpu=1, pcut=1e-8, pmeansub=True):
+        ctx = _ctx_of(orig)
+        _, _, mask = _inputs_on_device(orig, ctx)
+        faint = self._get_cube(orig, ctx, 'cube_faint')
+        self._loginfo('Correlation')
+        plan = kernels.GLRPlan(ctx, faint.shape, orig.PSF, orig.wfields, orig.profiles, pcut,
+                               pmeansub)
+        try:
+            out = pipeline.tglr(ctx, plan, faint, mask, size)
+            ctx.sync()
+        finally:
+            plan.close()
+        self._put_cube(orig, 'cube_correl', out['correl'])
+        self._put_cube(orig, 'cube_correl_min', out['correl_min'])
+        self._put_cube(orig, 'cube_profile', out['profile'], np.uint8)
+        self.store_image('maxmap', out['maxmap'].to_host().astype(np.float64))
+        self.store_image('minmap', out['minmap'].to_host().astype(np.float64))
+        self._put_cube(orig, 'cube_local_max', out['local_max'])
+        self._put_cube(orig, 'cube_local_min', out['local_min'])
+
+
+# ----------------------------------------------------------------------------- stand-alone
+class Preprocessing(_PreprocessingRun, Step):
+    cube_std = DataObj('cube')
+    cont_dct = DataObj('cube')
+    ima_std = DataObj('image')
+    ima_dct = DataObj('image')
+    segmap_cont = DataObj('image')
+    segmap_merged = DataObj('image')
+    cube_std_local_min = DataObj('cube')
+    cube_std_local_max = DataObj('cube')
+
+
+class Areas(Step):
+    """Stand-in for ``CreateAreas`` (reference steps.py:492-569, out of scope): takes the
+    area map it is given."""
+    name = 'areas'
+    desc = 'Areas creation'
+    areamap = DataObj('image')
+
+    def run(self, orig, areamap=None, nbAreas=None):
+        if areamap is None:
+            areamap = (np.sum(~np.asarray(orig.mask, dtype=bool), axis=0) > 0).astype(int)
+        areamap = np.asarray(areamap).astype(int)
+        labels = np.unique(areamap)
+        nb = len(labels) - 1 if 0 in labels else len(labels)
+        orig.param['nbareas'] = nb if nbAreas is None else nbAreas
+        self.store_image('areamap', LazyCube(host=areamap, dtype=int))
+
+
+class ComputePCAThreshold(_ComputePCAThresholdRun, Step):
+    thresO2 = DataObj('array')
+    meaO2 = DataObj('array')
+    stdO2 = DataObj('array')
+
+
+class ComputeGreedyPCA(_ComputeGreedyPCARun, Step):
+    cube_faint = DataObj('cube')
+    mapO2 = DataObj('image')
+
+
+class ComputeTGLR(_ComputeTGLRRun, Step):
+    cube_correl = DataObj('cube')
+    cube_correl_min = DataObj('cube')
+    cube_profile = DataObj('cube')
+    cube_local_min = DataObj('cube')
+    cube_local_max = DataObj('cube')
+    maxmap = DataObj('image')
+    minmap = DataObj('image')
+
+
+STEPS = [Preprocessing, Areas, ComputePCAThreshold, ComputeGreedyPCA, ComputeTGLR]
+
+
+class SimpleOrig:
+    """Stand-in for the ``ORIGIN`` session object carrying exactly what the four hot ``run``
+    bodies read: cube_raw, var, mask, FWHM_PSF, PSF, wfields, profiles,
+    nbAreas, areamap, param, testO2, thresO2, cube_std, cube_faint.  Steps are bound as
+    ``stepNN_name`` callables like origin.py:193-208 does."""
+
+    def __init__(self, cube_raw, var, mask, PSF, profiles, FWHM_PSF=3.3, wfields=None,
+                 param=None, ctx=None):
+        self.cube_raw, self.var, self.mask = cube_raw, var, mask
+        self.PSF, self.wfields, self.profiles = PSF, wfields, profiles
+        self.FWHM_PSF = FWHM_PSF
+        self.param = param or {}
+        self.wave = self.wcs = None
+        self.testO2 = self.histO2 = self.binO2 = None
+        self.hip_ctx = ctx or default_context(0)
+        self.steps = OrderedDict()
+        self._dataobjs = {}
+        for i, cls in enumerate(STEPS, start=1):
+            step = cls(self, i, self.param)
+            self.steps[step.name] = step
+            self.__dict__[step.method_name] = step
+            for name, _ in step._dataobjs:
+                self._dataobjs[name] = step
+
+    def __getattr__(self, name):
+        d = self.__dict__.get('_dataobjs', {})
+        if name in d:
+            return getattr(d[name], name)
+        raise AttributeError(f"unknown attribute {name}")
+
+    @property
+    def nbAreas(self):
+        return self.param.get('nbareas')
+
+
+# ----------------------------------------------------------------------------- register
+def register():
+    """Swap GPU versions of the four hot steps into ``muse_origin.steps.STEPS``.  Call
+    before constructing ``ORIGIN``.  Returns the list of replaced class names."""
+    import muse_origin.steps as ref  # noqa: raises ImportError when the reference is absent
+
+    replaced = []
+    for mixin, refname in ((_PreprocessingRun, 'Preprocessing'),
+                           (_ComputePCAThresholdRun, 'ComputePCAThreshold'),
+                           (_ComputeGreedyPCARun, 'ComputeGreedyPCA'),
+                           (_ComputeTGLRRun, 'ComputeTGLR')):
+        base = getattr(ref, refname)
+        new = type(base)(refname, (mixin, base), {'__doc__': base.__doc__})
+        ref.STEPS[ref.STEPS.index(base)] = new
+        setattr(ref, refname, new)
+        replaced.append(refname)
+    return replaced

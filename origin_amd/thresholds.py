@@ -1,0 +1,73 @@
+"""Host-side threshold estimation of the O2 test.
+
+``compute_thresh_gaussfit`` works on one O2 value per spaxel of an area (~1e4 numbers):
+sigma-clip, Freedman-Diaconis histogram, Levenberg-Marquardt Gaussian fit of the left
+half.  It is scalar work on a tiny vector and stays on the host by design; the dense part
+(the O2 values themselves) comes from the GPU.  Follows the reference
+muse_origin/lib_origin.py:977-1024, with astropy's ``sigma_clip`` / ``LevMarLSQFitter`` /
+``Gaussian1D`` restated on NumPy/SciPy (astropy is not needed at run time).
+"""
+import numpy as np
+from scipy import optimize, stats
+
+_SIGMA_TO_FWHM = 2.0 * np.sqrt(2.0 * np.log(2.0))
+
+
+def sigma_clip_compressed(data, sigma, maxiters=5):
+    """``astropy.stats.sigma_clip(data, sigma).compressed()`` with astropy's defaults
+    (median centre, std spread, 5 iterations), lib_origin.py:1000-1001."""
+    d = np.asarray(data, dtype=float).ravel()
+    kept = d[np.isfinite(d)]
+    lo, hi = -np.inf, np.inf
+    changed, it = 1, 0
+    while changed and it < maxiters:
+        it += 1
+        n = kept.size
+        cen, sd = np.median(kept), np.std(kept)
+        lo, hi = cen - sd * sigma, cen + sd * sigma
+        kept = kept[(kept >= lo) & (kept <= hi)]
+        changed = n - kept.size
+    return d[(d >= lo) & (d <= hi)]
+
+
+def fit_gauss1d(x, y, amplitude, mean, stddev):
+    """Levenberg-Marquardt fit of amplitude*exp(-(x-mean)^2/(2 stddev^2)) with the analytic
+    Jacobian (what LevMarLSQFitter does with Gaussian1D.fit_deriv, lib_origin.py:1014-1018)."""
+    tiny = float(np.finfo(np.float32).tiny)
+
+    def unpack(p):
+        return p[0], p[1], max(p[2], tiny)
+
+    def resid(p):
+        a, m, s = unpack(p)
+        return a * np.exp(-0.5 * (x - m) ** 2 / s ** 2) - y
+
+    def jac(p):
+        a, m, s = unpack(p)
+        g = np.exp(-0.5 / s ** 2 * (x - m) ** 2)
+        return [g, a * g * (x - m) / s ** 2, a * g * (x - m) ** 2 / s ** 3]
+
+    p, _ = optimize.leastsq(resid, [amplitude, mean, stddev], Dfun=jac, col_deriv=True,
+                            maxfev=100, epsfcn=np.sqrt(np.finfo(float).eps), xtol=1e-7)
+    return unpack(p)
+
+
+def compute_thresh_gaussfit(data, pfa, bins='fd', sigclip=10):
+    """Same signature and return tuple as the reference (lib_origin.py:977-1024):
+    histO2, frecO2, thresO2 (python float), mea, std."""
+    data = np.asarray(data, dtype=float)
+    data = data[data > 0]
+    data = sigma_clip_compressed(data, sigclip)
+    histO2, frecO2 = np.histogram(data, bins=bins, density=True)
+    ind = np.argmax(histO2)
+    mod = frecO2[ind]
+    ind2 = np.argmin((histO2[ind] / 2 - histO2[:ind]) ** 2)
+    fwhm = mod - frecO2[ind2]
+    sigma = fwhm / np.sqrt(2 * np.log(2))
+    coef = stats.norm.ppf(pfa)
+    x = (frecO2[1:] + frecO2[:-1]) / 2
+    xcut = mod + _SIGMA_TO_FWHM * sigma / 2
+    ksel = x < xcut
+    _, mea, std = fit_gauss1d(x[ksel], histO2[ksel], histO2.max(), mod, sigma)
+    thresO2 = float(mea - std * coef)
+    return histO2, frecO2, thresO2, mea, std

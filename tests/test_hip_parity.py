@@ -1,0 +1,242 @@
+"""GPU parity tests: the HIP path (through the ctypes C ABI) against the golden vectors
+recorded from the reference and against the CPU oracle on the same seeded inputs.
+
+Tolerances (fp32 device storage vs the float64 reference), stated per test:
+  cube_std / cont : |d| <= 1e-5 * max(1, |x|)                       
+  cube_faint      : rel-Frobenius <= 2e-6, max-abs <= 1e-4, mapO2 and nstop identical
+  GLR             : |dT| <= 1e-4, argmax-profile mismatches <= 0.01 % of voxels
+  local maxima    : bit exact on identical float32 inputs
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import cpu_ref
+from oracle import golden_cases as gc
+
+pytestmark = pytest.mark.gpu
+
+
+def load(name):
+    return np.load(os.path.join(gc.GOLDEN_DIR, name + ".npz"))
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import origin_amd.lib_origin as lib
+    return lib
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from origin_amd.device import default_context
+    return default_context(0)
+
+
+def assert_close_scaled(a, b, tol):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    err = np.abs(a - b) / np.maximum(1.0, np.abs(b))
+    assert err.max() <= tol, f"max scaled error {err.max():.3e} > {tol:.1e}"
+
+
+# ------------------------------------------------------------------------------- DCT
+@pytest.mark.parametrize("approx", [False, True])
+def test_dct_residual_golden(hip, approx):
+    g = load("g1_dct")
+    inp = gc.g1_inputs()
+    cont = hip.dct_residual(inp["raw"], 10, inp["var"], approx, inp["mask"])
+    ref = g["cont_approx" if approx else "cont"]
+    assert cont.shape == ref.shape and cont.dtype == np.float64
+    assert_close_scaled(cont, ref, 1e-5)
+
+
+@pytest.mark.parametrize("approx", [False, True])
+def test_preprocessing_golden(ctx, approx):
+    from origin_amd import pipeline
+    g = load("g2_preproc_approx" if approx else "g2_preproc")
+    inp = gc.g1_inputs()
+    raw = ctx.to_device(inp["raw"], np.float32)
+    var = ctx.to_device(inp["var"], np.float32)
+    mask = ctx.to_device(inp["mask"].astype(np.uint8))
+    out = pipeline.preprocess(ctx, raw, var, mask, 10, approx)
+    cube_std = out["cube_std"].to_host()
+    assert_close_scaled(cube_std, g["cube_std"], 1e-5)
+    assert np.all(cube_std[inp["mask"]] == 0)                  # data[mask] = 0
+    assert_close_scaled(out["cont_dct"].to_host(), g["cont_dct"], 1e-5)
+    assert_close_scaled(out["ima_std"].to_host(), g["ima_std"], 1e-5)
+    assert_close_scaled(out["ima_dct"].to_host(), g["ima_dct"], 1e-5)
+    assert_close_scaled(out["o2"].to_host(), g["o2"], 1e-5)
+
+
+def test_o2test_matches_numpy(hip):
+    rng = np.random.default_rng(3)
+    cube = rng.standard_normal((301, 7, 13)).astype(np.float32)
+    got = hip.O2test(cube)
+    assert got.shape == (7, 13)
+    np.testing.assert_allclose(got, np.mean(cube.astype(float) ** 2, axis=0), rtol=1e-12)
+    # (Nz, S) form used by Compute_PCA_threshold
+    got2 = hip.O2test(cube.reshape(301, -1))
+    np.testing.assert_allclose(got2, got.ravel(), rtol=0, atol=0)
+
+
+def test_dct_exact_on_dct_spectra(hip):
+    """Property: a spectrum lying in the span of the atoms is its own continuum."""
+    Nz, Ny, Nx = 3681, 5, 70
+    rng = np.random.default_rng(5)
+    D = cpu_ref.DCTMAT(Nz, 10)
+    coef = rng.standard_normal((11, Ny * Nx)) * 10
+    raw = (D @ coef).reshape(Nz, Ny, Nx).astype(np.float32)
+    var = (1 + rng.random((Nz, Ny, Nx))).astype(np.float32)
+    mask = np.zeros((Nz, Ny, Nx), bool)
+    for approx in (False, True):
+        cont = hip.dct_residual(raw, 10, var, approx, mask)
+        assert np.max(np.abs(cont - raw)) <= 2e-5 * np.max(np.abs(raw))
+
+
+# ------------------------------------------------------------------------------- PCA
+def test_gram_mfma_matches_numpy(ctx):
+    """G = X^T X from v_mfma_f64_16x16x4_f64 with a deliberately asymmetric X."""
+    import ctypes as C
+    from origin_amd import _capi
+    rng = np.random.default_rng(11)
+    Nz, n = 517, 77
+    ld = (n + 15) // 16 * 16
+    X = np.zeros((Nz, ld))
+    X[:, :n] = rng.standard_normal((Nz, n)) * (1 + np.arange(n))[None, :]
+    dX = ctx.to_device(X)
+    T = (ld + 31) // 32
+    iu, ju = np.triu_indices(T)
+    d_ti = ctx.to_device(iu.astype(np.int32))
+    d_tj = ctx.to_device(ju.astype(np.int32))
+    d_ta = ctx.to_device(np.zeros(len(iu), np.int32))
+    d_ld = ctx.to_device(np.array([ld], np.int32))
+    d_off = ctx.to_device(np.array([0, 0], np.int64))
+    G = ctx.zeros((ld, ld), np.float64)
+    _capi.call("origin_pca_gram", ctx.handle, dX.p, d_off.p, d_ld.p, Nz, len(iu), d_ti.p, d_tj.p,
+               d_ta.p, ld * ld, G.p, d_off.p)
+    ref = X.T @ X
+    got = G.to_host()
+    assert np.max(np.abs(got - ref)) <= 1e-12 * np.max(np.abs(ref))
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c"])
+def test_greedy_pca_golden(hip, name):
+    g = load("g4_pca")
+    cube = gc.g4_inputs()[name]
+    faint, mapO2, nstop = hip.Compute_GreedyPCA(cube, g[name + "_test"],
+                                                float(g[name + "_thr"][0]), 50, 100)
+    ref = g[name + "_faint"]
+    assert np.array_equal(mapO2, g[name + "_mapO2"])
+    assert nstop == int(g[name + "_nstop"])
+    assert np.linalg.norm(faint - ref) <= 2e-6 * np.linalg.norm(ref)
+    assert np.max(np.abs(faint - ref)) <= 1e-4
+
+
+def test_greedy_pca_itermax_guard(hip):
+    g = load("g4_pca")
+    cube = gc.g4_inputs()["a"]
+    faint, mapO2, nstop = hip.Compute_GreedyPCA(cube, g["a_test"], float(g["a_thr"][0]), 50, 2)
+    assert nstop == 1 and np.array_equal(mapO2, g["a_it2_mapO2"])
+    assert np.max(np.abs(faint - g["a_it2_faint"])) <= 1e-4
+
+
+def test_greedy_pca_area_golden(hip):
+    g = load("g4_pca")
+    inp = gc.g4_inputs()
+    cube, areamap, nb = inp["area_cube"], inp["areamap"], inp["nbAreas"]
+    res = [hip.Compute_PCA_threshold(cube[:, areamap == i], 0.01) for i in range(1, nb + 1)]
+    thr = [r[3] for r in res]
+    np.testing.assert_allclose(thr, g["area_thr"], rtol=1e-6)
+    faint, mapO2, nstop = hip.Compute_GreedyPCA_area(nb, cube, areamap, 50, list(g["area_thr"]),
+                                                     100, [r[0] for r in res])
+    ref = g["area_faint"]
+    assert np.array_equal(mapO2, g["area_mapO2"]) and nstop == int(g["area_nstop"])
+    assert np.linalg.norm(faint - ref) <= 2e-6 * np.linalg.norm(ref)
+    assert np.max(np.abs(faint - ref)) <= 1e-4
+
+
+# ------------------------------------------------------------------------------- GLR
+@pytest.mark.parametrize("name", list("abcde"))
+def test_glr_golden(hip, name):
+    g = load("g5_glr")
+    c = gc.g5_inputs()[name]
+    correl, profile, correl_min = hip.Correlation_GLR_test(
+        c["cube"], c["fsf"], c["weights"], c["profiles"], nthreads=1, pcut=c["pcut"],
+        pmeansub=c["pmeansub"])
+    assert profile.dtype == np.uint8
+    assert np.max(np.abs(correl - g[name + "_correl"])) <= 1e-4
+    assert np.max(np.abs(correl_min - g[name + "_correl_min"])) <= 1e-4
+    assert np.mean(profile != g[name + "_profile"]) <= 1e-4
+
+
+def test_glr_wide_profiles_fallback(hip):
+    """pcut=None with the full 201-tap dictionary takes the generic (wide-window) kernel."""
+    c = gc.g5_inputs()["a"]
+    args = (c["cube"], c["fsf"], None, c["profiles"])
+    correl, profile, correl_min = hip.Correlation_GLR_test(*args, pcut=None, pmeansub=True)
+    r = cpu_ref.Correlation_GLR_test(*args, nthreads=1, pcut=None, pmeansub=True)
+    assert np.max(np.abs(correl - r[0])) <= 1e-4
+    assert np.max(np.abs(correl_min - r[2])) <= 1e-4
+
+
+def test_glr_linearity_property(hip):
+    """T(a * cube) = a * T(cube) for a > 0 (size-independent property)."""
+    c = gc.g5_inputs()["e"]
+    r1 = hip.Correlation_GLR_test(c["cube"], c["fsf"], None, c["profiles"], pcut=1e-8)
+    r2 = hip.Correlation_GLR_test(4.0 * c["cube"], c["fsf"], None, c["profiles"], pcut=1e-8)
+    np.testing.assert_allclose(r2[0], 4.0 * r1[0], rtol=0, atol=1e-4)
+    assert np.array_equal(r1[1], r2[1])
+
+
+def test_local_max_golden(hip):
+    g5, g = load("g5_glr"), load("g6_localmax")
+    mask = gc.g5_mask(g5["a_correl"].shape)
+    cm = g5["a_correl"].astype(np.float32)
+    cm[mask] = 0
+    cmin = g5["a_correl_min"].astype(np.float32)
+    lmax, lmin = hip.compute_local_max(cm, cmin, mask, 3)
+    rmax, rmin = cpu_ref.compute_local_max(cm.astype(float), cmin.astype(float), mask, 3)
+    assert np.array_equal(lmax, rmax) and np.array_equal(lmin, rmin)
+    # and the float64 golden agrees where rounding to float32 does not create ties
+    assert np.mean((lmax != 0) != (g["local_max"] != 0)) < 1e-3
+
+
+# ------------------------------------------------------------------------------- chain
+def test_step_chain_golden(ctx):
+    """G7: minicube-shaped chain through the Step API (SimpleOrig) vs the reference."""
+    from origin_amd.steps import SimpleOrig, Status
+    g = load("g7_chain")
+    inp = gc.g7_inputs()
+    orig = SimpleOrig(inp["raw"], inp["var"], inp["mask"], inp["PSF"], inp["profiles"], ctx=ctx)
+    with pytest.raises(RuntimeError):
+        orig.step03_compute_PCA_threshold()          # require: preprocessing, areas
+    orig.step01_preprocessing()
+    orig.step02_areas(areamap=inp["areamap"])
+    orig.step03_compute_PCA_threshold()
+    orig.step04_compute_greedy_PCA()
+    orig.step05_compute_TGLR()
+    assert all(s.status is Status.RUN for s in orig.steps.values())
+    assert orig.param["compute_TGLR"]["params"]["pcut"] == 1e-8
+    zs = g["zs"]
+    np.testing.assert_allclose(orig.thresO2, g["thresO2"], rtol=1e-5)
+    assert_close_scaled(orig.cube_std._data[zs], g["cube_std_z"], 1e-5)
+    assert np.array_equal(orig.mapO2, g["mapO2"])
+    assert np.max(np.abs(orig.cube_faint._data[zs] - g["cube_faint_z"])) <= 1e-4
+    assert np.max(np.abs(orig.cube_correl._data[zs] - g["correl_z"])) <= 2e-4
+    assert np.max(np.abs(orig.cube_correl_min._data[zs] - g["correl_min_z"])) <= 2e-4
+    assert np.max(np.abs(orig.maxmap - g["maxmap"])) <= 2e-4
+    assert np.max(np.abs(orig.minmap - g["minmap"])) <= 2e-4
+    assert np.mean(orig.cube_profile._data[zs] != g["profile_z"]) <= 1e-3
+    assert orig.cube_local_max._data.shape == inp["raw"].shape
+
+
+def test_errors_are_raised_not_aborted(ctx):
+    from origin_amd import _capi, kernels
+    raw = ctx.zeros((8, 4, 4), np.float32)
+    mask = ctx.zeros((8, 4, 4), np.uint8)
+    with pytest.raises(_capi.OriginHipError) as e:
+        kernels.dct_fit(ctx, raw, raw, mask, order=40)
+    assert e.value.code == -1 and "order" in str(e.value)
+    with pytest.raises(_capi.OriginHipError):
+        kernels.GLRPlan(ctx, (8, 4, 4), np.ones((8, 4, 4)), None, [np.ones(5)])  # even PSF
