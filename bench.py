@@ -1,0 +1,263 @@
+#!/usr/bin/env python3
+"""Benchmark of the ORIGIN hot path on MI355X:  voxels/s through DCT + PCA + GLR.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the whole hot path (Preprocessing -> ComputePCAThreshold ->
+ComputeGreedyPCA -> ComputeTGLR dense parts) over one synthetic (Nz, N, N) cube whose
+inputs (raw, var, mask) are already resident in HBM.  With N > 1 ranks the field is cut into
+spatial tiles (one per GPU, PCA areas never straddle tiles) and the total work is fixed
+(strong scaling).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from origin_amd import synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
+
+
+def _gen_chunk(args):
+    field_args, ic, window = args
+    f = _gen_chunk.cache.get(field_args)
+    if f is None:
+        f = _gen_chunk.cache[field_args] = synth.SyntheticField(*field_args)
+    return ic, f.chunk(ic, window)
+
+
+_gen_chunk.cache = {}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=600, help="field is size x size spaxels")
+    ap.add_argument("--nz", type=int, default=3681)
+    ap.add_argument("--nprof", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-crop", type=int, default=48)
+    ap.add_argument("--local-max", action="store_true", help="also time compute_local_max")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    Nz, N = args.nz, args.size
+    field_args = (Nz, N, N, None, 25, args.nprof)
+    # worker pool for the synthetic cube: forked BEFORE this process touches the GPU
+    nworkers = max(1, min(12, (os.cpu_count() or 8) // max(1, min(world, 8)) - 1))
+    pool = mp.get_context("fork").Pool(nworkers)
+
+    comm = None
+    if world > 1:
+        from origin_amd import multigpu
+        comm = multigpu.init_comm(rank, world, local_rank)
+
+    from origin_amd import kernels, pipeline
+    from origin_amd.device import Context
+
+    ctx = Context(local_rank if world > 1 else 0)
+    field = synth.SyntheticField(*field_args)
+
+    if world > 1:
+        tiling = multigpu.Tiling(field.Ny, field.Nx, world, area_size=100, halo=12)
+        tile = tiling.tile(rank)
+        y0, y1, x0, x1 = tile.y0, tile.y1, tile.x0, tile.x1
+    else:
+        tiling, tile = None, None
+        y0, y1, x0, x1 = 0, N, 0, N
+    ny, nx = y1 - y0, x1 - x0
+    window = (y0, y1, x0, x1)
+
+    # ---- inputs resident in HBM --------------------------------------------------
+    t_gen = time.time()
+    raw = ctx.empty((Nz, ny, nx), np.float32)
+    var = ctx.empty((Nz, ny, nx), np.float32)
+    mask = ctx.empty((Nz, ny, nx), np.uint8)
+    plane = ny * nx
+    jobs = [(field_args, ic, window) for ic in range(field.nchunks)]
+    for ic, (r, v, m) in pool.imap_unordered(_gen_chunk, jobs):
+        z0 = ic * synth.ZCHUNK
+        raw.view(z0 * plane, r.shape).upload(r)
+        var.view(z0 * plane, v.shape).upload(v)
+        mask.view(z0 * plane, m.shape).upload(m)
+    pool.close()
+    pool.join()
+    t_gen = time.time() - t_gen
+
+    areamap = field.areamap[y0:y1, x0:x1]
+    labels = np.unique(areamap)
+    local_map = np.searchsorted(labels, areamap).astype(np.int32) + 1
+    nb_local = len(labels)
+    spx = pipeline.area_lists(local_map, nb_local)
+
+    if world > 1:
+        glr = multigpu.TiledGLR(ctx, comm, tiling, rank, Nz, field.PSF.astype(np.float64),
+                                field.profiles, pcut=1e-8)
+    else:
+        plan = kernels.GLRPlan(ctx, (Nz, ny, nx), field.PSF.astype(np.float64), None,
+                               field.profiles, pcut=1e-8, pmeansub=True)
+    allreduce = comm.allreduce_sum if comm is not None else None
+
+    cube_std = ctx.empty((Nz, ny, nx), np.float32)
+    cont_dct = ctx.empty((Nz, ny, nx), np.float32)
+    cube_faint = ctx.empty((Nz, ny, nx), np.float32)
+    correl = ctx.empty((Nz, ny, nx), np.float32)
+    correl_min = ctx.empty((Nz, ny, nx), np.float32)
+    profile = ctx.empty((Nz, ny, nx), np.uint8)
+    info = {}
+
+    def one_step():
+        coef = kernels.dct_fit(ctx, raw, var, mask, 10, False)
+        zsum, zcnt = kernels.dct_resid_sums(ctx, raw, mask, coef)
+        if allreduce is not None:
+            both = allreduce(np.concatenate([zsum.to_host(), zcnt.to_host()]))
+            zsum.upload(both[:Nz])
+            zcnt.upload(both[Nz:])
+        pre = kernels.dct_standardize(ctx, raw, var, mask, coef, zsum, zcnt, cube_std=cube_std,
+                                      cont_dct=cont_dct)
+        thr = pipeline.pca_threshold(pre["o2"].to_host(), local_map, nb_local, 0.01, spx=spx)
+        cube_faint.copy_from(cube_std)
+        F, mapO2, nstop, drv = pipeline.greedy_pca(ctx, cube_faint, local_map, nb_local,
+                                                   thr["thresO2"], thr["testO2"], 50, 100,
+                                                   spx=spx, inplace=True)
+        if world > 1:
+            out = glr.run(cube_faint, mask, correl, profile, correl_min)
+        else:
+            out = plan.run(cube_faint, mask=mask, correl=correl, profile=profile,
+                           correl_min=correl_min, want_maps=True)
+        if args.local_max:
+            kernels.local_max(ctx, correl, correl_min, mask, 3)
+        ctx.sync()
+        info["pca_iters"] = [len(t) for t in [drv.trace]][0]
+        info["n_nuis_first"] = int(sum(n for _, n, _ in drv.trace[0])) if drv.trace else 0
+        info["nstop"] = nstop
+        info["maxmap_max"] = float(out["maxmap"].to_host().max())
+        info["area_iters_mean"] = float(np.mean([mapO2.reshape(-1)[s].max() for s in spx]))
+        return out
+
+    def barrier():
+        if comm is not None:
+            comm.barrier()
+
+    for _ in range(args.warmup):
+        one_step()
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    barrier()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    ctx.sync()
+    barrier()
+    t1 = time.perf_counter()
+    ctx.prof_enable(False)
+    elapsed = t1 - t0
+    if comm is not None:
+        elapsed = comm.max_float(elapsed)
+    prof = ctx.prof_report()
+
+    total_vox = float(Nz) * N * N
+    ms_per_step = 1e3 * elapsed / max(1, args.steps)
+    value = total_vox * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel class (HIP events on the kernels' stream) ----
+    local_vox = float(Nz) * ny * nx
+    ntaps = sum(len(p) for p in kernels.prepare_profiles(field.profiles, 1e-8))
+    algo = {
+        # bytes per voxel per launch: what the kernel must move
+        "dct_fit": ("hbm", 9.0 * local_vox),            # raw 4 + var 4 + mask 1
+        "dct_plane_sums": ("hbm", 5.0 * local_vox),     # raw 4 + mask 1
+        "dct_standardize": ("hbm", 17.0 * local_vox),   # + cube_std 4 + cont_dct 4
+        "pca_deflate_dot": ("hbm", 4.0),                # per voxel of the launch's areas
+        "pca_deflate_update": ("hbm", 8.0),
+        # flops per launch for the compute-bound GLR stages (fp32 FMA = 2 flop)
+        "glr_spatial": ("mfma", 2.0 * 25 * 25 * local_vox),
+        "glr_spectral": ("mfma", 2.0 * ntaps * local_vox),
+    }
+    dominant = max(prof.items(), key=lambda kv: kv[1][0])[0] if prof else None
+    roofline = None
+    if dominant in algo:
+        bound, per_launch = algo[dominant]
+        tot_ms, launches = prof[dominant]
+        avg_s = tot_ms / launches / 1e3
+        if dominant.startswith("pca_deflate"):
+            per_launch = per_launch * local_vox  # upper bound: every area active
+        if bound == "hbm":
+            ach, peak, unit = per_launch / avg_s / 1e9, HBM_PEAK_GBS, "GB/s"
+        else:
+            ach, peak, unit = per_launch / avg_s / 1e12, FP32_PEAK_TFLOPS, "TFLOP/s"
+        roofline = dict(bound=bound, kernel=dominant, achieved=round(ach, 3), peak=peak,
+                        unit=unit, frac=round(ach / peak, 4), traffic=None,
+                        avg_launch_ms=round(tot_ms / launches, 4), launches=launches)
+
+    # ---- CPU baseline: the oracle on a centred crop, all host cores, rank 0, N == 1 ----
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import cpu_ref
+        c = min(args.cpu_crop, N)
+        cy0 = (N - c) // 2
+        craw, cvar, cmask = field.arrays(window=(cy0, cy0 + c, cy0, cy0 + c))
+        cores = os.cpu_count() or 1
+        tm = {}
+        t = time.perf_counter()
+        cpu_ref.run_chain(craw.astype(np.float64), cvar.astype(np.float64), cmask,
+                          field.PSF.astype(np.float64), None, field.profiles,
+                          np.ones((c, c), dtype=int), 1, ncpu=cores, timings=tm)
+        dt = time.perf_counter() - t
+        cpu_baseline = dict(value=round(Nz * c * c / dt, 1), unit="voxels/s", cores=cores,
+                            kind="port",
+                            sample=f"oracle.cpu_ref.run_chain on the centred {c}x{c} crop "
+                                   f"({Nz}x{c}x{c} voxels, {args.nprof} profiles, 1 area), "
+                                   f"GLR joblib ncpu={cores}",
+                            seconds={k: round(v, 2) for k, v in tm.items()})
+
+    if rank == 0:
+        line = {
+            "metric": "voxels/s through DCT+PCA+GLR (ORIGIN hot path)",
+            "value": round(value, 1),
+            "unit": "voxels/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"synthetic {Nz}x{N}x{N} cube, Dico_FWHM_2_12 "
+                                   f"({args.nprof} profiles), PSF 25x25, 100x100 areas, "
+                                   "dct_order 10, pfa 0.01, Noise_population 50, itermax 100",
+                       "tiles": world, "pca": info,
+                       "gen_seconds": round(t_gen, 1)},
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+            "kernels_ms_per_step": {k: round(v[0] / max(1, args.steps), 3)
+                                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
+            "kernel_launches_per_step": {k: v[1] // max(1, args.steps) for k, v in prof.items()},
+        }
+        print(json.dumps(line))
+    if comm is not None:
+        comm.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -70,6 +70,15 @@ int origin_timer_start(origin_ctx *ctx, int slot);
 int origin_timer_stop(origin_ctx *ctx, int slot);
 int origin_timer_ms(origin_ctx *ctx, int slot, float *ms); /* synchronises on the stop */
 
+/* Built-in per-kernel-class profiler: when enabled, every kernel launch of the library is
+ * bracketed by HIP events on the context's stream; totals are kept per class
+ * (id in [0, origin_prof_count())).  origin_prof_get synchronises on pending events. */
+int origin_prof_enable(origin_ctx *ctx, int on);
+int origin_prof_reset(origin_ctx *ctx);
+int origin_prof_count(void);
+int origin_prof_get(origin_ctx *ctx, int id, const char **name, double *total_ms,
+                    long *launches);
+
 /* ---- A. DCT continuum + standardisation -------------------------------------------
  * Replaces dct_residual (lib_origin.py:150-240) and the dense lines of
  * Preprocessing.run (steps.py:431-450, :463-465). */

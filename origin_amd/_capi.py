@@ -37,6 +37,10 @@ SIGNATURES = {
     "origin_timer_start": [vp, i32],
     "origin_timer_stop": [vp, i32],
     "origin_timer_ms": [vp, i32, PP(C.c_float)],
+    "origin_prof_enable": [vp, i32],
+    "origin_prof_reset": [vp],
+    "origin_prof_count": [],
+    "origin_prof_get": [vp, i32, PP(C.c_char_p), PP(C.c_double), PP(C.c_long)],
     "origin_dct_fit": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "origin_dct_continuum": [vp, vp, i32, i32, i32, i32, vp],
     "origin_dct_resid_sums": [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp],

@@ -5,8 +5,36 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <vector>
 
 #include "../../include/origin_hip.h"
+
+// kernel classes timed by the built-in HIP-event profiler (origin_prof_*)
+enum OriginKernelId {
+  K_DCT_FIT = 0,
+  K_DCT_SUMS,
+  K_DCT_STANDARDIZE,
+  K_DCT_CONTINUUM,
+  K_O2,
+  K_PCA_BMEAN,
+  K_PCA_GATHER,
+  K_PCA_PROJECT,
+  K_PCA_GRAM,
+  K_PCA_UVEC,
+  K_PCA_DEFLATE_DOT,
+  K_PCA_DEFLATE_UPDATE,
+  K_GLR_SPATIAL,
+  K_GLR_SPECTRAL,
+  K_GLR_TABLES,
+  K_LOCAL_MAX,
+  K_SMALL,
+  K_COUNT
+};
+
+struct OriginProfEvent {
+  hipEvent_t a, b;
+  int id;
+};
 
 struct origin_ctx {
   int device;
@@ -21,6 +49,26 @@ struct origin_ctx {
   // cached DCT cosine table (dct.hip)
   double *ctab;
   int ctab_nz, ctab_order;
+  // per-kernel-class timing with HIP events on the stream the kernels run on
+  bool prof_on;
+  std::vector<OriginProfEvent> prof_pending;
+  std::vector<hipEvent_t> prof_free;
+  double prof_ms[K_COUNT];
+  long prof_n[K_COUNT];
+};
+
+void origin_prof_begin(origin_ctx *ctx, int id);
+void origin_prof_end(origin_ctx *ctx);
+
+// RAII: times everything enqueued on ctx->stream during its lifetime as kernel class `id`
+struct ProfScope {
+  origin_ctx *ctx;
+  ProfScope(origin_ctx *c, int id) : ctx(c) {
+    if (ctx->prof_on) origin_prof_begin(ctx, id);
+  }
+  ~ProfScope() {
+    if (ctx->prof_on) origin_prof_end(ctx);
+  }
 };
 
 void origin_set_error(const char *fmt, ...);

@@ -26,7 +26,82 @@ int origin_scratch(origin_ctx *ctx, size_t bytes, void **out) {
   return ORIGIN_OK;
 }
 
+static hipEvent_t prof_event(origin_ctx *ctx) {
+  if (!ctx->prof_free.empty()) {
+    hipEvent_t e = ctx->prof_free.back();
+    ctx->prof_free.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+static void prof_drain(origin_ctx *ctx) {
+  for (auto &p : ctx->prof_pending) {
+    float ms = 0.f;
+    if (p.a && p.b && hipEventSynchronize(p.b) == hipSuccess &&
+        hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      ctx->prof_ms[p.id] += ms;
+      ctx->prof_n[p.id] += 1;
+    }
+    if (p.a) ctx->prof_free.push_back(p.a);
+    if (p.b) ctx->prof_free.push_back(p.b);
+  }
+  ctx->prof_pending.clear();
+}
+
+void origin_prof_begin(origin_ctx *ctx, int id) {
+  OriginProfEvent p;
+  p.a = prof_event(ctx);
+  p.b = nullptr;
+  p.id = id;
+  if (p.a) (void)hipEventRecord(p.a, ctx->stream);
+  ctx->prof_pending.push_back(p);
+}
+
+void origin_prof_end(origin_ctx *ctx) {
+  if (ctx->prof_pending.empty()) return;
+  OriginProfEvent &p = ctx->prof_pending.back();
+  p.b = prof_event(ctx);
+  if (p.b) (void)hipEventRecord(p.b, ctx->stream);
+  if (ctx->prof_pending.size() > 4096) prof_drain(ctx);
+}
+
+static const char *kKernelNames[K_COUNT] = {
+    "dct_fit",         "dct_plane_sums",     "dct_standardize", "dct_continuum", "o2",
+    "pca_bmean",       "pca_gather",         "pca_project",     "pca_gram",      "pca_uvec",
+    "pca_deflate_dot", "pca_deflate_update", "glr_spatial",     "glr_spectral",  "glr_tables",
+    "local_max",       "small"};
+
 extern "C" {
+
+int origin_prof_enable(origin_ctx *ctx, int on) {
+  ORIGIN_USE(ctx);
+  prof_drain(ctx);
+  ctx->prof_on = on != 0;
+  return ORIGIN_OK;
+}
+
+int origin_prof_reset(origin_ctx *ctx) {
+  ORIGIN_USE(ctx);
+  prof_drain(ctx);
+  memset(ctx->prof_ms, 0, sizeof(ctx->prof_ms));
+  memset(ctx->prof_n, 0, sizeof(ctx->prof_n));
+  return ORIGIN_OK;
+}
+
+int origin_prof_count(void) { return K_COUNT; }
+
+int origin_prof_get(origin_ctx *ctx, int id, const char **name, double *total_ms, long *launches) {
+  ORIGIN_USE(ctx);
+  ORIGIN_CHECK_ARG(id >= 0 && id < K_COUNT, "kernel id out of range");
+  prof_drain(ctx);
+  if (name) *name = kKernelNames[id];
+  if (total_ms) *total_ms = ctx->prof_ms[id];
+  if (launches) *launches = ctx->prof_n[id];
+  return ORIGIN_OK;
+}
 
 const char *origin_last_error(void) { return g_err; }
 
@@ -55,8 +130,17 @@ int origin_ctx_create(int device, origin_ctx **out) {
   ORIGIN_CHECK_ARG(device >= 0 && device < n, "device %d out of range [0,%d)", device, n);
   ORIGIN_HIP(hipSetDevice(device));
   origin_ctx *ctx = new origin_ctx();
-  memset(ctx, 0, sizeof(*ctx));
   ctx->device = device;
+  ctx->stream = nullptr;
+  memset(ctx->ev_made, 0, sizeof(ctx->ev_made));
+  ctx->scratch = nullptr;
+  ctx->scratch_bytes = 0;
+  ctx->num_cu = 0;
+  ctx->ctab = nullptr;
+  ctx->ctab_nz = ctx->ctab_order = 0;
+  ctx->prof_on = false;
+  memset(ctx->prof_ms, 0, sizeof(ctx->prof_ms));
+  memset(ctx->prof_n, 0, sizeof(ctx->prof_n));
   hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   if (e != hipSuccess) {
     delete ctx;
@@ -81,6 +165,8 @@ int origin_ctx_destroy(origin_ctx *ctx) {
     }
   if (ctx->scratch) hipFree(ctx->scratch);
   if (ctx->ctab) hipFree(ctx->ctab);
+  prof_drain(ctx);
+  for (hipEvent_t e : ctx->prof_free) hipEventDestroy(e);
   hipStreamDestroy(ctx->stream);
   delete ctx;
   return ORIGIN_OK;

@@ -480,6 +480,7 @@ int origin_dct_fit(origin_ctx *ctx, const float *d_raw, const float *d_var,
   const int NACC = (2 * order + 1) + 2 * (order + 1);
   const size_t lds = (size_t)(ZS - 1) * (NACC + 1) * 64 * sizeof(double);
   dim3 grid((unsigned)waves), block(64, ZS);
+  ProfScope ps(ctx, K_DCT_FIT);
 #define CALL(O)                                                                             \
   hipLaunchKernelGGL(dct_fit_kernel<O>, grid, block, lds, ctx->stream, d_raw, d_var, d_mask, \
                      tab.p, Nz, S, approx, d_coef)
@@ -502,6 +503,7 @@ int origin_dct_continuum(origin_ctx *ctx, const double *d_coef, int Nz, int Ny, 
   const int nzc = pick_zchunks(ctx, S, Nz);
   const int zchunk = cdiv(Nz, nzc);
   dim3 grid(cdiv(S, 256), cdiv(Nz, zchunk));
+  ProfScope ps(ctx, K_DCT_CONTINUUM);
 #define CALL(O)                                                                                \
   hipLaunchKernelGGL(dct_continuum_kernel<O>, grid, dim3(256), 0, ctx->stream, d_coef, tab.p, \
                      Nz, S, zchunk, d_cont)
@@ -530,6 +532,7 @@ int origin_dct_resid_sums(origin_ctx *ctx, const float *d_raw, const uint8_t *d_
   if (rc) return rc;
   double *part = (double *)scr;
   double *ctot = (double *)((char *)scr + part_bytes);
+  ProfScope ps(ctx, K_DCT_SUMS);
   hipLaunchKernelGGL(coef_total_kernel, dim3(order + 1), dim3(1024), 0, ctx->stream, d_coef, S,
                      ctot);
   dim3 grid(nchunk, Nz);
@@ -570,6 +573,7 @@ int origin_dct_standardize(origin_ctx *ctx, const float *d_raw, const float *d_v
     part = (double *)scr;
   }
   dim3 grid(cdiv(S, 256), nzc);
+  ProfScope ps(ctx, K_DCT_STANDARDIZE);
 #define CALL(O)                                                                               \
   hipLaunchKernelGGL(dct_standardize_kernel<O>, grid, dim3(256), 0, ctx->stream, d_raw, d_var, \
                      d_mask, d_coef, tab.p, d_zsum, d_zcnt, Nz, S, zchunk, d_cube_std,        \
@@ -594,6 +598,7 @@ int origin_o2(origin_ctx *ctx, const float *d_cube, int Nz, long S, double *d_ou
   void *scr = nullptr;
   int rc = origin_scratch(ctx, (size_t)nzc * S * sizeof(double), &scr);
   if (rc) return rc;
+  ProfScope ps(ctx, K_O2);
   hipLaunchKernelGGL(o2_partial_kernel, dim3(cdiv(S, 256), nzc), dim3(256), 0, ctx->stream,
                      d_cube, Nz, S, zchunk, (double *)scr);
   hipLaunchKernelGGL(o2_final_kernel, dim3(cdiv(S, 256)), dim3(256), 0, ctx->stream,

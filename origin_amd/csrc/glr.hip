@@ -479,6 +479,7 @@ int origin_glr_plan_create(origin_ctx *ctx, int Nz, int Ny, int Nx, int nfields,
       return ORIGIN_E_NOMEM;
     }
     pl->bytes += rn * sizeof(float);
+    ProfScope ps(ctx, K_GLR_TABLES);
     hipLaunchKernelGGL(norm_classes_kernel, dim3(cdiv((long)ncls_n, 256)), dim3(256), 0,
                        ctx->stream, pl->d_k2, Nz, P, ncls);
     hipLaunchKernelGGL(rden_kernel, dim3(cdiv((long)rn, 256)), dim3(256), 0, ctx->stream, ncls,
@@ -530,6 +531,7 @@ int origin_glr_run(origin_ctx *ctx, origin_glr_plan *pl, const float *d_cube,
   dim3 sgrid(cdiv(Nx, TX), cdiv(Ny, TY), Nz), sblock(64, 4);
   const size_t lds = (size_t)(TY + P - 1) * (TX + P - 1) * sizeof(float);
   for (int f = 0; f < pl->nfields; ++f) {
+    ProfScope ps(ctx, K_GLR_SPATIAL);
     const float *kf = pl->d_k + (size_t)f * Nz * P * P;
     const float *wf = pl->d_w ? pl->d_w + (size_t)f * S : nullptr;
     hipLaunchKernelGGL(spatial_kernel, sgrid, sblock, lds, ctx->stream, d_cube, wf, kf, Ny, Nx, P,
@@ -556,6 +558,8 @@ int origin_glr_run(origin_ctx *ctx, origin_glr_plan *pl, const float *d_cube,
                      pl->d_taps2, pl->d_tap_off, K, Nz, Ny, Nx, P, zchunk, d_mask, d_correl, \
                      d_profile, d_correl_min, pmax, pmin)
   const bool gen = pl->mode == 1;
+  {
+  ProfScope ps(ctx, K_GLR_SPECTRAL);
   if (pl->lwmax <= 8) {
     if (gen) LAUNCH((spectral_kernel<8, true>)); else LAUNCH((spectral_kernel<8, false>));
   } else if (pl->lwmax <= 16) {
@@ -565,9 +569,11 @@ int origin_glr_run(origin_ctx *ctx, origin_glr_plan *pl, const float *d_cube,
   } else {
     if (gen) LAUNCH((spectral_generic_kernel<true>)); else LAUNCH((spectral_generic_kernel<false>));
   }
+  }
 #undef LAUNCH
   ORIGIN_LAUNCH_CHECK();
   if (want_maps) {
+    ProfScope ps(ctx, K_SMALL);
     hipLaunchKernelGGL(maxmap_final_kernel, dim3(cdiv(S, 256)), dim3(256), 0, ctx->stream, pmax,
                        pmin, nzc, S, d_maxmap, d_minmap);
     ORIGIN_LAUNCH_CHECK();

@@ -42,6 +42,7 @@ extern "C" int origin_local_max(origin_ctx *ctx, const float *d_correl,
   // scipy maximum_filter: window offsets  -(size//2) .. size-1-(size//2)
   const int lo = size / 2, hi = size - 1 - size / 2;
   dim3 grid(cdiv(Nx, 64), cdiv(Ny, 4), Nz), block(64, 4);
+  ProfScope ps(ctx, K_LOCAL_MAX);
   if (d_correl && d_local_max)
     hipLaunchKernelGGL(local_max_kernel, grid, block, 0, ctx->stream, d_correl, d_mask, Nz, Ny, Nx,
                        lo, hi, 1.0f, d_local_max);

@@ -299,6 +299,7 @@ int origin_pca_bmean(origin_ctx *ctx, const float *d_F, int Nz, long S, const in
                      const long *d_bg_off, int na, double *d_b) {
   ORIGIN_USE(ctx);
   ORIGIN_CHECK_ARG(d_F && d_bg && d_bg_off && d_b && Nz > 0 && S > 0 && na > 0, "bad arguments");
+  ProfScope ps(ctx, K_PCA_BMEAN);
   hipLaunchKernelGGL(bmean_kernel, dim3(cdiv(Nz, 4), na), dim3(64, 4), 0, ctx->stream, d_F, Nz, S,
                      d_bg, d_bg_off, d_b);
   ORIGIN_LAUNCH_CHECK();
@@ -313,10 +314,16 @@ int origin_pca_build_xp(origin_ctx *ctx, const float *d_F, int Nz, long S, const
   ORIGIN_CHECK_ARG(d_F && d_nuis && d_nuis_off && d_b && d_Xp && d_xp_off && d_ld && d_c &&
                        d_c_off && Nz > 0 && S > 0 && na > 0 && ldmax > 0,
                    "bad arguments");
-  hipLaunchKernelGGL(gather_xp_kernel, dim3(cdiv(ldmax, 64), na), dim3(64, 16), 0, ctx->stream,
-                     d_F, Nz, S, d_nuis, d_nuis_off, d_b, d_Xp, d_xp_off, d_ld, d_c, d_c_off);
-  hipLaunchKernelGGL(project_xp_kernel, dim3(cdiv(Nz, 16), na), dim3(256), 0, ctx->stream, d_b,
-                     Nz, d_Xp, d_xp_off, d_ld, d_c, d_c_off);
+  {
+    ProfScope ps(ctx, K_PCA_GATHER);
+    hipLaunchKernelGGL(gather_xp_kernel, dim3(cdiv(ldmax, 64), na), dim3(64, 16), 0, ctx->stream,
+                       d_F, Nz, S, d_nuis, d_nuis_off, d_b, d_Xp, d_xp_off, d_ld, d_c, d_c_off);
+  }
+  {
+    ProfScope ps(ctx, K_PCA_PROJECT);
+    hipLaunchKernelGGL(project_xp_kernel, dim3(cdiv(Nz, 16), na), dim3(256), 0, ctx->stream, d_b,
+                       Nz, d_Xp, d_xp_off, d_ld, d_c, d_c_off);
+  }
   ORIGIN_LAUNCH_CHECK();
   return ORIGIN_OK;
 }
@@ -337,6 +344,7 @@ int origin_pca_gram(origin_ctx *ctx, const double *d_Xp, const long *d_xp_off,
   void *scr = nullptr;
   int rc = origin_scratch(ctx, (size_t)ksplit * g_total * sizeof(double), &scr);
   if (rc) return rc;
+  ProfScope ps(ctx, K_PCA_GRAM);
   hipLaunchKernelGGL(gram_kernel, dim3(ntiles, ksplit), dim3(64), 0, ctx->stream, d_Xp, d_xp_off,
                      d_ld, d_tile_i, d_tile_j, d_tile_a, Nz, ksplit, (double *)scr, d_g_off,
                      g_total);
@@ -353,6 +361,7 @@ int origin_pca_uvec(origin_ctx *ctx, const double *d_Xp, const long *d_xp_off, c
   ORIGIN_USE(ctx);
   ORIGIN_CHECK_ARG(d_Xp && d_xp_off && d_ld && d_n && d_v && d_v_off && d_u && na > 0 && Nz > 0,
                    "bad arguments");
+  ProfScope ps(ctx, K_PCA_UVEC);
   hipLaunchKernelGGL(xv_kernel, dim3(cdiv(Nz, 4), na), dim3(64, 4), 0, ctx->stream, d_Xp, d_xp_off,
                      d_ld, d_n, Nz, d_v, d_v_off, d_u);
   hipLaunchKernelGGL(normalize_kernel, dim3(na), dim3(1024), 0, ctx->stream, d_u, Nz);
@@ -380,10 +389,17 @@ int origin_pca_deflate(origin_ctx *ctx, float *d_F, int Nz, long S, const int *d
   double *cpart = (double *)scr;
   double *o2part = cpart + (size_t)nzs * ntot;
   dim3 grid(cdiv(nsmax, 256), nzs, na);
-  hipLaunchKernelGGL(deflate_dot_kernel, grid, dim3(256), 0, ctx->stream, d_F, Nz, S, d_spx,
-                     d_spx_off, d_u, zper, cpart, ntot);
-  hipLaunchKernelGGL(deflate_update_kernel, grid, dim3(256), 0, ctx->stream, d_F, Nz, S, d_spx,
-                     d_spx_off, d_u, zper, nzs, cpart, o2part, ntot);
+  {
+    ProfScope ps(ctx, K_PCA_DEFLATE_DOT);
+    hipLaunchKernelGGL(deflate_dot_kernel, grid, dim3(256), 0, ctx->stream, d_F, Nz, S, d_spx,
+                       d_spx_off, d_u, zper, cpart, ntot);
+  }
+  {
+    ProfScope ps(ctx, K_PCA_DEFLATE_UPDATE);
+    hipLaunchKernelGGL(deflate_update_kernel, grid, dim3(256), 0, ctx->stream, d_F, Nz, S, d_spx,
+                       d_spx_off, d_u, zper, nzs, cpart, o2part, ntot);
+  }
+  ProfScope ps(ctx, K_SMALL);
   hipLaunchKernelGGL(deflate_final_kernel, dim3(cdiv(ntot, 256)), dim3(256), 0, ctx->stream, d_spx,
                      ntot, nzs, Nz, o2part, d_test);
   ORIGIN_LAUNCH_CHECK();

@@ -61,6 +61,23 @@ class Context:
         _capi.call("origin_timer_ms", self._h, slot, C.byref(ms))
         return ms.value
 
+    # -- built-in per-kernel-class profiler (HIP events on the stream) --------
+    def prof_enable(self, on=True):
+        _capi.call("origin_prof_enable", self._h, int(bool(on)))
+
+    def prof_reset(self):
+        _capi.call("origin_prof_reset", self._h)
+
+    def prof_report(self):
+        """{kernel class: (total_ms, launches)} since the last reset (synchronises)."""
+        out = {}
+        for i in range(_capi.load().origin_prof_count()):
+            name, ms, n = C.c_char_p(), C.c_double(), C.c_long()
+            _capi.call("origin_prof_get", self._h, i, C.byref(name), C.byref(ms), C.byref(n))
+            if n.value:
+                out[name.value.decode()] = (ms.value, n.value)
+        return out
+
     # -- arrays ------------------------------------------------------------
     def empty(self, shape, dtype):
         return DeviceArray(self, shape, dtype)
