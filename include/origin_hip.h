@@ -113,42 +113,40 @@ int origin_dct_standardize(origin_ctx *ctx, const float *d_raw, const float *d_v
 /* O2test (lib_origin.py:957-974): out[s] = mean_z cube[z, s]^2, float64 [S]. */
 int origin_o2(origin_ctx *ctx, const float *d_cube, int Nz, long S, double *d_out);
 
-/* Building blocks of one Compute_GreedyPCA iteration (lib_origin.py:899-949), batched
- * over `na` areas.  The cube is updated in place; spaxels are addressed by flat index
- * s = y*Nx + x.  List arrays are concatenated per area with int64 offsets [na+1]; every
- * array below is a DEVICE array built by the host driver (origin_amd/pca.py).
- *
- * bmean   : b_a[z] = mean_{s in bg_a} F[z, s]           (float64 [na][Nz])        (:917)
- * build_xp: Xp_a = F[:, nuis_a] - b_a (b_a^T F[:, nuis_a])                    (:920-923)
- *           float64, row-major [Nz][ld_a] at d_Xp + xp_off[a], ld_a = n_a rounded up to
- *           16 (pad columns are zero); d_c receives b_a^T F[:, nuis_a] at c_off[a].
- *           (the reference's extra division by sum(b^2), :924, only rescales Xp and does
- *           not change its singular vectors.)
- * gram    : G_a = Xp_a^T Xp_a with v_mfma_f64_16x16x4_f64; float64 [ld_a][ld_a] at
- *           d_G + g_off[a].  The host lists the 32x32 upper-triangle tiles to compute
- *           (tile_i <= tile_j, area tile_a); g_total = sum_a ld_a^2.       -- Gram form
- *           of the svds(k=1) call at :940: its leading eigenvector v gives
- * uvec    : u_a = Xp_a v_a / ||Xp_a v_a||               (float64 [na][Nz])        (:940)
- * deflate : F[:, s] -= u_a (u_a^T F[:, s]) for every spaxel s of area a, and
- *           test[s] = mean_z F[z, s]^2                                        (:943-946)
- *           ntot = total list length, nsmax = longest per-area list.
- */
-int origin_pca_bmean(origin_ctx *ctx, const float *d_F, int Nz, long S, const int *d_bg,
-                     const long *d_bg_off, int na, double *d_b);
-int origin_pca_build_xp(origin_ctx *ctx, const float *d_F, int Nz, long S, const int *d_nuis,
-                        const long *d_nuis_off, int na, int ldmax, const double *d_b,
-                        double *d_Xp, const long *d_xp_off, const int *d_ld, double *d_c,
-                        const long *d_c_off);
-int origin_pca_gram(origin_ctx *ctx, const double *d_Xp, const long *d_xp_off,
-                    const int *d_ld, int Nz, int ntiles, const int *d_tile_i,
-                    const int *d_tile_j, const int *d_tile_a, long g_total, double *d_G,
-                    const long *d_g_off);
-int origin_pca_uvec(origin_ctx *ctx, const double *d_Xp, const long *d_xp_off, const int *d_ld,
-                    const int *d_n, int na, int Nz, const double *d_v, const long *d_v_off,
-                    double *d_u);
-int origin_pca_deflate(origin_ctx *ctx, float *d_F, int Nz, long S, const int *d_spx,
-                       const long *d_spx_off, int na, long ntot, int nsmax, const double *d_u,
-                       double *d_test);
+/* Compute_GreedyPCA_area / Compute_GreedyPCA (lib_origin.py:769-821, :848-954): the whole
+ * greedy loop for `na` areas, in place on d_F (float32 (Nz, S), S = Ny*Nx), all areas in lock
+ * step, control flow on the device.
+ *   d_spx      int32 device: concatenated flat spaxel indices s = y*Nx + x of the areas, each
+ *              in the column order of cube[:, areamap == i]; h_spx_off: host int64 [na+1].
+ *   d_test0    float64 device [S]: O2 test per spaxel (testO2, lib :840) -- not modified.
+ *   h_thr      host float64 [na]: thresholds (thresO2).
+ *   d_mapO2    int32 device [S]: out, iterations per spaxel (zero outside the areas).
+ *   h_nstop    out: number of areas stopped by itermax (:902-905); h_iters (may be NULL):
+ *              lock-step iterations executed; h_trace (may be NULL): per iteration
+ *              (areas iterating, total nuisance spaxels), int64 [2*trace_cap].
+ * Per iteration (lib :899-949): nuisance/background selection (:889-917, including the
+ * filtered-index quirk of :908-917), b = mean background (:917), Xp = X - b(b^T X)
+ * (:920-923; the division by sum(b^2) at :924 only rescales Xp), G = Xp^T Xp with
+ * v_mfma_f64_16x16x4_f64 and its leading eigenvector by restarted Lanczos in place of
+ * svds(k=1) (:940), u = Xp v/|Xp v|, F -= u u^T F and the new O2 test (:943-946). */
+int origin_pca_run(origin_ctx *ctx, float *d_F, int Nz, long S, int na, const int *d_spx,
+                   const long *h_spx_off, const double *d_test0, const double *h_thr,
+                   double noise_pop, int itermax, int *d_mapO2, int *h_nstop, int *h_iters,
+                   long *h_trace, int trace_cap);
+
+/* Pieces of the above exposed for unit tests.  gram: G_a = X_a^T X_a for `nmat` float64
+ * matrices X_a ([Nz][ld_a] at d_Xp + xp_off[a], ld_a a multiple of 16); the caller lists the
+ * 32x32 upper-triangle tiles (tile_i <= tile_j, matrix tile_a); g_total = sum ld_a^2.
+ * eig: leading eigenvector (unit norm) of symmetric PSD matrices G_a (n_a x n_a, row stride
+ * ld_a); scratch rows: q_off[a] into a buffer of q_total = sum origin_pca_eig_qrows()*ld_a
+ * doubles; d_info (may be NULL): (eigenvalue, Ritz residual, restarts) per matrix. */
+int origin_pca_gram(origin_ctx *ctx, const double *d_Xp, const long *d_xp_off, const long *d_ld,
+                    int Nz, int ntiles, const int *d_tile_i, const int *d_tile_j,
+                    const int *d_tile_a, long g_total, double *d_G, const long *d_g_off);
+int origin_pca_eig(origin_ctx *ctx, const double *d_G, const long *d_g_off, const long *d_ld,
+                   const long *d_n, int nmat, long q_total, const long *d_q_off, double *d_v,
+                   const long *d_v_off, double *d_info);
+int origin_pca_eig_qrows(void);
 
 /* ---- C. GLR correlation ------------------------------------------------------------
  * Replaces Correlation_GLR_test (lib_origin.py:1070-1217) and the dense lines of

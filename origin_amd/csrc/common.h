@@ -16,10 +16,12 @@ enum OriginKernelId {
   K_DCT_STANDARDIZE,
   K_DCT_CONTINUUM,
   K_O2,
+  K_PCA_SELECT,
   K_PCA_BMEAN,
   K_PCA_GATHER,
   K_PCA_PROJECT,
   K_PCA_GRAM,
+  K_PCA_EIG,
   K_PCA_UVEC,
   K_PCA_DEFLATE_DOT,
   K_PCA_DEFLATE_UPDATE,

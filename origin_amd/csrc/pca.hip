@@ -1,22 +1,30 @@
-// Greedy PCA building blocks  (SURVEY.md 2.2 rows k5-k7).
+// Greedy PCA  (SURVEY.md 2.2 rows k5-k7): the whole loop of Compute_GreedyPCA
+// (reference muse_origin/lib_origin.py:848-954) for all areas of a cube that stays in
+// place in HBM as (Nz, S), S = Ny*Nx.
 //
-// One iteration of Compute_GreedyPCA (reference muse_origin/lib_origin.py:899-949) for a
-// batch of areas, on a cube that stays in place in HBM as (Nz, S), S = Ny*Nx:
+// Per iteration and per area (lib :899-949):
+//   nuisance set   pypx = {test > thr}; mapO2[pypx] += 1; itermax guard        (:889,:901-905)
+//   background     the nb = 1 + int(n_bg / Noise_population) lowest-O2 spectra  (:908-917)
+//   b   = mean of the background spectra                                       (:917)
+//   Xp  = X_nuis - b (b^T X_nuis)            [un-normalised projection]        (:920-923)
+//   u   = leading left singular vector of Xp (ARPACK svds(k=1, tol=0))         (:940)
+//   F  -= u (u^T F) over the whole area; test = mean_z F^2                     (:943-946)
 //
-//   b   = mean of the background spectra                                  (lib :917)
-//   Xp  = X_nuis - b (b^T X_nuis)          [un-normalised projection]     (lib :920-923)
-//   u   = leading left singular vector of Xp                              (lib :940)
-//   F  -= u (u^T F) over the whole area; test = mean_z F^2                (lib :943-946)
+// All areas advance in lock step (they are independent, lib :806-819), every kernel is
+// batched over the areas still iterating, and the control flow (which spaxels are
+// nuisances, which background spectra feed the mean, when an area stops) runs on the device:
+// per iteration the host reads back two ints per area to size the launches.
 //
-// The reference calls ARPACK svds(k=1, tol=0).  Here u comes from the Gram matrix
-// G = Xp^T Xp (float64 MFMA, the only matrix-shaped contraction of the path): its leading
-// eigenvector v gives u = Xp v / |Xp v|.  SURVEY.md section 7 (hard part 1) shows the loop is
-// threshold driven, so the eigen-solve must be *converged*; everything that feeds it is
-// float64, only the cube itself is float32.
+// u comes from the Gram matrix G = Xp^T Xp (float64 MFMA, the only matrix-shaped
+// contraction of the path): its leading eigenvector v (device Lanczos with full
+// re-orthogonalisation, restarted until the Ritz residual is at rounding level) gives
+// u = Xp v / |Xp v|.  SURVEY.md section 7 (hard part 1): the loop is threshold driven, so the
+// eigen-solve must be converged; everything that feeds it is float64, only the cube is f32.
 //
-// Lists (spaxel indices of the nuisance / background / area members) are concatenated per
-// area with int64 offsets; a block never straddles two areas, so the per-area vectors
-// (b, u) are wave-uniform and read with scalar loads.
+// A block never straddles two areas, so per-area vectors (b, u) are wave-uniform.
+#include <algorithm>
+#include <vector>
+
 #include "common.h"
 
 namespace {
@@ -29,77 +37,236 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
+// descriptor fields of the per-iteration work list (int64 [DF_COUNT][nw])
+enum { DF_AREA = 0, DF_LIST0, DF_N, DF_NB, DF_LD, DF_XP, DF_C, DF_G, DF_Q, DF_NS, DF_CBASE, DF_COUNT };
+#define DSC(f, k) (D[(long)(f) * nw + (k)])
+
 // ------------------------------------------------------------------------------------
-// b_a[z] = mean_{i in bg_a} F[z, bg[i]]        grid (ceil(Nz/4), na), block (64,4)
+// selection: nuisance list, background list, iteration bookkeeping.  One block per area.
+// ------------------------------------------------------------------------------------
+struct BlockScan {
+  int *wtot;  // LDS [16]
+  __device__ __forceinline__ int exclusive(bool f, int &total) {
+    const unsigned long long b = __ballot(f);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rank = __popcll(b & ((1ull << lane) - 1ull));
+    __syncthreads();  // previous users of wtot are done
+    if (lane == 0) wtot[wave] = __popcll(b);
+    __syncthreads();
+    int pre = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const int c = wtot[w];
+      pre += (w < wave) ? c : 0;
+      tot += c;
+    }
+    total = tot;
+    return pre + rank;
+  }
+};
+
+__global__ __launch_bounds__(1024) void pca_select_kernel(
+    const int *__restrict__ spx, const long *__restrict__ spx_off, const double *__restrict__ test,
+    const double *__restrict__ thr_, double noise_pop, int itermax, int *__restrict__ active,
+    int *__restrict__ nbiter, int *__restrict__ nstop, int *__restrict__ mapO2,
+    int *__restrict__ nuis, int *__restrict__ bg, int *__restrict__ n_out,
+    int *__restrict__ nb_out) {
+  __shared__ int wtot[16];
+  __shared__ int hist[256];
+  __shared__ unsigned long long s_prefix;
+  __shared__ int s_remaining, s_ncand;
+  const int a = blockIdx.x;
+  const int tid = threadIdx.x;
+  const long o0 = spx_off[a];
+  const int ns = (int)(spx_off[a + 1] - o0);
+  if (!active[a]) {
+    if (tid == 0) n_out[a] = 0, nb_out[a] = 0;
+    return;
+  }
+  const double thr = thr_[a];
+  BlockScan scan{wtot};
+
+  // ---- pass 1: nuisance compaction in index order (np.where(test > thr)), candidates count
+  int n = 0, ncand = 0;
+  for (int c0 = 0; c0 < ns; c0 += 1024) {
+    const int i = c0 + tid;
+    const bool valid = i < ns;
+    const int sp = valid ? spx[o0 + i] : 0;
+    const double t = valid ? test[sp] : 0.0;
+    const bool isn = valid && (t > thr);
+    const bool cand = valid && (t > 0.0) && (t <= thr);
+    int tot;
+    const int r = scan.exclusive(isn, tot);
+    if (isn) {
+      nuis[o0 + n + r] = sp;
+      mapO2[sp] += 1;  // mapO2[pypx] += 1                                       (lib :901)
+    }
+    n += tot;
+    int tc;
+    scan.exclusive(cand, tc);
+    ncand += tc;
+  }
+  if (n == 0) {  // while len(pypx) > 0                                           (lib :899)
+    if (tid == 0) active[a] = 0, n_out[a] = 0, nb_out[a] = 0;
+    return;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const int it = nbiter[a] + 1;  // nbiter += 1                                 (lib :900)
+    nbiter[a] = it;
+    s_ncand = it;
+  }
+  __syncthreads();
+  if (s_ncand > itermax) {  // if nbiter > itermax: nstop += 1; break          (lib :902-905)
+    if (tid == 0) {
+      atomicAdd(nstop, 1);
+      active[a] = 0;
+      n_out[a] = 0;
+      nb_out[a] = 0;
+    }
+    return;
+  }
+  // nb = 1 + int(len(nind) / Noise_population), clipped by the slice [:nb]     (lib :914-917)
+  int nb = 1 + (int)floor((double)ncand / noise_pop);
+  if (nb > ncand) nb = ncand;
+
+  if (nb > 0) {
+    // ---- radix select of the nb-th smallest candidate (keys: bits of positive doubles)
+    if (tid == 0) s_prefix = 0ull, s_remaining = nb - 1;
+    unsigned long long maskbits = 0ull;
+    for (int pass = 7; pass >= 0; --pass) {
+      const int shift = pass * 8;
+      if (tid < 256) hist[tid] = 0;
+      __syncthreads();
+      const unsigned long long prefix = s_prefix;
+      for (int i = tid; i < ns; i += 1024) {
+        const double t = test[spx[o0 + i]];
+        if ((t > 0.0) && (t <= thr)) {
+          const unsigned long long key = (unsigned long long)__double_as_longlong(t);
+          if ((key & maskbits) == prefix) atomicAdd(&hist[(int)((key >> shift) & 255ull)], 1);
+        }
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int rem = s_remaining, b = 0;
+        for (; b < 256; ++b) {
+          if (rem < hist[b]) break;
+          rem -= hist[b];
+        }
+        s_remaining = rem;
+        s_prefix = prefix | ((unsigned long long)b << shift);
+      }
+      maskbits |= 255ull << shift;
+      __syncthreads();
+    }
+    const unsigned long long tau = s_prefix;
+    const int need_equal = s_remaining + 1;
+    // ---- emit the background columns.  The reference indexes the *filtered* vector
+    // test[test > 0] and uses those indices on the unfiltered columns (lib :908-917): the
+    // column of a selected element is its rank among the elements with test > 0.
+    int nfilt = 0, neq = 0, nemit = 0;
+    for (int c0 = 0; c0 < ns; c0 += 1024) {
+      const int i = c0 + tid;
+      const bool valid = i < ns;
+      const double t = valid ? test[spx[o0 + i]] : 0.0;
+      const bool pos = valid && (t > 0.0);
+      const bool cand = pos && (t <= thr);
+      const unsigned long long key = (unsigned long long)__double_as_longlong(t);
+      int tf, te, tm;
+      const int rf = scan.exclusive(pos, tf);
+      const bool eq = cand && key == tau;
+      const int re = scan.exclusive(eq, te);
+      const bool emit = cand && (key < tau || (eq && (neq + re) < need_equal));
+      const int rm = scan.exclusive(emit, tm);
+      if (emit) bg[o0 + nemit + rm] = spx[o0 + nfilt + rf];
+      nfilt += tf;
+      neq += te;
+      nemit += tm;
+    }
+  }
+  if (tid == 0) {
+    nb_out[a] = nb;
+    if (n == 1) {  // if x_red.shape[1] == 1: break                              (lib :927-928)
+      active[a] = 0;
+      n_out[a] = 0;
+    } else {
+      n_out[a] = n;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// b_k[z] = mean_{i in bg_k} F[z, bg[i]]        grid (ceil(Nz/4), nw), block (64,4)
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bmean_kernel(const float *__restrict__ F, int Nz, long S,
                                                     const int *__restrict__ bg,
-                                                    const long *__restrict__ bg_off,
+                                                    const long *__restrict__ D, int nw,
                                                     double *__restrict__ b) {
-  const int a = blockIdx.y;
+  const int k = blockIdx.y;
   const int z = blockIdx.x * 4 + threadIdx.y;
   if (z >= Nz) return;
-  const long o0 = bg_off[a], o1 = bg_off[a + 1];
+  const long o0 = DSC(DF_LIST0, k);
+  const int nb = (int)DSC(DF_NB, k);
   const float *row = F + (long)z * S;
   double acc = 0.0;
-  for (long i = o0 + threadIdx.x; i < o1; i += 64) acc += (double)row[bg[i]];
+  for (int i = threadIdx.x; i < nb; i += 64) acc += (double)row[bg[o0 + i]];
   acc = wave_sum_d(acc);
-  if (threadIdx.x == 0) b[(long)a * Nz + z] = acc / (double)(o1 - o0);
+  if (threadIdx.x == 0) b[(long)k * Nz + z] = acc / (double)nb;
 }
 
 // ------------------------------------------------------------------------------------
 // gather the nuisance columns into X (float64, [Nz][ld]) and c_j = b^T X_j
-// grid (ceil(ld/64), na), block (64 columns, 16 waves over z)
+// grid (ceil(ldmax/64), nw), block (64 columns, 16 waves over z)
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void gather_xp_kernel(
-    const float *__restrict__ F, int Nz, long S, const int *__restrict__ nuis,
-    const long *__restrict__ nuis_off, const double *__restrict__ b, double *__restrict__ Xp,
-    const long *__restrict__ xp_off, const int *__restrict__ ld_, double *__restrict__ cvec,
-    const long *__restrict__ c_off) {
+__global__ __launch_bounds__(1024) void gather_xp_kernel(const float *__restrict__ F, int Nz,
+                                                         long S, const int *__restrict__ nuis,
+                                                         const long *__restrict__ D, int nw,
+                                                         const double *__restrict__ b,
+                                                         double *__restrict__ Xp,
+                                                         double *__restrict__ cvec) {
   __shared__ double red[16][64];
-  const int a = blockIdx.y;
-  const int ld = ld_[a];
+  const int k = blockIdx.y;
+  const int ld = (int)DSC(DF_LD, k);
   const int j = blockIdx.x * 64 + threadIdx.x;
   if (blockIdx.x * 64 >= ld) return;  // whole block out of range (uniform)
-  const long n = nuis_off[a + 1] - nuis_off[a];
-  const bool live = j < n;       // real nuisance column
-  const bool inld = j < ld;      // padded column (stored as zeros)
-  const long col = live ? (long)nuis[nuis_off[a] + j] : 0;
-  const double *ba = b + (long)a * Nz;
-  double *X = Xp + xp_off[a];
+  const int n = (int)DSC(DF_N, k);
+  const bool live = j < n;   // real nuisance column
+  const bool inld = j < ld;  // padded column (stored as zeros)
+  const long col = live ? (long)nuis[DSC(DF_LIST0, k) + j] : 0;
+  const double *bk = b + (long)k * Nz;
+  double *X = Xp + DSC(DF_XP, k);
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.y);
   double acc = 0.0;
   for (int z = w; z < Nz; z += 16) {
     const double v = live ? (double)F[(long)z * S + col] : 0.0;
     if (inld) X[(long)z * ld + j] = v;
-    acc = fma(ba[z], v, acc);
+    acc = fma(bk[z], v, acc);
   }
   red[threadIdx.y][threadIdx.x] = acc;
   __syncthreads();
   if (threadIdx.y == 0 && inld) {
     double t = 0.0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
-    cvec[c_off[a] + j] = t;
+    for (int q = 0; q < 16; ++q) t += red[q][threadIdx.x];
+    cvec[DSC(DF_C, k) + j] = t;
   }
 }
 
-// Xp[z][j] -= b[z] c[j]       grid (ceil(Nz/16), na), block 256 (lanes over columns)
+// Xp[z][j] -= b[z] c[j]       grid (ceil(Nz/16), nw), block 256 (lanes over columns)
 __global__ __launch_bounds__(256) void project_xp_kernel(const double *__restrict__ b, int Nz,
+                                                         const long *__restrict__ D, int nw,
                                                          double *__restrict__ Xp,
-                                                         const long *__restrict__ xp_off,
-                                                         const int *__restrict__ ld_,
-                                                         const double *__restrict__ cvec,
-                                                         const long *__restrict__ c_off) {
-  const int a = blockIdx.y;
-  const int ld = ld_[a];
-  double *X = Xp + xp_off[a];
-  const double *c = cvec + c_off[a];
-  const double *ba = b + (long)a * Nz;
+                                                         const double *__restrict__ cvec) {
+  const int k = blockIdx.y;
+  const int ld = (int)DSC(DF_LD, k);
+  double *X = Xp + DSC(DF_XP, k);
+  const double *c = cvec + DSC(DF_C, k);
+  const double *bk = b + (long)k * Nz;
   const int z0 = blockIdx.x * 16, z1 = min(Nz, z0 + 16);
   for (int z = z0; z < z1; ++z) {
-    const double bz = ba[z];
-    for (int j = threadIdx.x; j < ld; j += 256) X[(long)z * ld + j] = fma(-bz, c[j], X[(long)z * ld + j]);
+    const double bz = bk[z];
+    for (int j = threadIdx.x; j < ld; j += 256)
+      X[(long)z * ld + j] = fma(-bz, c[j], X[(long)z * ld + j]);
   }
 }
 
@@ -113,15 +280,16 @@ __global__ __launch_bounds__(256) void project_xp_kernel(const double *__restric
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void gram_kernel(const double *__restrict__ Xp,
                                                   const long *__restrict__ xp_off,
-                                                  const int *__restrict__ ld_,
+                                                  const long *__restrict__ ld_,
                                                   const int *__restrict__ tile_i,
                                                   const int *__restrict__ tile_j,
                                                   const int *__restrict__ tile_a, int Nz,
                                                   int ksplit, double *__restrict__ slab,
-                                                  const long *__restrict__ g_off, long slab_stride) {
+                                                  const long *__restrict__ g_off,
+                                                  long slab_stride) {
   const int t = blockIdx.x;
   const int a = tile_a[t];
-  const int ld = ld_[a];
+  const int ld = (int)ld_[a];
   const int i0 = tile_i[t] * 32, j0 = tile_j[t] * 32;
   const int ks = blockIdx.y;
   const int zper = ((Nz + ksplit - 1) / ksplit + 3) & ~3;
@@ -162,7 +330,7 @@ __global__ __launch_bounds__(64) void gram_kernel(const double *__restrict__ Xp,
 // G[i][j] = sum_ks slab[ks][i][j] for tile (ti <= tj), mirrored into the lower triangle
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const double *__restrict__ slab,
                                                           long slab_stride, int ksplit,
-                                                          const int *__restrict__ ld_,
+                                                          const long *__restrict__ ld_,
                                                           const int *__restrict__ tile_i,
                                                           const int *__restrict__ tile_j,
                                                           const int *__restrict__ tile_a,
@@ -170,172 +338,371 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const double *__restri
                                                           const long *__restrict__ g_off) {
   const int t = blockIdx.x;
   const int a = tile_a[t];
-  const int ld = ld_[a];
+  const int ld = (int)ld_[a];
   const int i0 = tile_i[t] * 32, j0 = tile_j[t] * 32;
   double *Ga = G + g_off[a];
   for (int e = threadIdx.x; e < 1024; e += 256) {
     const int i = i0 + (e >> 5), j = j0 + (e & 31);
     if (i >= ld || j >= ld) continue;
     double acc = 0.0;
-    for (int ks = 0; ks < ksplit; ++ks) acc += slab[(long)ks * slab_stride + g_off[a] + (long)i * ld + j];
+    for (int ks = 0; ks < ksplit; ++ks)
+      acc += slab[(long)ks * slab_stride + g_off[a] + (long)i * ld + j];
     Ga[(long)i * ld + j] = acc;
     Ga[(long)j * ld + i] = acc;
   }
 }
 
 // ------------------------------------------------------------------------------------
-// u = Xp v, then normalised.     grid (ceil(Nz/4), na), block (64,4)
+// Leading eigenvector of the symmetric PSD matrix G (n x n, row stride ld): restarted
+// Lanczos with full (twice-applied classical Gram-Schmidt) re-orthogonalisation.  One block
+// of 1024 threads per matrix; the Krylov basis Q lives in global scratch (L2 resident).
+// The small tridiagonal problem is solved by 64-way multisection on Sturm counts (wave 0)
+// and inverse iteration with partial pivoting (thread 0).
+// ------------------------------------------------------------------------------------
+constexpr int LANCZOS_M = 48;
+
+__device__ __forceinline__ double block_sum(double v, double *red) {
+  v = wave_sum_d(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) t += red[w];
+  return t;
+}
+
+// number of eigenvalues of T (alpha[0..m), beta[0..m-1)) that are < x
+__device__ __forceinline__ int sturm_count(const double *alpha, const double *beta, int m, double x,
+                                           double pivmin) {
+  int cnt = 0;
+  double q = alpha[0] - x;
+  if (fabs(q) < pivmin) q = -pivmin;
+  cnt += q < 0.0;
+  for (int i = 1; i < m; ++i) {
+    q = alpha[i] - x - beta[i - 1] * beta[i - 1] / q;
+    if (fabs(q) < pivmin) q = -pivmin;
+    cnt += q < 0.0;
+  }
+  return cnt;
+}
+
+__global__ __launch_bounds__(1024) void lanczos_kernel(const double *__restrict__ G,
+                                                       const long *__restrict__ g_off,
+                                                       const long *__restrict__ ld_,
+                                                       const long *__restrict__ n_,
+                                                       double *__restrict__ Q,
+                                                       const long *__restrict__ q_off,
+                                                       double *__restrict__ vout,
+                                                       const long *__restrict__ v_off,
+                                                       int max_restart, double tol,
+                                                       double *__restrict__ info) {
+  __shared__ double alpha[LANCZOS_M], beta[LANCZOS_M], svec[LANCZOS_M], h[LANCZOS_M + 1];
+  __shared__ double x[LANCZOS_M], d[LANCZOS_M], du[LANCZOS_M], du2[LANCZOS_M], dl[LANCZOS_M];
+  __shared__ double red[16];
+  __shared__ double s_theta, s_lo, s_hi;
+  __shared__ int s_m;
+  const int k = blockIdx.x;
+  const int n = (int)n_[k], ld = (int)ld_[k];
+  const double *Gk = G + g_off[k];
+  double *Qk = Q + q_off[k];  // (LANCZOS_M + 2) rows of length ld; last row = Ritz vector
+  double *y = Qk + (long)(LANCZOS_M + 1) * ld;
+  double *v = vout + v_off[k];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int mmax = min(LANCZOS_M, n);
+
+  // start vector: G * ones (a few power-like steps come for free in the Krylov space)
+  for (int r = wave; r < n; r += 16) {
+    double acc = 0.0;
+    for (int c = lane; c < n; c += 64) acc += Gk[(long)r * ld + c];
+    acc = wave_sum_d(acc);
+    if (lane == 0) y[r] = acc;
+  }
+  __syncthreads();
+  double theta = 0.0, resid = 0.0;
+  int restarts = 0;
+  for (; restarts < max_restart; ++restarts) {
+    // q_0 = y / |y|
+    double p = 0.0;
+    for (int e = tid; e < n; e += 1024) p = fma(y[e], y[e], p);
+    const double nrm = sqrt(block_sum(p, red));
+    const double inv = nrm > 0.0 ? 1.0 / nrm : 0.0;
+    for (int e = tid; e < n; e += 1024) Qk[e] = (nrm > 0.0) ? y[e] * inv : (e == 0 ? 1.0 : 0.0);
+    __syncthreads();
+    int m = 0;
+    double beta_last = 0.0;
+    for (int j = 0; j < mmax; ++j) {
+      const double *qj = Qk + (long)j * ld;
+      double *w = Qk + (long)(j + 1) * ld;
+      // w = G q_j   (rows over waves, columns over lanes: coalesced, G symmetric)
+      for (int r = wave; r < n; r += 16) {
+        const double *row = Gk + (long)r * ld;
+        double acc = 0.0;
+        for (int c = lane; c < n; c += 64) acc = fma(row[c], qj[c], acc);
+        acc = wave_sum_d(acc);
+        if (lane == 0) w[r] = acc;
+      }
+      __syncthreads();
+      // classical Gram-Schmidt against q_0..q_j, twice; alpha_j = first-pass h_j (+ fix)
+      double aj = 0.0;
+      for (int pass = 0; pass < 2; ++pass) {
+        for (int i = wave; i <= j; i += 16) {
+          const double *qi = Qk + (long)i * ld;
+          double acc = 0.0;
+          for (int c = lane; c < n; c += 64) acc = fma(qi[c], w[c], acc);
+          acc = wave_sum_d(acc);
+          if (lane == 0) h[i] = acc;
+        }
+        __syncthreads();
+        aj += h[j];
+        for (int e = tid; e < n; e += 1024) {
+          double we = w[e];
+          for (int i = 0; i <= j; ++i) we = fma(-h[i], Qk[(long)i * ld + e], we);
+          w[e] = we;
+        }
+        __syncthreads();
+      }
+      double pw = 0.0;
+      for (int e = tid; e < n; e += 1024) pw = fma(w[e], w[e], pw);
+      const double bj = sqrt(block_sum(pw, red));
+      if (tid == 0) alpha[j] = aj, beta[j] = bj;
+      m = j + 1;
+      beta_last = bj;
+      // invariant subspace reached (also the exact case m == n)
+      if (bj <= 1e-300 || bj <= 1e-15 * fabs(aj)) break;
+      if (j + 1 < mmax) {
+        const double ib = 1.0 / bj;
+        for (int e = tid; e < n; e += 1024) w[e] *= ib;
+      }
+      __syncthreads();
+    }
+    __syncthreads();
+    // ---- largest eigenvalue of T_m by multisection (wave 0)
+    if (wave == 0) {
+      double lo = 1e300, hi = -1e300, tn = 0.0;
+      for (int i = 0; i < m; ++i) {
+        const double r = (i > 0 ? fabs(beta[i - 1]) : 0.0) + (i < m - 1 ? fabs(beta[i]) : 0.0);
+        lo = fmin(lo, alpha[i] - r);
+        hi = fmax(hi, alpha[i] + r);
+        tn = fmax(tn, fabs(alpha[i]) + r);
+      }
+      const double pivmin = fmax(tn * tn, 1.0) * 1e-300 + 1e-290;
+      hi += 1e-14 * tn + 1e-300;
+      for (int it = 0; it < 12; ++it) {
+        // lane l tests x_l = lo + (l+1) (hi-lo)/65 ; count(x) == m  <=>  x > theta_max
+        const double x = lo + (hi - lo) * (double)(lane + 1) / 65.0;
+        const bool above = sturm_count(alpha, beta, m, x, pivmin) >= m;
+        const unsigned long long bal = __ballot(above);
+        const int first = bal ? __ffsll((long long)bal) - 1 : 64;  // first lane above
+        const double nlo = first == 0 ? lo : lo + (hi - lo) * (double)first / 65.0;
+        const double nhi = first == 64 ? hi : lo + (hi - lo) * (double)(first + 1) / 65.0;
+        lo = nlo;
+        hi = nhi;
+      }
+      if (lane == 0) s_theta = 0.5 * (lo + hi), s_lo = lo, s_hi = hi, s_m = m;
+    }
+    __syncthreads();
+    // ---- Ritz vector of T_m: inverse iteration with partial pivoting (thread 0)
+    if (tid == 0) {
+      const int mm = s_m;
+      double tnorm = 0.0;
+      for (int i = 0; i < mm; ++i) tnorm = fmax(tnorm, fabs(alpha[i]) + (i < mm - 1 ? fabs(beta[i]) : 0.0));
+      const double sigma = s_theta + 4e-16 * tnorm;
+      for (int i = 0; i < mm; ++i) x[i] = 1.0 / sqrt((double)mm);
+      for (int iter = 0; iter < 3; ++iter) {
+        for (int i = 0; i < mm; ++i) {
+          d[i] = alpha[i] - sigma;
+          du[i] = i < mm - 1 ? beta[i] : 0.0;
+          dl[i] = du[i];
+          du2[i] = 0.0;
+        }
+        // LU with partial pivoting (dgtsv), solving in place
+        for (int i = 0; i < mm - 1; ++i) {
+          if (fabs(d[i]) >= fabs(dl[i])) {
+            if (d[i] == 0.0) d[i] = 1e-300;
+            const double f = dl[i] / d[i];
+            d[i + 1] -= f * du[i];
+            x[i + 1] -= f * x[i];
+            dl[i] = 0.0;
+          } else {
+            const double f = d[i] / dl[i];
+            d[i] = dl[i];
+            const double t = d[i + 1];
+            d[i + 1] = du[i] - f * t;
+            du2[i] = (i < mm - 2) ? du[i + 1] : 0.0;
+            if (i < mm - 2) du[i + 1] = -f * du2[i];
+            du[i] = t;
+            const double tx = x[i];
+            x[i] = x[i + 1];
+            x[i + 1] = tx - f * x[i + 1];
+          }
+        }
+        if (d[mm - 1] == 0.0) d[mm - 1] = 1e-300;
+        x[mm - 1] /= d[mm - 1];
+        if (mm > 1) x[mm - 2] = (x[mm - 2] - du[mm - 2] * x[mm - 1]) / d[mm - 2];
+        for (int i = mm - 3; i >= 0; --i) x[i] = (x[i] - du[i] * x[i + 1] - du2[i] * x[i + 2]) / d[i];
+        double nx = 0.0;
+        for (int i = 0; i < mm; ++i) nx += x[i] * x[i];
+        nx = 1.0 / sqrt(nx);
+        for (int i = 0; i < mm; ++i) x[i] *= nx;
+      }
+      for (int i = 0; i < mm; ++i) svec[i] = x[i];
+    }
+    __syncthreads();
+    theta = s_theta;
+    // y = Q s
+    for (int e = tid; e < n; e += 1024) {
+      double acc = 0.0;
+      for (int i = 0; i < m; ++i) acc = fma(svec[i], Qk[(long)i * ld + e], acc);
+      y[e] = acc;
+    }
+    resid = fabs(beta_last * svec[m - 1]);
+    __syncthreads();
+    if (m >= n || resid <= tol * fabs(theta)) break;
+  }
+  // final normalisation of the eigenvector
+  double p = 0.0;
+  for (int e = tid; e < n; e += 1024) p = fma(y[e], y[e], p);
+  const double nrm = sqrt(block_sum(p, red));
+  const double inv = nrm > 0.0 ? 1.0 / nrm : 0.0;
+  for (int e = tid; e < n; e += 1024) v[e] = y[e] * inv;
+  for (int e = n + tid; e < ld; e += 1024) v[e] = 0.0;
+  if (tid == 0 && info) {
+    info[3 * k] = theta;
+    info[3 * k + 1] = resid;
+    info[3 * k + 2] = (double)restarts;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// u = Xp v, then normalised.     grid (ceil(Nz/4), nw), block (64,4)
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void xv_kernel(const double *__restrict__ Xp,
-                                                 const long *__restrict__ xp_off,
-                                                 const int *__restrict__ ld_,
-                                                 const int *__restrict__ n_, int Nz,
+                                                 const long *__restrict__ D, int nw, int Nz,
                                                  const double *__restrict__ v,
-                                                 const long *__restrict__ v_off,
                                                  double *__restrict__ u) {
-  const int a = blockIdx.y;
+  const int k = blockIdx.y;
   const int z = blockIdx.x * 4 + threadIdx.y;
   if (z >= Nz) return;
-  const int ld = ld_[a], n = n_[a];
-  const double *row = Xp + xp_off[a] + (long)z * ld;
-  const double *va = v + v_off[a];
+  const int ld = (int)DSC(DF_LD, k), n = (int)DSC(DF_N, k);
+  const double *row = Xp + DSC(DF_XP, k) + (long)z * ld;
+  const double *vk = v + DSC(DF_C, k);
   double acc = 0.0;
-  for (int j = threadIdx.x; j < n; j += 64) acc = fma(row[j], va[j], acc);
+  for (int j = threadIdx.x; j < n; j += 64) acc = fma(row[j], vk[j], acc);
   acc = wave_sum_d(acc);
-  if (threadIdx.x == 0) u[(long)a * Nz + z] = acc;
+  if (threadIdx.x == 0) u[(long)k * Nz + z] = acc;
 }
 
 __global__ __launch_bounds__(1024) void normalize_kernel(double *__restrict__ u, int Nz) {
   __shared__ double red[16];
-  __shared__ double inv;
-  double *ua = u + (long)blockIdx.x * Nz;
+  double *uk = u + (long)blockIdx.x * Nz;
   double acc = 0.0;
-  for (int z = threadIdx.x; z < Nz; z += 1024) acc = fma(ua[z], ua[z], acc);
-  acc = wave_sum_d(acc);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double t = 0.0;
-    for (int i = 0; i < 16; ++i) t += red[i];
-    inv = t > 0.0 ? 1.0 / sqrt(t) : 0.0;
-  }
-  __syncthreads();
-  for (int z = threadIdx.x; z < Nz; z += 1024) ua[z] *= inv;
+  for (int z = threadIdx.x; z < Nz; z += 1024) acc = fma(uk[z], uk[z], acc);
+  const double t = block_sum(acc, red);
+  const double inv = t > 0.0 ? 1.0 / sqrt(t) : 0.0;
+  for (int z = threadIdx.x; z < Nz; z += 1024) uk[z] *= inv;
 }
 
 // ------------------------------------------------------------------------------------
 // deflation of whole areas.
-//   dot    : cpart[zs][i] = sum_{z in slice zs} u_a[z] F[z, spx[i]]
-//   update : c_i = sum_zs cpart ; F[z, spx[i]] -= u_a[z] c_i ; o2part[zs][i] = sum F_new^2
+//   dot    : cpart[zs][i] = sum_{z in slice zs} u_k[z] F[z, spx[i]]
+//   update : c_i = sum_zs cpart ; F[z, spx[i]] -= u_k[z] c_i ; o2part[zs][i] = sum F_new^2
 //   final  : test[spx[i]] = sum_zs o2part / Nz
-// grid (ceil(max_ns/256), ZS, na); block 256 lanes over the area's spaxel list
+// grid (ceil(nsmax/256), ZS, nw); block 256 lanes over the area's spaxel list
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void deflate_dot_kernel(const float *__restrict__ F, int Nz,
                                                           long S, const int *__restrict__ spx,
-                                                          const long *__restrict__ spx_off,
+                                                          const long *__restrict__ D, int nw,
                                                           const double *__restrict__ u, int zper,
-                                                          double *__restrict__ cpart,
-                                                          long ntot) {
-  const int a = blockIdx.z;
-  const long o0 = spx_off[a], o1 = spx_off[a + 1];
-  const long i = o0 + (long)blockIdx.x * 256 + threadIdx.x;
-  if (o0 + (long)blockIdx.x * 256 >= o1) return;
-  const bool live = i < o1;
-  const long col = spx[live ? i : o1 - 1];
-  const double *ua = u + (long)a * Nz;
+                                                          double *__restrict__ cpart, long ntot) {
+  const int k = blockIdx.z;
+  const int ns = (int)DSC(DF_NS, k);
+  const int li = blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x * 256 >= ns) return;
+  const bool live = li < ns;
+  const long col = spx[DSC(DF_LIST0, k) + (live ? li : ns - 1)];
+  const double *uk = u + (long)k * Nz;
   const int z0 = blockIdx.y * zper, z1 = min(Nz, z0 + zper);
   double acc = 0.0;
 #pragma unroll 4
-  for (int z = z0; z < z1; ++z) acc = fma(ua[z], (double)F[(long)z * S + col], acc);
-  if (live) cpart[(long)blockIdx.y * ntot + i] = acc;
+  for (int z = z0; z < z1; ++z) acc = fma(uk[z], (double)F[(long)z * S + col], acc);
+  if (live) cpart[(long)blockIdx.y * ntot + DSC(DF_CBASE, k) + li] = acc;
 }
 
 __global__ __launch_bounds__(256) void deflate_update_kernel(float *__restrict__ F, int Nz, long S,
                                                              const int *__restrict__ spx,
-                                                             const long *__restrict__ spx_off,
+                                                             const long *__restrict__ D, int nw,
                                                              const double *__restrict__ u,
                                                              int zper, int nzs,
                                                              const double *__restrict__ cpart,
                                                              double *__restrict__ o2part,
                                                              long ntot) {
-  const int a = blockIdx.z;
-  const long o0 = spx_off[a], o1 = spx_off[a + 1];
-  const long i = o0 + (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= o1) return;
-  const long col = spx[i];
-  const double *ua = u + (long)a * Nz;
+  const int k = blockIdx.z;
+  const int ns = (int)DSC(DF_NS, k);
+  const int li = blockIdx.x * 256 + threadIdx.x;
+  if (li >= ns) return;
+  const long col = spx[DSC(DF_LIST0, k) + li];
+  const long ci = DSC(DF_CBASE, k) + li;
+  const double *uk = u + (long)k * Nz;
   double c = 0.0;
-  for (int k = 0; k < nzs; ++k) c += cpart[(long)k * ntot + i];
+  for (int q = 0; q < nzs; ++q) c += cpart[(long)q * ntot + ci];
   const int z0 = blockIdx.y * zper, z1 = min(Nz, z0 + zper);
   double acc = 0.0;
 #pragma unroll 4
   for (int z = z0; z < z1; ++z) {
     const long idx = (long)z * S + col;
-    const float nv = (float)fma(-ua[z], c, (double)F[idx]);
+    const float nv = (float)fma(-uk[z], c, (double)F[idx]);
     F[idx] = nv;
     acc = fma((double)nv, (double)nv, acc);
   }
-  o2part[(long)blockIdx.y * ntot + i] = acc;
+  o2part[(long)blockIdx.y * ntot + ci] = acc;
 }
 
-__global__ __launch_bounds__(256) void deflate_final_kernel(const int *__restrict__ spx, long ntot,
-                                                            int nzs, int Nz,
+__global__ __launch_bounds__(256) void deflate_final_kernel(const int *__restrict__ spx,
+                                                            const long *__restrict__ D, int nw,
+                                                            int nzs, int Nz, long ntot,
                                                             const double *__restrict__ o2part,
                                                             double *__restrict__ test) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= ntot) return;
+  const int k = blockIdx.y;
+  const int ns = (int)DSC(DF_NS, k);
+  const int li = blockIdx.x * 256 + threadIdx.x;
+  if (li >= ns) return;
+  const long ci = DSC(DF_CBASE, k) + li;
   double acc = 0.0;
-  for (int k = 0; k < nzs; ++k) acc += o2part[(long)k * ntot + i];
-  test[spx[i]] = acc / (double)Nz;
+  for (int q = 0; q < nzs; ++q) acc += o2part[(long)q * ntot + ci];
+  test[spx[DSC(DF_LIST0, k) + li]] = acc / (double)Nz;
 }
 
-}  // namespace
-
-// host-side view of small descriptor arrays that live on the device: the batched kernels
-// need a few of them on the host to size grids, so the binding passes both.
-extern "C" {
-
-int origin_pca_bmean(origin_ctx *ctx, const float *d_F, int Nz, long S, const int *d_bg,
-                     const long *d_bg_off, int na, double *d_b) {
-  ORIGIN_USE(ctx);
-  ORIGIN_CHECK_ARG(d_F && d_bg && d_bg_off && d_b && Nz > 0 && S > 0 && na > 0, "bad arguments");
-  ProfScope ps(ctx, K_PCA_BMEAN);
-  hipLaunchKernelGGL(bmean_kernel, dim3(cdiv(Nz, 4), na), dim3(64, 4), 0, ctx->stream, d_F, Nz, S,
-                     d_bg, d_bg_off, d_b);
-  ORIGIN_LAUNCH_CHECK();
-  return ORIGIN_OK;
-}
-
-int origin_pca_build_xp(origin_ctx *ctx, const float *d_F, int Nz, long S, const int *d_nuis,
-                        const long *d_nuis_off, int na, int ldmax, const double *d_b,
-                        double *d_Xp, const long *d_xp_off, const int *d_ld, double *d_c,
-                        const long *d_c_off) {
-  ORIGIN_USE(ctx);
-  ORIGIN_CHECK_ARG(d_F && d_nuis && d_nuis_off && d_b && d_Xp && d_xp_off && d_ld && d_c &&
-                       d_c_off && Nz > 0 && S > 0 && na > 0 && ldmax > 0,
-                   "bad arguments");
-  {
-    ProfScope ps(ctx, K_PCA_GATHER);
-    hipLaunchKernelGGL(gather_xp_kernel, dim3(cdiv(ldmax, 64), na), dim3(64, 16), 0, ctx->stream,
-                       d_F, Nz, S, d_nuis, d_nuis_off, d_b, d_Xp, d_xp_off, d_ld, d_c, d_c_off);
+// ------------------------------------------------------------------------------------
+// host helpers
+// ------------------------------------------------------------------------------------
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  int reserve(origin_ctx *ctx, size_t want) {
+    if (want <= bytes) return ORIGIN_OK;
+    if (p) {
+      ORIGIN_HIP(hipStreamSynchronize(ctx->stream));
+      ORIGIN_HIP(hipFree(p));
+      p = nullptr;
+      bytes = 0;
+    }
+    const size_t n = want + want / 4 + 4096;
+    ORIGIN_HIP(hipMalloc(&p, n));
+    bytes = n;
+    return ORIGIN_OK;
   }
-  {
-    ProfScope ps(ctx, K_PCA_PROJECT);
-    hipLaunchKernelGGL(project_xp_kernel, dim3(cdiv(Nz, 16), na), dim3(256), 0, ctx->stream, d_b,
-                       Nz, d_Xp, d_xp_off, d_ld, d_c, d_c_off);
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
   }
-  ORIGIN_LAUNCH_CHECK();
-  return ORIGIN_OK;
-}
+  ~DevBuf() { release(); }
+};
 
-int origin_pca_gram(origin_ctx *ctx, const double *d_Xp, const long *d_xp_off,
-                    const int *d_ld, int Nz, int ntiles, const int *d_tile_i,
-                    const int *d_tile_j, const int *d_tile_a, long g_total, double *d_G,
-                    const long *d_g_off) {
-  ORIGIN_USE(ctx);
-  ORIGIN_CHECK_ARG(d_Xp && d_xp_off && d_ld && d_tile_i && d_tile_j && d_tile_a && d_G &&
-                       d_g_off && Nz > 0 && ntiles > 0 && g_total > 0,
-                   "bad arguments");
+int gram_launch(origin_ctx *ctx, const double *d_Xp, const long *d_xp_off, const long *d_ld, int Nz,
+                int ntiles, const int *d_ti, const int *d_tj, const int *d_ta, long g_total,
+                double *d_G, const long *d_g_off) {
   // K-split so that small problems still put >= ~8 waves on every CU
   int ksplit = (int)(((long)ctx->num_cu * 8 + ntiles - 1) / ntiles);
   if (ksplit < 1) ksplit = 1;
@@ -346,63 +713,253 @@ int origin_pca_gram(origin_ctx *ctx, const double *d_Xp, const long *d_xp_off,
   if (rc) return rc;
   ProfScope ps(ctx, K_PCA_GRAM);
   hipLaunchKernelGGL(gram_kernel, dim3(ntiles, ksplit), dim3(64), 0, ctx->stream, d_Xp, d_xp_off,
-                     d_ld, d_tile_i, d_tile_j, d_tile_a, Nz, ksplit, (double *)scr, d_g_off,
-                     g_total);
+                     d_ld, d_ti, d_tj, d_ta, Nz, ksplit, (double *)scr, d_g_off, g_total);
   hipLaunchKernelGGL(gram_reduce_kernel, dim3(ntiles), dim3(256), 0, ctx->stream,
-                     (const double *)scr, g_total, ksplit, d_ld, d_tile_i, d_tile_j, d_tile_a, d_G,
-                     d_g_off);
+                     (const double *)scr, g_total, ksplit, d_ld, d_ti, d_tj, d_ta, d_G, d_g_off);
   ORIGIN_LAUNCH_CHECK();
   return ORIGIN_OK;
 }
 
-int origin_pca_uvec(origin_ctx *ctx, const double *d_Xp, const long *d_xp_off, const int *d_ld,
-                    const int *d_n, int na, int Nz, const double *d_v, const long *d_v_off,
-                    double *d_u) {
+}  // namespace
+
+extern "C" {
+
+// Stand-alone Gram product (used by tests): nmat matrices, offsets/ld as int64 arrays.
+int origin_pca_gram(origin_ctx *ctx, const double *d_Xp, const long *d_xp_off, const long *d_ld,
+                    int Nz, int ntiles, const int *d_tile_i, const int *d_tile_j,
+                    const int *d_tile_a, long g_total, double *d_G, const long *d_g_off) {
   ORIGIN_USE(ctx);
-  ORIGIN_CHECK_ARG(d_Xp && d_xp_off && d_ld && d_n && d_v && d_v_off && d_u && na > 0 && Nz > 0,
+  ORIGIN_CHECK_ARG(d_Xp && d_xp_off && d_ld && d_tile_i && d_tile_j && d_tile_a && d_G &&
+                       d_g_off && Nz > 0 && ntiles > 0 && g_total > 0,
                    "bad arguments");
-  ProfScope ps(ctx, K_PCA_UVEC);
-  hipLaunchKernelGGL(xv_kernel, dim3(cdiv(Nz, 4), na), dim3(64, 4), 0, ctx->stream, d_Xp, d_xp_off,
-                     d_ld, d_n, Nz, d_v, d_v_off, d_u);
-  hipLaunchKernelGGL(normalize_kernel, dim3(na), dim3(1024), 0, ctx->stream, d_u, Nz);
-  ORIGIN_LAUNCH_CHECK();
-  return ORIGIN_OK;
+  return gram_launch(ctx, d_Xp, d_xp_off, d_ld, Nz, ntiles, d_tile_i, d_tile_j, d_tile_a, g_total,
+                     d_G, d_g_off);
 }
 
-int origin_pca_deflate(origin_ctx *ctx, float *d_F, int Nz, long S, const int *d_spx,
-                       const long *d_spx_off, int na, long ntot, int nsmax, const double *d_u,
-                       double *d_test) {
+// Stand-alone leading eigenvector of nmat symmetric PSD matrices (used by tests).
+// d_info (may be NULL): per matrix (theta, residual, restarts).
+int origin_pca_eig(origin_ctx *ctx, const double *d_G, const long *d_g_off, const long *d_ld,
+                   const long *d_n, int nmat, long q_total, const long *d_q_off, double *d_v,
+                   const long *d_v_off, double *d_info) {
   ORIGIN_USE(ctx);
-  ORIGIN_CHECK_ARG(d_F && d_spx && d_spx_off && d_u && d_test && Nz > 0 && S > 0 && na > 0 &&
-                       ntot > 0 && nsmax > 0,
+  ORIGIN_CHECK_ARG(d_G && d_g_off && d_ld && d_n && d_q_off && d_v && d_v_off && nmat > 0 &&
+                       q_total > 0,
                    "bad arguments");
-  const long blocks = (long)cdiv(nsmax, 256) * na;
-  int nzs = (int)(((long)ctx->num_cu * 8 + blocks - 1) / blocks);
-  if (nzs < 1) nzs = 1;
-  if (nzs > 32) nzs = 32;
-  if (nzs > Nz) nzs = Nz;
-  const int zper = cdiv(Nz, nzs);
-  nzs = cdiv(Nz, zper);
   void *scr = nullptr;
-  int rc = origin_scratch(ctx, (size_t)2 * nzs * ntot * sizeof(double), &scr);
+  int rc = origin_scratch(ctx, (size_t)q_total * sizeof(double), &scr);
   if (rc) return rc;
-  double *cpart = (double *)scr;
-  double *o2part = cpart + (size_t)nzs * ntot;
-  dim3 grid(cdiv(nsmax, 256), nzs, na);
-  {
-    ProfScope ps(ctx, K_PCA_DEFLATE_DOT);
-    hipLaunchKernelGGL(deflate_dot_kernel, grid, dim3(256), 0, ctx->stream, d_F, Nz, S, d_spx,
-                       d_spx_off, d_u, zper, cpart, ntot);
-  }
-  {
-    ProfScope ps(ctx, K_PCA_DEFLATE_UPDATE);
-    hipLaunchKernelGGL(deflate_update_kernel, grid, dim3(256), 0, ctx->stream, d_F, Nz, S, d_spx,
-                       d_spx_off, d_u, zper, nzs, cpart, o2part, ntot);
-  }
-  ProfScope ps(ctx, K_SMALL);
-  hipLaunchKernelGGL(deflate_final_kernel, dim3(cdiv(ntot, 256)), dim3(256), 0, ctx->stream, d_spx,
-                     ntot, nzs, Nz, o2part, d_test);
+  ProfScope ps(ctx, K_PCA_EIG);
+  hipLaunchKernelGGL(lanczos_kernel, dim3(nmat), dim3(1024), 0, ctx->stream, d_G, d_g_off, d_ld, d_n,
+                     (double *)scr, d_q_off, d_v, d_v_off, 60, 1e-14, d_info);
   ORIGIN_LAUNCH_CHECK();
+  return ORIGIN_OK;
+}
+
+int origin_pca_eig_qrows(void) { return LANCZOS_M + 2; }
+
+// The whole greedy PCA of `na` areas, in place on d_F.
+int origin_pca_run(origin_ctx *ctx, float *d_F, int Nz, long S, int na, const int *d_spx,
+                   const long *h_spx_off, const double *d_test0, const double *h_thr,
+                   double noise_pop, int itermax, int *d_mapO2, int *h_nstop, int *h_iters,
+                   long *h_trace, int trace_cap) {
+  ORIGIN_USE(ctx);
+  ORIGIN_CHECK_ARG(d_F && d_spx && h_spx_off && d_test0 && h_thr && d_mapO2 && h_nstop &&
+                       Nz > 0 && S > 0 && na > 0,
+                   "bad arguments");
+  ORIGIN_CHECK_ARG(noise_pop > 0 && itermax >= 0, "bad Noise_population / itermax");
+  const long ntot = h_spx_off[na];
+  ORIGIN_CHECK_ARG(ntot >= 0 && ntot <= S, "area lists longer than the field");
+  hipStream_t st = ctx->stream;
+  if (h_iters) *h_iters = 0;
+  *h_nstop = 0;
+  ORIGIN_HIP(hipMemsetAsync(d_mapO2, 0, (size_t)S * sizeof(int), st));
+  if (ntot == 0) return ORIGIN_OK;
+
+  // ---- persistent state on the device
+  DevBuf b_state, b_lists, b_test, b_desc, b_tiles, b_xp, b_g, b_cv, b_bu, b_part;
+  const size_t st_bytes = (size_t)na * (sizeof(double) + 4 * sizeof(int)) + sizeof(int) * 2 +
+                          (size_t)(na + 1) * sizeof(long) + 64;
+  int rc;
+  if ((rc = b_state.reserve(ctx, st_bytes))) return rc;
+  char *sp = (char *)b_state.p;
+  double *d_thr = (double *)sp;
+  sp += (size_t)na * sizeof(double);
+  long *d_spx_off = (long *)sp;
+  sp += (size_t)(na + 1) * sizeof(long);
+  int *d_active = (int *)sp;
+  sp += (size_t)na * sizeof(int);
+  int *d_nbiter = (int *)sp;
+  sp += (size_t)na * sizeof(int);
+  int *d_n = (int *)sp;  // n and nb are contiguous: one read-back
+  sp += (size_t)na * sizeof(int);
+  int *d_nb = (int *)sp;
+  sp += (size_t)na * sizeof(int);
+  int *d_nstop = (int *)sp;
+  std::vector<int> ones(na, 1);
+  ORIGIN_HIP(hipMemcpyAsync(d_thr, h_thr, (size_t)na * sizeof(double), hipMemcpyHostToDevice, st));
+  ORIGIN_HIP(hipMemcpyAsync(d_spx_off, h_spx_off, (size_t)(na + 1) * sizeof(long),
+                            hipMemcpyHostToDevice, st));
+  ORIGIN_HIP(hipMemcpyAsync(d_active, ones.data(), (size_t)na * sizeof(int), hipMemcpyHostToDevice,
+                            st));
+  ORIGIN_HIP(hipMemsetAsync(d_nbiter, 0, (size_t)na * sizeof(int), st));
+  ORIGIN_HIP(hipMemsetAsync(d_nstop, 0, sizeof(int), st));
+  ORIGIN_HIP(hipStreamSynchronize(st));  // `ones` goes out of use
+  if ((rc = b_lists.reserve(ctx, (size_t)2 * ntot * sizeof(int)))) return rc;
+  int *d_nuis = (int *)b_lists.p, *d_bg = d_nuis + ntot;
+  if ((rc = b_test.reserve(ctx, (size_t)S * sizeof(double)))) return rc;
+  double *d_test = (double *)b_test.p;
+  ORIGIN_HIP(hipMemcpyAsync(d_test, d_test0, (size_t)S * sizeof(double), hipMemcpyDeviceToDevice,
+                            st));
+
+  int *h_nnb = nullptr;  // pinned read-back buffer [2*na]
+  ORIGIN_HIP(hipHostMalloc((void **)&h_nnb, (size_t)2 * na * sizeof(int), hipHostMallocDefault));
+  struct Pinned {
+    int *p;
+    ~Pinned() { (void)hipHostFree(p); }
+  } pinned{h_nnb};
+
+  std::vector<long> D;
+  std::vector<int> tiles;
+  int iters = 0;
+  for (;;) {
+    {
+      ProfScope ps(ctx, K_PCA_SELECT);
+      hipLaunchKernelGGL(pca_select_kernel, dim3(na), dim3(1024), 0, st, d_spx, d_spx_off, d_test,
+                         d_thr, noise_pop, itermax, d_active, d_nbiter, d_nstop, d_mapO2, d_nuis,
+                         d_bg, d_n, d_nb);
+    }
+    ORIGIN_LAUNCH_CHECK();
+    ORIGIN_HIP(hipMemcpyAsync(h_nnb, d_n, (size_t)2 * na * sizeof(int), hipMemcpyDeviceToHost, st));
+    ORIGIN_HIP(hipStreamSynchronize(st));
+    // ---- work list of this iteration
+    int nw = 0;
+    for (int a = 0; a < na; ++a) nw += h_nnb[a] >= 2;
+    if (nw == 0) break;
+    D.assign((size_t)DF_COUNT * nw, 0);
+    tiles.clear();
+    long xp = 0, c = 0, g = 0, q = 0, cb = 0;
+    int ldmax = 0, nsmax = 0, k = 0;
+    std::vector<int> ti, tj, ta;
+    long nsum = 0;
+    for (int a = 0; a < na; ++a) {
+      const int n = h_nnb[a];
+      if (n < 2) continue;
+      const int ld = (n + 15) / 16 * 16;
+      const int ns = (int)(h_spx_off[a + 1] - h_spx_off[a]);
+      D[(size_t)DF_AREA * nw + k] = a;
+      D[(size_t)DF_LIST0 * nw + k] = h_spx_off[a];
+      D[(size_t)DF_N * nw + k] = n;
+      D[(size_t)DF_NB * nw + k] = h_nnb[na + a];
+      D[(size_t)DF_LD * nw + k] = ld;
+      D[(size_t)DF_XP * nw + k] = xp;
+      D[(size_t)DF_C * nw + k] = c;
+      D[(size_t)DF_G * nw + k] = g;
+      D[(size_t)DF_Q * nw + k] = q;
+      D[(size_t)DF_NS * nw + k] = ns;
+      D[(size_t)DF_CBASE * nw + k] = cb;
+      xp += (long)Nz * ld;
+      c += ld;
+      g += (long)ld * ld;
+      q += (long)(LANCZOS_M + 2) * ld;
+      cb += ns;
+      ldmax = std::max(ldmax, ld);
+      nsmax = std::max(nsmax, ns);
+      nsum += n;
+      const int T = (ld + 31) / 32;
+      for (int i = 0; i < T; ++i)
+        for (int j = i; j < T; ++j) ti.push_back(i), tj.push_back(j), ta.push_back(k);
+      ++k;
+    }
+    if (h_trace && iters < trace_cap) {
+      h_trace[2 * iters] = nw;
+      h_trace[2 * iters + 1] = nsum;
+    }
+    const int ntiles = (int)ti.size();
+    if ((rc = b_desc.reserve(ctx, D.size() * sizeof(long)))) return rc;
+    if ((rc = b_tiles.reserve(ctx, (size_t)3 * ntiles * sizeof(int)))) return rc;
+    long *dD = (long *)b_desc.p;
+    int *d_ti = (int *)b_tiles.p, *d_tj = d_ti + ntiles, *d_ta = d_tj + ntiles;
+    ORIGIN_HIP(hipMemcpyAsync(dD, D.data(), D.size() * sizeof(long), hipMemcpyHostToDevice, st));
+    ORIGIN_HIP(hipMemcpyAsync(d_ti, ti.data(), (size_t)ntiles * sizeof(int), hipMemcpyHostToDevice, st));
+    ORIGIN_HIP(hipMemcpyAsync(d_tj, tj.data(), (size_t)ntiles * sizeof(int), hipMemcpyHostToDevice, st));
+    ORIGIN_HIP(hipMemcpyAsync(d_ta, ta.data(), (size_t)ntiles * sizeof(int), hipMemcpyHostToDevice, st));
+    ORIGIN_HIP(hipStreamSynchronize(st));  // pageable sources are reused next iteration
+    if ((rc = b_xp.reserve(ctx, (size_t)xp * sizeof(double)))) return rc;
+    if ((rc = b_g.reserve(ctx, (size_t)g * sizeof(double)))) return rc;
+    if ((rc = b_cv.reserve(ctx, (size_t)2 * c * sizeof(double)))) return rc;
+    if ((rc = b_bu.reserve(ctx, (size_t)2 * nw * Nz * sizeof(double)))) return rc;
+    double *d_Xp = (double *)b_xp.p, *d_G = (double *)b_g.p;
+    double *d_c = (double *)b_cv.p, *d_v = d_c + c;
+    double *d_b = (double *)b_bu.p, *d_u = d_b + (size_t)nw * Nz;
+    const long *dLD = dD + (size_t)DF_LD * nw, *dXP = dD + (size_t)DF_XP * nw;
+    const long *dG = dD + (size_t)DF_G * nw, *dQ = dD + (size_t)DF_Q * nw;
+    const long *dN = dD + (size_t)DF_N * nw, *dC = dD + (size_t)DF_C * nw;
+
+    {
+      ProfScope ps(ctx, K_PCA_BMEAN);
+      hipLaunchKernelGGL(bmean_kernel, dim3(cdiv(Nz, 4), nw), dim3(64, 4), 0, st, d_F, Nz, S, d_bg,
+                         dD, nw, d_b);
+    }
+    {
+      ProfScope ps(ctx, K_PCA_GATHER);
+      hipLaunchKernelGGL(gather_xp_kernel, dim3(cdiv(ldmax, 64), nw), dim3(64, 16), 0, st, d_F, Nz,
+                         S, d_nuis, dD, nw, d_b, d_Xp, d_c);
+    }
+    {
+      ProfScope ps(ctx, K_PCA_PROJECT);
+      hipLaunchKernelGGL(project_xp_kernel, dim3(cdiv(Nz, 16), nw), dim3(256), 0, st, d_b, Nz, dD,
+                         nw, d_Xp, d_c);
+    }
+    ORIGIN_LAUNCH_CHECK();
+    if ((rc = gram_launch(ctx, d_Xp, dXP, dLD, Nz, ntiles, d_ti, d_tj, d_ta, g, d_G, dG))) return rc;
+    {
+      void *scr = nullptr;
+      if ((rc = b_part.reserve(ctx, (size_t)q * sizeof(double)))) return rc;
+      scr = b_part.p;
+      ProfScope ps(ctx, K_PCA_EIG);
+      hipLaunchKernelGGL(lanczos_kernel, dim3(nw), dim3(1024), 0, st, d_G, dG, dLD, dN,
+                         (double *)scr, dQ, d_v, dC, 60, 1e-14, (double *)nullptr);
+    }
+    {
+      ProfScope ps(ctx, K_PCA_UVEC);
+      hipLaunchKernelGGL(xv_kernel, dim3(cdiv(Nz, 4), nw), dim3(64, 4), 0, st, d_Xp, dD, nw, Nz,
+                         d_v, d_u);
+      hipLaunchKernelGGL(normalize_kernel, dim3(nw), dim3(1024), 0, st, d_u, Nz);
+    }
+    ORIGIN_LAUNCH_CHECK();
+    // ---- deflation
+    const long blocks = (long)cdiv(nsmax, 256) * nw;
+    int nzs = (int)(((long)ctx->num_cu * 8 + blocks - 1) / blocks);
+    nzs = std::max(1, std::min(nzs, 32));
+    nzs = std::min(nzs, Nz);
+    const int zper = cdiv(Nz, nzs);
+    nzs = cdiv(Nz, zper);
+    void *scr = nullptr;
+    if ((rc = origin_scratch(ctx, (size_t)2 * nzs * cb * sizeof(double), &scr))) return rc;
+    double *cpart = (double *)scr, *o2part = cpart + (size_t)nzs * cb;
+    dim3 grid(cdiv(nsmax, 256), nzs, nw);
+    {
+      ProfScope ps(ctx, K_PCA_DEFLATE_DOT);
+      hipLaunchKernelGGL(deflate_dot_kernel, grid, dim3(256), 0, st, d_F, Nz, S, d_spx, dD, nw, d_u,
+                         zper, cpart, cb);
+    }
+    {
+      ProfScope ps(ctx, K_PCA_DEFLATE_UPDATE);
+      hipLaunchKernelGGL(deflate_update_kernel, grid, dim3(256), 0, st, d_F, Nz, S, d_spx, dD, nw,
+                         d_u, zper, nzs, cpart, o2part, cb);
+    }
+    {
+      ProfScope ps(ctx, K_SMALL);
+      hipLaunchKernelGGL(deflate_final_kernel, dim3(cdiv(nsmax, 256), nw), dim3(256), 0, st, d_spx,
+                         dD, nw, nzs, Nz, cb, o2part, d_test);
+    }
+    ORIGIN_LAUNCH_CHECK();
+    ++iters;
+  }
+  ORIGIN_HIP(hipMemcpyAsync(h_nnb, d_nstop, sizeof(int), hipMemcpyDeviceToHost, st));
+  ORIGIN_HIP(hipStreamSynchronize(st));
+  *h_nstop = h_nnb[0];
+  if (h_iters) *h_iters = iters;
   return ORIGIN_OK;
 }
 

@@ -97,7 +97,6 @@ def test_dct_exact_on_dct_spectra(hip):
 # ------------------------------------------------------------------------------- PCA
 def test_gram_mfma_matches_numpy(ctx):
     """G = X^T X from v_mfma_f64_16x16x4_f64 with a deliberately asymmetric X."""
-    import ctypes as C
     from origin_amd import _capi
     rng = np.random.default_rng(11)
     Nz, n = 517, 77
@@ -110,7 +109,7 @@ def test_gram_mfma_matches_numpy(ctx):
     d_ti = ctx.to_device(iu.astype(np.int32))
     d_tj = ctx.to_device(ju.astype(np.int32))
     d_ta = ctx.to_device(np.zeros(len(iu), np.int32))
-    d_ld = ctx.to_device(np.array([ld], np.int32))
+    d_ld = ctx.to_device(np.array([ld], np.int64))
     d_off = ctx.to_device(np.array([0, 0], np.int64))
     G = ctx.zeros((ld, ld), np.float64)
     _capi.call("origin_pca_gram", ctx.handle, dX.p, d_off.p, d_ld.p, Nz, len(iu), d_ti.p, d_tj.p,
@@ -118,6 +117,46 @@ def test_gram_mfma_matches_numpy(ctx):
     ref = X.T @ X
     got = G.to_host()
     assert np.max(np.abs(got - ref)) <= 1e-12 * np.max(np.abs(ref))
+
+
+@pytest.mark.parametrize("n,spectrum", [(1, "flat"), (2, "gap"), (37, "gap"), (130, "close"),
+                                        (300, "flat"), (700, "close")])
+def test_lanczos_leading_eigenvector(ctx, n, spectrum):
+    """Device Lanczos vs LAPACK on PSD matrices with wide, close and flat spectra."""
+    from origin_amd import _capi
+    rng = np.random.default_rng(100 + n)
+    Qm, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    if spectrum == "gap":
+        lam = np.concatenate([[1000.0], rng.uniform(0.1, 10, n - 1)])
+    elif spectrum == "close":
+        lam = np.concatenate([[1.0, 0.999], rng.uniform(0.0, 0.9, n - 2)])
+    else:
+        lam = 1.0 + 0.05 * rng.random(n)
+    lam = np.sort(lam)[::-1]
+    A = (Qm * lam) @ Qm.T
+    A = 0.5 * (A + A.T)
+    ld = (n + 15) // 16 * 16
+    G = np.zeros((ld, ld))
+    G[:n, :n] = A
+    rows = _capi.load().origin_pca_eig_qrows()
+    dG = ctx.to_device(G)
+    d0 = ctx.to_device(np.array([0], np.int64))
+    dld = ctx.to_device(np.array([ld], np.int64))
+    dn = ctx.to_device(np.array([n], np.int64))
+    v = ctx.zeros((ld,), np.float64)
+    info = ctx.zeros((3,), np.float64)
+    _capi.call("origin_pca_eig", ctx.handle, dG.p, d0.p, dld.p, dn.p, 1, rows * ld, d0.p, v.p,
+               d0.p, info.p)
+    got = v.to_host()[:n]
+    theta, resid, restarts = info.to_host()
+    w, V = np.linalg.eigh(A)
+    assert abs(theta - w[-1]) <= 1e-12 * w[-1]
+    assert abs(np.linalg.norm(got) - 1) < 1e-12
+    # residual of the returned pair and alignment with the LAPACK vector (gap permitting)
+    r = np.linalg.norm(A @ got - w[-1] * got)
+    assert r <= 1e-11 * w[-1], (r, resid, restarts)
+    gap = (w[-1] - w[-2]) / w[-1] if n > 1 else 1.0
+    assert 1 - abs(got @ V[:, -1]) <= 1e-10 / max(gap, 1e-12) ** 2 + 1e-13
 
 
 @pytest.mark.parametrize("name", ["a", "b", "c"])
