@@ -145,8 +145,8 @@ def main():
         if args.local_max:
             kernels.local_max(ctx, correl, correl_min, mask, 3)
         ctx.sync()
-        info["pca_iters"] = [len(t) for t in [drv.trace]][0]
-        info["n_nuis_first"] = int(sum(n for _, n, _ in drv.trace[0])) if drv.trace else 0
+        info["pca_iters"] = drv.iterations
+        info["n_nuis_first"] = drv.trace[0][1] if drv.trace else 0
         info["nstop"] = nstop
         info["maxmap_max"] = float(out["maxmap"].to_host().max())
         info["area_iters_mean"] = float(np.mean([mapO2.reshape(-1)[s].max() for s in spx]))
