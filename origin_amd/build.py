@@ -39,7 +39,7 @@ def build(force=False, verbose=False):
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     flags = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-value",
-             "-Wno-unused-result"]
+             "-Wno-unused-result"] + os.environ.get("ORIGIN_HIPCC_FLAGS", "").split()
     objs = []
     procs = []
     for src in sources():

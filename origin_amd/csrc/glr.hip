@@ -20,6 +20,7 @@
 // The plan tabulates 1/sqrt(den_k[z]) per class once, so the hot kernel never touches a
 // second cube.  With field weights (or fields smaller than the PSF) norm_fsf is a real
 // cube, produced by the same stencil kernel, and den_k is convolved next to num_k.
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -36,7 +37,15 @@ struct origin_glr_plan {
   float *d_taps;  // concatenated profiles (odd lengths; even ones padded with a 0 tap)
   float *d_taps2; // squares
   int *d_tap_off; // [K+1]
-  float *d_rden;  // mode 0: [P*P][K][Nz]
+  float *d_rden;  // mode 0: [P*P][Nz][Kp], Kp = K rounded up to 4
+  int Kp;
+  int symmetric;   // every prepared profile is exactly symmetric about its centre
+  float *d_htaps;  // symmetric case: half profiles h_k[d] = p_k[lw_k + d], d = 0..lw_k
+  int *d_htap_off; // [K+1]
+  float *d_rows;   // [K+1][RL] rows (lw, p[0..2 lw]) for spectral3_kernel<LWT>
+  float *d_rdi;    // mode 0: interior-class 1/sqrt(den), transposed [K][NzP]
+  int lwt;         // template half width chosen for d_rows (8, 16, 24, 29 or 32; 0 = none)
+  int NzP;
   size_t bytes;
 };
 
@@ -98,6 +107,159 @@ __global__ __launch_bounds__(256) void spatial_kernel(const float *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------
+// spatial stage, register-tiled: block 256 threads = 16 x 16, every thread owns a 4 x 4
+// patch of outputs (tile 64 x 64).  For each of the 4+P-1 input rows of its patch a thread
+// reads the row segment it needs once from LDS (ds_read_b128, conflict free because the
+// pitch is a multiple of 16 floats) and feeds up to 4 output rows x P taps x 4 columns of
+// FMAs from registers; the taps are wave-uniform and come from scalar loads.
+// ------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int P, bool VEC, bool HAS_B>
+__global__ __launch_bounds__(256) void spatial4x4_kernel(const float *__restrict__ A,
+                                                         const float *__restrict__ B,
+                                                         const float *__restrict__ taps, int Nz,
+                                                         int Ny, int Nx, int zper, int accumulate,
+                                                         float *__restrict__ out) {
+  constexpr int H = P - 1;
+  constexpr int W = 64 + H;                  // tile width in floats (multiple of 4: P odd)
+  constexpr int W4 = (W + 3) / 4;            // float4 per tile row
+  constexpr int PITCH = (W + 15) / 16 * 16;  // multiple of 16 floats: conflict-free b128 reads
+  constexpr int ROWS = 64 + H;
+  constexpr int NV = (4 + H + 3) / 4;        // float4 per row segment a thread consumes
+  constexpr int RPT = 256 / W4;               // tile rows staged per pass by the block
+  constexpr int NQ = (ROWS + RPT - 1) / RPT;  // staged float4 per thread
+  static_assert(60 + 4 * NV <= PITCH && 4 * W4 <= PITCH, "row segment exceeds the LDS pitch");
+  __shared__ __attribute__((aligned(16))) float tile[ROWS * PITCH];
+  constexpr int c = P / 2;
+  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 64;
+  const long S = (long)Ny * Nx;
+  const int tid = threadIdx.x;
+  const int z0 = blockIdx.z * zper, z1 = min(Nz, z0 + zper);
+
+  // Register staging of the next plane's tile (issue early, write to LDS late).  Thread
+  // (sr, sc4) stages the float4 column sc4 of tile rows sr, sr+RPT, sr+2 RPT, ...
+  const int sr = tid / W4, sc4 = tid - sr * W4;
+  const bool stager = sr < RPT;
+  const int sx = x0 - c + 4 * sc4;  // first field column of the staged float4
+  // VEC: Nx % 4 == 0 and sx % 4 == 0, so a float4 is either fully inside or fully outside
+  const bool xin = sx >= 0 && sx + 3 < Nx;
+  float4 stage[NQ];
+  auto load_tile = [&](int z) {
+    const float *Az = A + (long)z * S;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      const int ry = sr + RPT * j;
+      const int y = y0 - c + ry;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (stager && ry < ROWS && y >= 0 && y < Ny) {
+        const long p = (long)y * Nx + sx;
+        if constexpr (VEC) {
+          if (xin) {
+            v = *reinterpret_cast<const float4 *>(Az + p);
+            if constexpr (HAS_B) {
+              const float4 w = *reinterpret_cast<const float4 *>(B + p);
+              v.x *= w.x, v.y *= w.y, v.z *= w.z, v.w *= w.w;
+            }
+          }
+        } else {
+          float e[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int xx = sx + t;
+            float u = 0.f;
+            if (xx >= 0 && xx < Nx) {
+              u = Az[p + t];
+              if constexpr (HAS_B) u *= B[p + t];
+            }
+            e[t] = u;
+          }
+          v = make_float4(e[0], e[1], e[2], e[3]);
+        }
+      }
+      stage[j] = v;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      const int ry = sr + RPT * j;
+      if (stager && ry < ROWS)
+        *reinterpret_cast<float4 *>(tile + ry * PITCH + 4 * sc4) = stage[j];
+    }
+  };
+
+  const int tx = tid & 15, ty = tid >> 4;
+  load_tile(z0);
+  for (int z = z0; z < z1; ++z) {
+    __syncthreads();  // every wave is done reading the previous tile
+    store_tile();
+    __syncthreads();
+    if (z + 1 < z1) load_tile(z + 1);  // in flight while this plane is computed
+    const float *kz = taps + (long)z * P * P;  // uniform -> scalar loads
+    // Full-rate fp32 on gfx950 needs v_pk_fma_f32, whose 64-bit operands are even-aligned
+    // register pairs: keep the row segment twice, as pairs starting at even (rowE) and at
+    // odd (rowO) columns, so that every (column, column+1) pair is a ready-made operand.
+    f32x2 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) acc[a][0] = acc[a][1] = (f32x2){0.f, 0.f};
+#pragma unroll 1
+    for (int i = 0; i < 4 + H; ++i) {
+      const float *rbase = tile + (4 * ty + i) * PITCH + 4 * tx;
+      const float4 *rp = reinterpret_cast<const float4 *>(rbase);
+      f32x2 rowE[2 * NV], rowO[2 * NV];
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        const float4 v = rp[q];
+        rowE[2 * q] = (f32x2){v.x, v.y};
+        rowE[2 * q + 1] = (f32x2){v.z, v.w};
+      }
+#pragma unroll
+      for (int q = 0; q < (3 + H + 1) / 2; ++q)  // pairs (2q+1, 2q+2), up to column 3+H
+        rowO[q] = (f32x2){rbase[2 * q + 1], rbase[2 * q + 2]};
+#pragma unroll
+      for (int ry = 0; ry < 4; ++ry) {
+        const int dy = i - ry;
+        if (dy >= 0 && dy < P) {  // wave-uniform
+          const float *kr = kz + dy * P;
+#pragma unroll
+          for (int dx = 0; dx < P; ++dx) {
+            const float kv = kr[dx];
+            const f32x2 k2 = (f32x2){kv, kv};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int j = 2 * h + dx;  // first column of the pair
+              const f32x2 in = (j & 1) ? rowO[j >> 1] : rowE[j >> 1];
+              acc[ry][h] = __builtin_elementwise_fma(k2, in, acc[ry][h]);
+            }
+          }
+        }
+      }
+    }
+    const int xo = x0 + 4 * tx;
+#pragma unroll
+    for (int ry = 0; ry < 4; ++ry) {
+      const int y = y0 + 4 * ty + ry;
+      if (y >= Ny) continue;
+      float *o = out + (long)z * S + (long)y * Nx + xo;
+      if (VEC && xo + 3 < Nx) {
+        float4 v = make_float4(acc[ry][0].x, acc[ry][0].y, acc[ry][1].x, acc[ry][1].y);
+        if (accumulate) {
+          const float4 old = *reinterpret_cast<float4 *>(o);
+          v.x += old.x, v.y += old.y, v.z += old.z, v.w += old.w;
+        }
+        *reinterpret_cast<float4 *>(o) = v;
+      } else {
+        const float r4[4] = {acc[ry][0].x, acc[ry][0].y, acc[ry][1].x, acc[ry][1].y};
+#pragma unroll
+        for (int rx = 0; rx < 4; ++rx)
+          if (xo + rx < Nx) o[rx] = accumulate ? o[rx] + r4[rx] : r4[rx];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // border-class normalisation tables (mode 0)
 // ------------------------------------------------------------------------------------
 // normcls[z][cy][cx] = sum over the in-field part of the window of k_z^2
@@ -120,17 +282,21 @@ __global__ __launch_bounds__(256) void norm_classes_kernel(const float *__restri
   ncls[i] = acc;
 }
 
-// rden[cls][k][z] = 1/sqrt(sum_j p_k[j]^2 normcls[z + lw - j][cls])   (0 if den <= 0)
+// rden[cls][z][k] = 1/sqrt(sum_j p_k[j]^2 normcls[z + lw - j][cls])   (0 if den <= 0)
 __global__ __launch_bounds__(256) void rden_kernel(const double *__restrict__ ncls,
                                                    const float *__restrict__ taps2,
                                                    const int *__restrict__ tap_off, int K, int Nz,
-                                                   int PP, float *__restrict__ rden) {
+                                                   int PP, int Kp, float *__restrict__ rden) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  const long n = (long)PP * K * Nz;
+  const long n = (long)PP * Kp * Nz;
   if (i >= n) return;
-  const int z = (int)(i % Nz);
-  const int k = (int)((i / Nz) % K);
-  const int cls = (int)(i / ((long)Nz * K));
+  const int k = (int)(i % Kp);
+  const int z = (int)((i / Kp) % Nz);
+  const int cls = (int)(i / ((long)Nz * Kp));
+  if (k >= K) {
+    rden[i] = 0.0f;
+    return;
+  }
   const int off = tap_off[k], L = tap_off[k + 1] - off, lw = (L - 1) / 2;
   double den = 0.0;
   for (int j = 0; j < L; ++j) {
@@ -184,8 +350,9 @@ template <int LWMAX, bool GENERAL>
 __global__ __launch_bounds__(256) void spectral_kernel(
     const float *__restrict__ fsf, const float *__restrict__ norm,
     const float *__restrict__ rden, const float *__restrict__ taps,
-    const float *__restrict__ taps2, const int *__restrict__ tap_off, int K, int Nz, int Ny,
-    int Nx, int P, int zchunk, const uint8_t *__restrict__ mask, float *__restrict__ correl,
+    const float *__restrict__ taps2, const int *__restrict__ tap_off, int K, int Kp, int Nz,
+    int Ny, int Nx, int P, int zchunk, const uint8_t *__restrict__ mask,
+    float *__restrict__ correl,
     uint8_t *__restrict__ profile, float *__restrict__ correl_min,
     float *__restrict__ part_max, float *__restrict__ part_min) {
   constexpr int W = 2 * LWMAX + 1;
@@ -200,7 +367,7 @@ __global__ __launch_bounds__(256) void spectral_kernel(
   if constexpr (!GENERAL) {
     const int y = (int)(sc / Nx), x = (int)(sc - (long)y * Nx);
     const int cls = border_class(y, Ny, P) * P + border_class(x, Nx, P);
-    rd = rden + (long)cls * K * Nz;
+    rd = rden + (long)cls * Kp * Nz;
   }
 
   float w[W];
@@ -226,7 +393,7 @@ __global__ __launch_bounds__(256) void spectral_kernel(
         const float den = conv_sel<LWMAX>(wn, taps2 + off, lw);
         T = den > 0.0f ? num / sqrtf(den) : 0.0f;  // den <= 0 -> inf -> T = 0  (lib :1057)
       } else {
-        T = num * rd[(long)k * Nz + z];
+        T = num * rd[(long)z * Kp + k];
       }
       if (T > best) {  // strict '>' : first maximum wins                      (lib :1210)
         best = T;
@@ -263,13 +430,192 @@ __global__ __launch_bounds__(256) void spectral_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------
+// spectral stage, packed and z-blocked.  One lane owns TWO adjacent spaxels (float2 loads,
+// v_pk_fma_f32: the only way to the full fp32 rate on gfx950) and produces SPEC_ZC
+// consecutive channels per step from a register window of 2*LWMAX + SPEC_ZC float2.
+// Profiles are the OUTER loop of a step: the constants of profile k come as one fixed-length
+// row  [lw_k (int bits), p_k[0], ..., p_k[2 lw_k], 0 ...]  fetched by a few wide scalar loads
+// and then feed SPEC_ZC * (2 lw_k + 1) packed FMAs, so the scalar-load latency is amortised
+// over hundreds of cycles of arithmetic.  On waves whose 128 spaxels are all interior (border
+// class (c,c)), 1/sqrt(den) is wave-uniform and is read by scalar loads too.
+// ------------------------------------------------------------------------------------
+constexpr int SPEC_ZC = 4;
+
+template <int LWMAX, int LW>
+__device__ __forceinline__ void conv3_one(const f32x2 (&w)[2 * LWMAX + SPEC_ZC],
+                                          const float *__restrict__ taps,  // wave-uniform
+                                          f32x2 (&num)[SPEC_ZC]) {
+#pragma unroll
+  for (int o = 0; o < SPEC_ZC; ++o) num[o] = (f32x2){0.f, 0.f};
+  // taps are consumed in chunks of 16 scalars so that only a few SGPRs are live and the
+  // next chunk's scalar load overlaps the FMAs of the current one
+#pragma unroll
+  for (int c0 = 0; c0 <= 2 * LW; c0 += 16) {
+    float t[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t[i] = taps[c0 + i];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int j = c0 + i;
+      if (j <= 2 * LW) {
+        const f32x2 pj = (f32x2){t[i], t[i]};
+#pragma unroll
+        for (int o = 0; o < SPEC_ZC; ++o)
+          num[o] = __builtin_elementwise_fma(pj, w[LWMAX + o + LW - j], num[o]);
+      }
+    }
+  }
+}
+
+#define CASE3(N)                                                              \
+  case N:                                                                     \
+    if constexpr (N <= LWMAX) conv3_one<LWMAX, (N <= LWMAX ? N : 0)>(w, taps, num); \
+    break;
+
+template <int LWMAX>
+__device__ __forceinline__ void conv3_sel(const f32x2 (&w)[2 * LWMAX + SPEC_ZC],
+                                          const float *__restrict__ taps, int lw,
+                                          f32x2 (&num)[SPEC_ZC]) {
+  switch (lw) {
+    CASE3(0) CASE3(1) CASE3(2) CASE3(3) CASE3(4) CASE3(5) CASE3(6) CASE3(7) CASE3(8) CASE3(9)
+    CASE3(10) CASE3(11) CASE3(12) CASE3(13) CASE3(14) CASE3(15) CASE3(16) CASE3(17) CASE3(18)
+    CASE3(19) CASE3(20) CASE3(21) CASE3(22) CASE3(23) CASE3(24) CASE3(25) CASE3(26) CASE3(27)
+    CASE3(28) CASE3(29) CASE3(30) CASE3(31) CASE3(32)
+    default:
+#pragma unroll
+      for (int o = 0; o < SPEC_ZC; ++o) num[o] = (f32x2){0.f, 0.f};
+      break;
+  }
+}
+#undef CASE3
+
+// interior-class table transposed: rdi[k][z] = rden_interior[z][k]
+__global__ __launch_bounds__(256) void rdi_kernel(const float *__restrict__ rd_int, int K, int Kp,
+                                                  int Nz, int NzP, float *__restrict__ rdi) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)K * NzP) return;
+  const int k = (int)(i / NzP), z = (int)(i - (long)k * NzP);
+  rdi[i] = z < Nz ? rd_int[(long)z * Kp + k] : 0.0f;
+}
+
+template <int LWMAX>
+__global__ __launch_bounds__(256) void spectral3_kernel(
+    const float *__restrict__ fsf, const float *__restrict__ rden, const float *__restrict__ rdi,
+    int NzP, const float *__restrict__ rows, int K, int Kp, int Nz, int Ny, int Nx, int P,
+    int zchunk, const uint8_t *__restrict__ mask, float *__restrict__ correl,
+    uint8_t *__restrict__ profile, float *__restrict__ correl_min, float *__restrict__ part_max,
+    float *__restrict__ part_min) {
+  constexpr int ZC = SPEC_ZC;
+  constexpr int RL = (2 * LWMAX + 1 + 15) / 16 * 16 + 16;
+  constexpr int W = 2 * LWMAX + ZC;
+  const long S = (long)Ny * Nx;  // even
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const bool live = 2 * t < S;
+  const long s0 = live ? 2 * t : S - 2;
+  const int z0 = blockIdx.y * zchunk;  // multiple of ZC
+  const int z1 = min(Nz, z0 + zchunk);
+
+  const int ccls = (P / 2) * P + P / 2;
+  const float *rd[2];
+  bool interior = true;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const long s = s0 + e;
+    const int y = (int)(s / Nx), x = (int)(s - (long)y * Nx);
+    const int cls = border_class(y, Ny, P) * P + border_class(x, Nx, P);
+    interior = interior && cls == ccls;
+    rd[e] = rden + (long)cls * Kp * Nz;
+  }
+  const bool uni = __all(interior) != 0;  // wave-uniform
+  auto load2 = [&](int zz) -> f32x2 {
+    if (zz < 0 || zz >= Nz) return (f32x2){0.f, 0.f};
+    return *reinterpret_cast<const f32x2 *>(fsf + (long)zz * S + s0);
+  };
+
+  f32x2 w[W];
+#pragma unroll
+  for (int i = 0; i < W; ++i) w[i] = load2(z0 - LWMAX + i);
+
+  f32x2 vmax = (f32x2){-INFINITY, -INFINITY}, vmin = (f32x2){INFINITY, INFINITY};
+  for (int zb = z0; zb < z1; zb += ZC) {
+    f32x2 best[ZC], worst[ZC];
+    int bk0[ZC], bk1[ZC];
+#pragma unroll
+    for (int o = 0; o < ZC; ++o) {
+      best[o] = (f32x2){-INFINITY, -INFINITY};
+      worst[o] = (f32x2){INFINITY, INFINITY};
+      bk0[o] = bk1[o] = 0;
+    }
+    int lw_next = __float_as_int(rows[0]);
+    for (int k = 0; k < K; ++k) {
+      const float *rk = rows + (long)k * RL;  // wave-uniform -> wide scalar loads
+      const int lw = lw_next;
+      lw_next = __float_as_int(rk[RL]);  // rows has K+1 entries; used by the next iteration
+      float rdu[ZC];
+      if (uni) {
+        const float *ru = rdi + (long)k * NzP + zb;  // NzP >= Nz + ZC: no bound check
+#pragma unroll
+        for (int o = 0; o < ZC; ++o) rdu[o] = ru[o];
+      }
+      f32x2 num[ZC];
+      conv3_sel<LWMAX>(w, rk + 1, lw, num);
+#pragma unroll
+      for (int o = 0; o < ZC; ++o) {
+        f32x2 T;
+        if (uni) {
+          T = num[o] * (f32x2){rdu[o], rdu[o]};
+        } else {
+          const long zi = (long)min(zb + o, Nz - 1) * Kp + k;
+          T = (f32x2){num[o].x * rd[0][zi], num[o].y * rd[1][zi]};
+        }
+        // strict '>' : the first maximum wins                             (lib :1210)
+        if (T.x > best[o].x) best[o].x = T.x, bk0[o] = k;
+        if (T.y > best[o].y) best[o].y = T.y, bk1[o] = k;
+        worst[o].x = fminf(worst[o].x, T.x);
+        worst[o].y = fminf(worst[o].y, T.y);
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < ZC; ++o) {
+      const int zz = zb + o;
+      if (zz < z1) {
+        const long idx = (long)zz * S + s0;
+        f32x2 b = best[o];
+        int k0 = bk0[o], k1 = bk1[o];
+        if (mask) {  // correl[mask] = 0 ; profile[mask] = 0          (steps.py:781,788)
+          if (mask[idx]) b.x = 0.0f, k0 = 0;
+          if (mask[idx + 1]) b.y = 0.0f, k1 = 0;
+        }
+        if (live) {
+          *reinterpret_cast<f32x2 *>(correl + idx) = b;
+          *reinterpret_cast<f32x2 *>(correl_min + idx) = worst[o];
+          *reinterpret_cast<unsigned short *>(profile + idx) = (unsigned short)(k0 | (k1 << 8));
+        }
+        vmax.x = fmaxf(vmax.x, b.x), vmax.y = fmaxf(vmax.y, b.y);
+        vmin.x = fminf(vmin.x, worst[o].x), vmin.y = fminf(vmin.y, worst[o].y);
+      }
+    }
+    // slide the window by ZC channels
+#pragma unroll
+    for (int i = 0; i < W - ZC; ++i) w[i] = w[i + ZC];
+#pragma unroll
+    for (int o = 0; o < ZC; ++o) w[W - ZC + o] = load2(zb + ZC + LWMAX + o);
+  }
+  if (live && part_max) {
+    *reinterpret_cast<f32x2 *>(part_max + (long)blockIdx.y * S + s0) = vmax;
+    *reinterpret_cast<f32x2 *>(part_min + (long)blockIdx.y * S + s0) = vmin;
+  }
+}
+
 // fallback for profiles wider than the register window: plain loops over global memory
 template <bool GENERAL>
 __global__ __launch_bounds__(256) void spectral_generic_kernel(
     const float *__restrict__ fsf, const float *__restrict__ norm,
     const float *__restrict__ rden, const float *__restrict__ taps,
-    const float *__restrict__ taps2, const int *__restrict__ tap_off, int K, int Nz, int Ny,
-    int Nx, int P, int zchunk, const uint8_t *__restrict__ mask, float *__restrict__ correl,
+    const float *__restrict__ taps2, const int *__restrict__ tap_off, int K, int Kp, int Nz,
+    int Ny, int Nx, int P, int zchunk, const uint8_t *__restrict__ mask,
+    float *__restrict__ correl,
     uint8_t *__restrict__ profile, float *__restrict__ correl_min,
     float *__restrict__ part_max, float *__restrict__ part_min) {
   const long S = (long)Ny * Nx;
@@ -280,7 +626,7 @@ __global__ __launch_bounds__(256) void spectral_generic_kernel(
   const float *rd = nullptr;
   if constexpr (!GENERAL) {
     const int y = (int)(s / Nx), x = (int)(s - (long)y * Nx);
-    rd = rden + (long)(border_class(y, Ny, P) * P + border_class(x, Nx, P)) * K * Nz;
+    rd = rden + (long)(border_class(y, Ny, P) * P + border_class(x, Nx, P)) * Kp * Nz;
   }
   float vmax = -INFINITY, vmin = INFINITY;
   for (int z = z0; z < z1; ++z) {
@@ -300,7 +646,7 @@ __global__ __launch_bounds__(256) void spectral_generic_kernel(
       if constexpr (GENERAL)
         T = den > 0.0f ? num / sqrtf(den) : 0.0f;
       else
-        T = num * rd[(long)k * Nz + z];
+        T = num * rd[(long)z * Kp + k];
       if (T > best) {
         best = T;
         bk = k;
@@ -374,7 +720,9 @@ int origin_glr_plan_destroy(origin_glr_plan *plan) {
   (void)hipSetDevice(plan->ctx->device);
   (void)hipStreamSynchronize(plan->ctx->stream);
   for (void *p : {(void *)plan->d_k, (void *)plan->d_k2, (void *)plan->d_w, (void *)plan->d_taps,
-                  (void *)plan->d_taps2, (void *)plan->d_tap_off, (void *)plan->d_rden})
+                  (void *)plan->d_taps2, (void *)plan->d_tap_off, (void *)plan->d_rden,
+                  (void *)plan->d_htaps, (void *)plan->d_htap_off, (void *)plan->d_rows,
+                  (void *)plan->d_rdi})
     if (p) (void)hipFree(p);
   delete plan;
   return ORIGIN_OK;
@@ -452,6 +800,36 @@ int origin_glr_plan_create(origin_ctx *ctx, int Nz, int Ny, int Nx, int nfields,
     lwmax = std::max(lwmax, (off[kk + 1] - off[kk] - 1) / 2);
   }
   pl->lwmax = lwmax;
+  pl->Kp = (K + 3) / 4 * 4;
+  // exactly symmetric profiles (the Gaussian dictionaries are) allow p[c+d] (w[c+d] + w[c-d])
+  std::vector<float> htaps;
+  std::vector<int> hoff(K + 1, 0);
+  pl->symmetric = 1;
+  for (int kk = 0; kk < K; ++kk) {
+    const int L = off[kk + 1] - off[kk], lw = (L - 1) / 2;
+    for (int d = 0; d <= lw; ++d) {
+      if (taps[off[kk] + lw + d] != taps[off[kk] + lw - d]) pl->symmetric = 0;
+      htaps.push_back(taps[off[kk] + lw + d]);
+    }
+    hoff[kk + 1] = (int)htaps.size();
+  }
+  for (int i = 0; i < 64; ++i) htaps.push_back(0.f);
+  TRY(upload(ctx, htaps, &pl->d_htaps, &pl->bytes));
+  TRY(upload(ctx, hoff, &pl->d_htap_off, &pl->bytes));
+  pl->lwt = 0;
+  pl->NzP = (Nz + 3) / 4 * 4 + 8;
+  if (lwmax <= 32) {
+    const int lwt = lwmax <= 8 ? 8 : lwmax <= 16 ? 16 : lwmax <= 24 ? 24 : lwmax <= 29 ? 29 : 32;
+    const int RL = (2 * lwt + 1 + 15) / 16 * 16 + 16;  // [lw | taps padded to 16s]
+    std::vector<float> rows((size_t)(K + 2) * RL, 0.f);
+    for (int kk = 0; kk < K; ++kk) {
+      const int L = off[kk + 1] - off[kk], lw = (L - 1) / 2;
+      memcpy(&rows[(size_t)kk * RL], &lw, sizeof(int));
+      for (int j = 0; j < L; ++j) rows[(size_t)kk * RL + 1 + j] = taps[off[kk] + j];
+    }
+    TRY(upload(ctx, rows, &pl->d_rows, &pl->bytes));
+    pl->lwt = lwt;
+  }
   // scalar loads may read a few taps past the end of a profile row: pad
   for (int i = 0; i < 64; ++i) {
     taps.push_back(0.f);
@@ -470,7 +848,7 @@ int origin_glr_plan_create(origin_ctx *ctx, int Nz, int Ny, int Nx, int nfields,
       origin_glr_plan_destroy(pl);
       return ORIGIN_E_NOMEM;
     }
-    const size_t rn = PP * (size_t)K * Nz;
+    const size_t rn = PP * (size_t)pl->Kp * Nz;
     e = hipMalloc((void **)&pl->d_rden, rn * sizeof(float));
     if (e != hipSuccess) {
       (void)hipFree(ncls);
@@ -483,8 +861,15 @@ int origin_glr_plan_create(origin_ctx *ctx, int Nz, int Ny, int Nx, int nfields,
     hipLaunchKernelGGL(norm_classes_kernel, dim3(cdiv((long)ncls_n, 256)), dim3(256), 0,
                        ctx->stream, pl->d_k2, Nz, P, ncls);
     hipLaunchKernelGGL(rden_kernel, dim3(cdiv((long)rn, 256)), dim3(256), 0, ctx->stream, ncls,
-                       pl->d_taps2, pl->d_tap_off, K, Nz, (int)PP, pl->d_rden);
-    e = hipGetLastError();
+                       pl->d_taps2, pl->d_tap_off, K, Nz, (int)PP, pl->Kp, pl->d_rden);
+    e = hipMalloc((void **)&pl->d_rdi, (size_t)K * pl->NzP * sizeof(float));
+    if (e == hipSuccess) {
+      pl->bytes += (size_t)K * pl->NzP * sizeof(float);
+      const int ccls = (P / 2) * P + P / 2;
+      hipLaunchKernelGGL(rdi_kernel, dim3(cdiv((long)K * pl->NzP, 256)), dim3(256), 0, ctx->stream,
+                         pl->d_rden + (size_t)ccls * pl->Kp * Nz, K, pl->Kp, Nz, pl->NzP, pl->d_rdi);
+      e = hipGetLastError();
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(ncls);
     if (e != hipSuccess) {
@@ -528,18 +913,50 @@ int origin_glr_run(origin_ctx *ctx, origin_glr_plan *pl, const float *d_cube,
   float *part = d_work + cube * (pl->mode == 1 ? 2 : 1);
 
   // ---- spatial stage
-  dim3 sgrid(cdiv(Nx, TX), cdiv(Ny, TY), Nz), sblock(64, 4);
-  const size_t lds = (size_t)(TY + P - 1) * (TX + P - 1) * sizeof(float);
+  auto spatial = [&](const float *A, const float *B, const float *taps, int acc, float *dst) {
+    // each block marches `zper` channels of one 64x64 tile, prefetching the next plane
+    const long tiles = (long)cdiv(Nx, 64) * cdiv(Ny, 64);
+    int nzb = (int)(((long)ctx->num_cu * 16 + tiles - 1) / tiles);
+    nzb = std::max(1, std::min(nzb, Nz));
+    const int zper = cdiv(Nz, nzb);
+    dim3 g4(cdiv(Nx, 64), cdiv(Ny, 64), cdiv(Nz, zper));
+    const bool vec = (Nx & 3) == 0 && ((P / 2) & 3) == 0;
+#define LAUNCH_SP2(PP, VV, BB)                                                                  \
+  hipLaunchKernelGGL((spatial4x4_kernel<PP, VV, BB>), g4, dim3(256), 0, ctx->stream, A, B, taps, \
+                     Nz, Ny, Nx, zper, acc, dst)
+#define LAUNCH_SP(PP)                                \
+  if (vec && B) LAUNCH_SP2(PP, true, true);          \
+  else if (vec) LAUNCH_SP2(PP, true, false);         \
+  else if (B) LAUNCH_SP2(PP, false, true);           \
+  else LAUNCH_SP2(PP, false, false)
+    switch (A ? P : 0) {  // A == NULL (norm of the weights) takes the generic kernel
+      case 7:
+        LAUNCH_SP(7);
+        break;
+      case 9:
+        LAUNCH_SP(9);
+        break;
+      case 25:
+        LAUNCH_SP(25);
+        break;
+      default: {  // any other odd PSF size: generic LDS-tiled kernel
+        dim3 sgrid(cdiv(Nx, TX), cdiv(Ny, TY), Nz), sblock(64, 4);
+        const size_t lds = (size_t)(TY + P - 1) * (TX + P - 1) * sizeof(float);
+        hipLaunchKernelGGL(spatial_kernel, sgrid, sblock, lds, ctx->stream, A, B, taps, Ny, Nx, P,
+                           acc, dst);
+      }
+    }
+#undef LAUNCH_SP
+#undef LAUNCH_SP2
+  };
   for (int f = 0; f < pl->nfields; ++f) {
     ProfScope ps(ctx, K_GLR_SPATIAL);
     const float *kf = pl->d_k + (size_t)f * Nz * P * P;
     const float *wf = pl->d_w ? pl->d_w + (size_t)f * S : nullptr;
-    hipLaunchKernelGGL(spatial_kernel, sgrid, sblock, lds, ctx->stream, d_cube, wf, kf, Ny, Nx, P,
-                       f > 0, fsf);
+    spatial(d_cube, wf, kf, f > 0, fsf);
     if (pl->mode == 1) {
       const float *k2f = pl->d_k2 + (size_t)f * Nz * P * P;
-      hipLaunchKernelGGL(spatial_kernel, sgrid, sblock, lds, ctx->stream, (const float *)nullptr,
-                         wf, k2f, Ny, Nx, P, f > 0, norm);
+      spatial(nullptr, wf, k2f, f > 0, norm);
     }
   }
   ORIGIN_LAUNCH_CHECK();
@@ -548,19 +965,36 @@ int origin_glr_run(origin_ctx *ctx, origin_glr_plan *pl, const float *d_cube,
   const bool want_maps = d_maxmap || d_minmap;
   int nzc = spectral_zchunks(ctx, S, Nz, std::max(pl->lwmax, 1));
   if (nzc > 64) nzc = 64;
-  const int zchunk = cdiv(Nz, nzc);
+  int zchunk = cdiv(Nz, nzc);
+  zchunk = (zchunk + SPEC_ZC - 1) / SPEC_ZC * SPEC_ZC;  // the packed kernel steps SPEC_ZC channels
   nzc = cdiv(Nz, zchunk);
   float *pmax = want_maps ? part : nullptr;
   float *pmin = want_maps ? part + (size_t)nzc * S : nullptr;
   dim3 grid(cdiv(S, 256), nzc), block(256);
 #define LAUNCH(KERNEL)                                                                        \
   hipLaunchKernelGGL(KERNEL, grid, block, 0, ctx->stream, fsf, norm, pl->d_rden, pl->d_taps, \
-                     pl->d_taps2, pl->d_tap_off, K, Nz, Ny, Nx, P, zchunk, d_mask, d_correl, \
+                     pl->d_taps2, pl->d_tap_off, K, pl->Kp, Nz, Ny, Nx, P, zchunk, d_mask,   \
+                     d_correl,                                                              \
                      d_profile, d_correl_min, pmax, pmin)
   const bool gen = pl->mode == 1;
   {
   ProfScope ps(ctx, K_GLR_SPECTRAL);
-  if (pl->lwmax <= 8) {
+  if (!gen && (S & 1) == 0 && pl->lwt) {
+    // packed path: one lane = two adjacent spaxels, SPEC_ZC channels per step
+    dim3 g2(cdiv(S / 2, 256), nzc);
+#define LAUNCH3(LW)                                                                            \
+  hipLaunchKernelGGL((spectral3_kernel<LW>), g2, block, 0, ctx->stream, fsf, pl->d_rden,       \
+                     pl->d_rdi, pl->NzP, pl->d_rows, K, pl->Kp, Nz, Ny, Nx, P, zchunk, d_mask,  \
+                     d_correl, d_profile, d_correl_min, pmax, pmin)
+    switch (pl->lwt) {
+      case 8: LAUNCH3(8); break;
+      case 16: LAUNCH3(16); break;
+      case 24: LAUNCH3(24); break;
+      case 29: LAUNCH3(29); break;
+      default: LAUNCH3(32); break;
+    }
+#undef LAUNCH3
+  } else if (pl->lwmax <= 8) {
     if (gen) LAUNCH((spectral_kernel<8, true>)); else LAUNCH((spectral_kernel<8, false>));
   } else if (pl->lwmax <= 16) {
     if (gen) LAUNCH((spectral_kernel<16, true>)); else LAUNCH((spectral_kernel<16, false>));
