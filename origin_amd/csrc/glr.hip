@@ -44,6 +44,8 @@ struct origin_glr_plan {
   int *d_htap_off; // [K+1]
   float *d_rows;   // [K+1][RL] rows (lw, p[0..2 lw]) for spectral3_kernel<LWT>
   float *d_rdi;    // mode 0: interior-class 1/sqrt(den), transposed [K][NzP]
+  int *d_border;   // mode 0: flat indices of the spaxels whose border class is not interior
+  int nborder;
   int lwt;         // template half width chosen for d_rows (8, 16, 24, 29 or 32; 0 = none)
   int NzP;
   size_t bytes;
@@ -354,11 +356,14 @@ __global__ __launch_bounds__(256) void spectral_kernel(
     int Ny, int Nx, int P, int zchunk, const uint8_t *__restrict__ mask,
     float *__restrict__ correl,
     uint8_t *__restrict__ profile, float *__restrict__ correl_min,
-    float *__restrict__ part_max, float *__restrict__ part_min) {
+    float *__restrict__ part_max, float *__restrict__ part_min,
+    const int *__restrict__ list, int nlist) {
+  // with `list` the kernel only (re)computes the listed spaxels (border fix-up pass)
   constexpr int W = 2 * LWMAX + 1;
   const long S = (long)Ny * Nx;
-  const long s = (long)blockIdx.x * 256 + threadIdx.x;
-  const bool live = s < S;
+  const long i0 = (long)blockIdx.x * 256 + threadIdx.x;
+  const bool live = list ? i0 < nlist : i0 < S;
+  const long s = list ? (long)list[live ? i0 : 0] : i0;
   const long sc = live ? s : S - 1;
   const int z0 = blockIdx.y * zchunk;
   const int z1 = min(Nz, z0 + zchunk);
@@ -437,8 +442,10 @@ __global__ __launch_bounds__(256) void spectral_kernel(
 // Profiles are the OUTER loop of a step: the constants of profile k come as one fixed-length
 // row  [lw_k (int bits), p_k[0], ..., p_k[2 lw_k], 0 ...]  fetched by a few wide scalar loads
 // and then feed SPEC_ZC * (2 lw_k + 1) packed FMAs, so the scalar-load latency is amortised
-// over hundreds of cycles of arithmetic.  On waves whose 128 spaxels are all interior (border
-// class (c,c)), 1/sqrt(den) is wave-uniform and is read by scalar loads too.
+// over hundreds of cycles of arithmetic.  The kernel normalises EVERY spaxel with the
+// interior-class 1/sqrt(den) (wave-uniform, scalar loads); the spaxels within P/2 of the field
+// border, whose normalisation differs, are recomputed afterwards by spectral_kernel on the
+// plan's border list (a few percent of the field).
 // ------------------------------------------------------------------------------------
 constexpr int SPEC_ZC = 4;
 
@@ -446,25 +453,51 @@ template <int LWMAX, int LW>
 __device__ __forceinline__ void conv3_one(const f32x2 (&w)[2 * LWMAX + SPEC_ZC],
                                           const float *__restrict__ taps,  // wave-uniform
                                           f32x2 (&num)[SPEC_ZC]) {
+  constexpr int NT = 2 * LW + 1;         // taps of this profile
+  constexpr int NCH = (NT + 15) / 16;    // chunks of 16 scalars
 #pragma unroll
   for (int o = 0; o < SPEC_ZC; ++o) num[o] = (f32x2){0.f, 0.f};
-  // taps are consumed in chunks of 16 scalars so that only a few SGPRs are live and the
-  // next chunk's scalar load overlaps the FMAs of the current one
+  // Taps are consumed in chunks of 16 scalars from two alternating SGPR sets: the chunk
+  // c+1 is requested right after chunk c has arrived and before the 64 packed FMAs of chunk c
+  // are issued, so the scalar-load latency hides behind them.  Scalar loads return out of
+  // order, hence the explicit lgkmcnt(0) / sched_barrier fences that pin this order.
+  float ta[16], tb[16];
+  auto load = [&](float (&t)[16], int c) {
 #pragma unroll
-  for (int c0 = 0; c0 <= 2 * LW; c0 += 16) {
-    float t[16];
+    for (int i = 0; i < 16; ++i) t[i] = taps[16 * c + i];
+  };
+  auto fmas = [&](const float (&t)[16], int c, int i0, int i1) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) t[i] = taps[c0 + i];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int j = c0 + i;
-      if (j <= 2 * LW) {
+    for (int i = i0; i < i1; ++i) {
+      const int j = 16 * c + i;
+      if (j < NT) {
         const f32x2 pj = (f32x2){t[i], t[i]};
 #pragma unroll
         for (int o = 0; o < SPEC_ZC; ++o)
           num[o] = __builtin_elementwise_fma(pj, w[LWMAX + o + LW - j], num[o]);
       }
     }
+  };
+  // hipcc's own waitcnt insertion puts lgkmcnt(0) in front of the first use of a chunk, so
+  // the first tap of chunk c is consumed BEFORE chunk c+1 is requested: the wait then covers
+  // only chunk c, and the request for c+1 flies during the remaining 15 x SPEC_ZC FMAs.
+  load(ta, 0);
+#pragma unroll
+  for (int c = 0; c < NCH; c += 2) {
+    fmas(ta, c, 0, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (c + 1 < NCH) load(tb, c + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    fmas(ta, c, 1, 16);
+    if (c + 1 < NCH) {
+      __builtin_amdgcn_sched_barrier(0);
+      fmas(tb, c + 1, 0, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (c + 2 < NCH) load(ta, c + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      fmas(tb, c + 1, 1, 16);
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -501,9 +534,9 @@ __global__ __launch_bounds__(256) void rdi_kernel(const float *__restrict__ rd_i
 
 template <int LWMAX>
 __global__ __launch_bounds__(256) void spectral3_kernel(
-    const float *__restrict__ fsf, const float *__restrict__ rden, const float *__restrict__ rdi,
-    int NzP, const float *__restrict__ rows, int K, int Kp, int Nz, int Ny, int Nx, int P,
-    int zchunk, const uint8_t *__restrict__ mask, float *__restrict__ correl,
+    const float *__restrict__ fsf, const float *__restrict__ rdi, int NzP,
+    const float *__restrict__ rows, int K, int Nz, int Ny, int Nx, int zchunk,
+    const uint8_t *__restrict__ mask, float *__restrict__ correl,
     uint8_t *__restrict__ profile, float *__restrict__ correl_min, float *__restrict__ part_max,
     float *__restrict__ part_min) {
   constexpr int ZC = SPEC_ZC;
@@ -516,18 +549,6 @@ __global__ __launch_bounds__(256) void spectral3_kernel(
   const int z0 = blockIdx.y * zchunk;  // multiple of ZC
   const int z1 = min(Nz, z0 + zchunk);
 
-  const int ccls = (P / 2) * P + P / 2;
-  const float *rd[2];
-  bool interior = true;
-#pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const long s = s0 + e;
-    const int y = (int)(s / Nx), x = (int)(s - (long)y * Nx);
-    const int cls = border_class(y, Ny, P) * P + border_class(x, Nx, P);
-    interior = interior && cls == ccls;
-    rd[e] = rden + (long)cls * Kp * Nz;
-  }
-  const bool uni = __all(interior) != 0;  // wave-uniform
   auto load2 = [&](int zz) -> f32x2 {
     if (zz < 0 || zz >= Nz) return (f32x2){0.f, 0.f};
     return *reinterpret_cast<const f32x2 *>(fsf + (long)zz * S + s0);
@@ -539,6 +560,17 @@ __global__ __launch_bounds__(256) void spectral3_kernel(
 
   f32x2 vmax = (f32x2){-INFINITY, -INFINITY}, vmin = (f32x2){INFINITY, INFINITY};
   for (int zb = z0; zb < z1; zb += ZC) {
+    // request the planes that enter the window at the end of this step now: the loads have
+    // the whole step (K profiles) to land
+    f32x2 incoming[ZC];
+#pragma unroll
+    for (int o = 0; o < ZC; ++o) incoming[o] = load2(zb + ZC + LWMAX + o);
+    unsigned short mk[ZC];  // mask bytes of the two spaxels, also requested a step ahead
+#pragma unroll
+    for (int o = 0; o < ZC; ++o)
+      mk[o] = (mask && zb + o < z1)
+                  ? *reinterpret_cast<const unsigned short *>(mask + (long)(zb + o) * S + s0)
+                  : (unsigned short)0;
     f32x2 best[ZC], worst[ZC];
     int bk0[ZC], bk1[ZC];
 #pragma unroll
@@ -553,7 +585,7 @@ __global__ __launch_bounds__(256) void spectral3_kernel(
       const int lw = lw_next;
       lw_next = __float_as_int(rk[RL]);  // rows has K+1 entries; used by the next iteration
       float rdu[ZC];
-      if (uni) {
+      {
         const float *ru = rdi + (long)k * NzP + zb;  // NzP >= Nz + ZC: no bound check
 #pragma unroll
         for (int o = 0; o < ZC; ++o) rdu[o] = ru[o];
@@ -562,13 +594,7 @@ __global__ __launch_bounds__(256) void spectral3_kernel(
       conv3_sel<LWMAX>(w, rk + 1, lw, num);
 #pragma unroll
       for (int o = 0; o < ZC; ++o) {
-        f32x2 T;
-        if (uni) {
-          T = num[o] * (f32x2){rdu[o], rdu[o]};
-        } else {
-          const long zi = (long)min(zb + o, Nz - 1) * Kp + k;
-          T = (f32x2){num[o].x * rd[0][zi], num[o].y * rd[1][zi]};
-        }
+        const f32x2 T = num[o] * (f32x2){rdu[o], rdu[o]};
         // strict '>' : the first maximum wins                             (lib :1210)
         if (T.x > best[o].x) best[o].x = T.x, bk0[o] = k;
         if (T.y > best[o].y) best[o].y = T.y, bk1[o] = k;
@@ -583,10 +609,9 @@ __global__ __launch_bounds__(256) void spectral3_kernel(
         const long idx = (long)zz * S + s0;
         f32x2 b = best[o];
         int k0 = bk0[o], k1 = bk1[o];
-        if (mask) {  // correl[mask] = 0 ; profile[mask] = 0          (steps.py:781,788)
-          if (mask[idx]) b.x = 0.0f, k0 = 0;
-          if (mask[idx + 1]) b.y = 0.0f, k1 = 0;
-        }
+        // correl[mask] = 0 ; profile[mask] = 0                        (steps.py:781,788)
+        if (mk[o] & 0x00ff) b.x = 0.0f, k0 = 0;
+        if (mk[o] & 0xff00) b.y = 0.0f, k1 = 0;
         if (live) {
           *reinterpret_cast<f32x2 *>(correl + idx) = b;
           *reinterpret_cast<f32x2 *>(correl_min + idx) = worst[o];
@@ -600,7 +625,7 @@ __global__ __launch_bounds__(256) void spectral3_kernel(
 #pragma unroll
     for (int i = 0; i < W - ZC; ++i) w[i] = w[i + ZC];
 #pragma unroll
-    for (int o = 0; o < ZC; ++o) w[W - ZC + o] = load2(zb + ZC + LWMAX + o);
+    for (int o = 0; o < ZC; ++o) w[W - ZC + o] = incoming[o];
   }
   if (live && part_max) {
     *reinterpret_cast<f32x2 *>(part_max + (long)blockIdx.y * S + s0) = vmax;
@@ -617,9 +642,12 @@ __global__ __launch_bounds__(256) void spectral_generic_kernel(
     int Ny, int Nx, int P, int zchunk, const uint8_t *__restrict__ mask,
     float *__restrict__ correl,
     uint8_t *__restrict__ profile, float *__restrict__ correl_min,
-    float *__restrict__ part_max, float *__restrict__ part_min) {
+    float *__restrict__ part_max, float *__restrict__ part_min,
+    const int *__restrict__ list, int nlist) {
   const long S = (long)Ny * Nx;
   const long s = (long)blockIdx.x * 256 + threadIdx.x;
+  (void)list;
+  (void)nlist;
   if (s >= S) return;
   const int z0 = blockIdx.y * zchunk;
   const int z1 = min(Nz, z0 + zchunk);
@@ -686,6 +714,32 @@ __global__ __launch_bounds__(256) void maxmap_final_kernel(const float *__restri
   if (minmap) minmap[s] = b;
 }
 
+// maxmap / minmap of the listed spaxels straight from the final cubes (border fix-up)
+__global__ __launch_bounds__(256) void list_maps_kernel(const float *__restrict__ correl,
+                                                        const float *__restrict__ correl_min,
+                                                        int Nz, long S, const int *__restrict__ list,
+                                                        int nlist, float *__restrict__ maxmap,
+                                                        float *__restrict__ minmap) {
+  // one wave per listed spaxel: lanes stride over z, then a wave reduction
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= nlist) return;
+  const long s = list[i];
+  float a = -INFINITY, b = INFINITY;
+  for (int z = threadIdx.x & 63; z < Nz; z += 64) {
+    a = fmaxf(a, correl[(long)z * S + s]);
+    b = fminf(b, correl_min[(long)z * S + s]);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a = fmaxf(a, __shfl_xor(a, off, 64));
+    b = fminf(b, __shfl_xor(b, off, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (maxmap) maxmap[s] = a;
+    if (minmap) minmap[s] = b;
+  }
+}
+
 int spectral_zchunks(origin_ctx *ctx, long S, int Nz, int lwmax) {
   const long blocks = (S + 255) / 256;
   long want = ((long)ctx->num_cu * 8 + blocks - 1) / blocks;
@@ -722,7 +776,7 @@ int origin_glr_plan_destroy(origin_glr_plan *plan) {
   for (void *p : {(void *)plan->d_k, (void *)plan->d_k2, (void *)plan->d_w, (void *)plan->d_taps,
                   (void *)plan->d_taps2, (void *)plan->d_tap_off, (void *)plan->d_rden,
                   (void *)plan->d_htaps, (void *)plan->d_htap_off, (void *)plan->d_rows,
-                  (void *)plan->d_rdi})
+                  (void *)plan->d_rdi, (void *)plan->d_border})
     if (p) (void)hipFree(p);
   delete plan;
   return ORIGIN_OK;
@@ -840,6 +894,13 @@ int origin_glr_plan_create(origin_ctx *ctx, int Nz, int Ny, int Nx, int nfields,
   TRY(upload(ctx, off, &pl->d_tap_off, &pl->bytes));
 
   if (pl->mode == 0) {
+    std::vector<int> border;
+    const int c = P / 2;
+    for (int y = 0; y < Ny; ++y)
+      for (int x = 0; x < Nx; ++x)
+        if (y < c || y > Ny - 1 - c || x < c || x > Nx - 1 - c) border.push_back(y * Nx + x);
+    pl->nborder = (int)border.size();
+    TRY(upload(ctx, border, &pl->d_border, &pl->bytes));
     double *ncls = nullptr;
     const size_t ncls_n = (size_t)Nz * PP;
     hipError_t e = hipMalloc((void **)&ncls, ncls_n * sizeof(double));
@@ -975,23 +1036,42 @@ int origin_glr_run(origin_ctx *ctx, origin_glr_plan *pl, const float *d_cube,
   hipLaunchKernelGGL(KERNEL, grid, block, 0, ctx->stream, fsf, norm, pl->d_rden, pl->d_taps, \
                      pl->d_taps2, pl->d_tap_off, K, pl->Kp, Nz, Ny, Nx, P, zchunk, d_mask,   \
                      d_correl,                                                              \
-                     d_profile, d_correl_min, pmax, pmin)
+                     d_profile, d_correl_min, pmax, pmin, (const int *)nullptr, 0)
   const bool gen = pl->mode == 1;
+  bool border_fix = false;
   {
   ProfScope ps(ctx, K_GLR_SPECTRAL);
   if (!gen && (S & 1) == 0 && pl->lwt) {
     // packed path: one lane = two adjacent spaxels, SPEC_ZC channels per step
     dim3 g2(cdiv(S / 2, 256), nzc);
 #define LAUNCH3(LW)                                                                            \
-  hipLaunchKernelGGL((spectral3_kernel<LW>), g2, block, 0, ctx->stream, fsf, pl->d_rden,       \
-                     pl->d_rdi, pl->NzP, pl->d_rows, K, pl->Kp, Nz, Ny, Nx, P, zchunk, d_mask,  \
-                     d_correl, d_profile, d_correl_min, pmax, pmin)
+  hipLaunchKernelGGL((spectral3_kernel<LW>), g2, block, 0, ctx->stream, fsf, pl->d_rdi, pl->NzP, \
+                     pl->d_rows, K, Nz, Ny, Nx, zchunk, d_mask, d_correl, d_profile,           \
+                     d_correl_min, pmax, pmin)
     switch (pl->lwt) {
       case 8: LAUNCH3(8); break;
       case 16: LAUNCH3(16); break;
       case 24: LAUNCH3(24); break;
       case 29: LAUNCH3(29); break;
       default: LAUNCH3(32); break;
+    }
+    if (pl->nborder > 0) {  // border spaxels: exact per-class normalisation
+      // few spaxels: cut z finer so that the pass still fills the chip (its maps are redone
+      // from the final cubes below, so it writes no partials)
+      const long bb = cdiv(pl->nborder, 256);
+      int nzb = (int)(((long)ctx->num_cu * 12 + bb - 1) / bb);
+      nzb = std::max(1, std::min(nzb, Nz / (4 * std::max(pl->lwmax, 1) + 4)));
+      nzb = std::max(nzb, 1);
+      const int zcb = cdiv(Nz, nzb);
+      dim3 gb((unsigned)bb, cdiv(Nz, zcb));
+      border_fix = true;
+#define LAUNCHB(LW)                                                                            \
+  hipLaunchKernelGGL((spectral_kernel<LW, false>), gb, block, 0, ctx->stream, fsf, norm,       \
+                     pl->d_rden, pl->d_taps, pl->d_taps2, pl->d_tap_off, K, pl->Kp, Nz, Ny, Nx, \
+                     P, zcb, d_mask, d_correl, d_profile, d_correl_min, (float *)nullptr,      \
+                     (float *)nullptr, pl->d_border, pl->nborder)
+      if (pl->lwmax <= 8) LAUNCHB(8); else if (pl->lwmax <= 16) LAUNCHB(16); else LAUNCHB(32);
+#undef LAUNCHB
     }
 #undef LAUNCH3
   } else if (pl->lwmax <= 8) {
@@ -1010,6 +1090,10 @@ int origin_glr_run(origin_ctx *ctx, origin_glr_plan *pl, const float *d_cube,
     ProfScope ps(ctx, K_SMALL);
     hipLaunchKernelGGL(maxmap_final_kernel, dim3(cdiv(S, 256)), dim3(256), 0, ctx->stream, pmax,
                        pmin, nzc, S, d_maxmap, d_minmap);
+    if (border_fix)
+      hipLaunchKernelGGL(list_maps_kernel, dim3(cdiv(pl->nborder, 4)), dim3(256), 0, ctx->stream,
+                         d_correl, d_correl_min, Nz, S, pl->d_border, pl->nborder, d_maxmap,
+                         d_minmap);
     ORIGIN_LAUNCH_CHECK();
   }
   return ORIGIN_OK;
