@@ -316,9 +316,9 @@ def _convolve_spectral(parallel, nslices, arr, shape, func):
 
 def _convolve_profile(Dico, cube_fft, norm_fft, fshape, n_jobs, parallel):
     """lib_origin.py:1046-1060."""
-    dico_fft = fft.rfftn(Dico, fshape)[:, None] * cube_fft
+    dico_fft = fft.rfftn(Dico, fshape, axes=(0,))[:, None] * cube_fft
     cube_profile = _convolve_spectral(parallel, n_jobs, dico_fft, fshape, func=fft.irfftn)
-    dico_fft = fft.rfftn(Dico ** 2, fshape)[:, None] * norm_fft
+    dico_fft = fft.rfftn(Dico ** 2, fshape, axes=(0,))[:, None] * norm_fft
     norm_profile = _convolve_spectral(parallel, n_jobs, dico_fft, fshape, func=fft.irfftn)
     norm_profile[norm_profile <= 0] = np.inf
     np.sqrt(norm_profile, out=norm_profile)

@@ -223,7 +223,8 @@ __global__ __launch_bounds__(1024) void gather_xp_kernel(const float *__restrict
                                                          const long *__restrict__ D, int nw,
                                                          const double *__restrict__ b,
                                                          double *__restrict__ Xp,
-                                                         double *__restrict__ cvec) {
+                                                         double *__restrict__ cpart, long ctot,
+                                                         int zper) {
   __shared__ double red[16][64];
   const int k = blockIdx.y;
   const int ld = (int)DSC(DF_LD, k);
@@ -236,8 +237,9 @@ __global__ __launch_bounds__(1024) void gather_xp_kernel(const float *__restrict
   const double *bk = b + (long)k * Nz;
   double *X = Xp + DSC(DF_XP, k);
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  const int z0 = blockIdx.z * zper, z1 = min(Nz, z0 + zper);
   double acc = 0.0;
-  for (int z = w; z < Nz; z += 16) {
+  for (int z = z0 + w; z < z1; z += 16) {
     const double v = live ? (double)F[(long)z * S + col] : 0.0;
     if (inld) X[(long)z * ld + j] = v;
     acc = fma(bk[z], v, acc);
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(1024) void gather_xp_kernel(const float *__restrict
     double t = 0.0;
 #pragma unroll
     for (int q = 0; q < 16; ++q) t += red[q][threadIdx.x];
-    cvec[DSC(DF_C, k) + j] = t;
+    cpart[(long)blockIdx.z * ctot + DSC(DF_C, k) + j] = t;
   }
 }
 
@@ -256,17 +258,18 @@ __global__ __launch_bounds__(1024) void gather_xp_kernel(const float *__restrict
 __global__ __launch_bounds__(256) void project_xp_kernel(const double *__restrict__ b, int Nz,
                                                          const long *__restrict__ D, int nw,
                                                          double *__restrict__ Xp,
-                                                         const double *__restrict__ cvec) {
+                                                         const double *__restrict__ cpart,
+                                                         long ctot, int nzb) {
   const int k = blockIdx.y;
   const int ld = (int)DSC(DF_LD, k);
   double *X = Xp + DSC(DF_XP, k);
-  const double *c = cvec + DSC(DF_C, k);
+  const double *c = cpart + DSC(DF_C, k);
   const double *bk = b + (long)k * Nz;
   const int z0 = blockIdx.x * 16, z1 = min(Nz, z0 + 16);
-  for (int z = z0; z < z1; ++z) {
-    const double bz = bk[z];
-    for (int j = threadIdx.x; j < ld; j += 256)
-      X[(long)z * ld + j] = fma(-bz, c[j], X[(long)z * ld + j]);
+  for (int j = threadIdx.x; j < ld; j += 256) {
+    double cj = 0.0;  // c_j = b^T X_j, summed over the z slices of the gather in fixed order
+    for (int q = 0; q < nzb; ++q) cj += c[(long)q * ctot + j];
+    for (int z = z0; z < z1; ++z) X[(long)z * ld + j] = fma(-bk[z], cj, X[(long)z * ld + j]);
   }
 }
 
@@ -409,7 +412,7 @@ __global__ __launch_bounds__(1024) void lanczos_kernel(const double *__restrict_
   double *y = Qk + (long)(LANCZOS_M + 1) * ld;
   double *v = vout + v_off[k];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int mmax = min(LANCZOS_M, n);
+  const int mfull = min(LANCZOS_M, n);
 
   // start vector: G * ones (a few power-like steps come for free in the Krylov space)
   for (int r = wave; r < n; r += 16) {
@@ -431,6 +434,8 @@ __global__ __launch_bounds__(1024) void lanczos_kernel(const double *__restrict_
     __syncthreads();
     int m = 0;
     double beta_last = 0.0;
+    // a dominant nuisance converges in a few steps: try a short Krylov space first
+    const int mmax = restarts == 0 ? min(mfull, LANCZOS_M / 2) : mfull;
     for (int j = 0; j < mmax; ++j) {
       const double *qj = Qk + (long)j * ld;
       double *w = Qk + (long)(j + 1) * ld;
@@ -509,7 +514,7 @@ __global__ __launch_bounds__(1024) void lanczos_kernel(const double *__restrict_
       for (int i = 0; i < mm; ++i) tnorm = fmax(tnorm, fabs(alpha[i]) + (i < mm - 1 ? fabs(beta[i]) : 0.0));
       const double sigma = s_theta + 4e-16 * tnorm;
       for (int i = 0; i < mm; ++i) x[i] = 1.0 / sqrt((double)mm);
-      for (int iter = 0; iter < 3; ++iter) {
+      for (int iter = 0; iter < 2; ++iter) {
         for (int i = 0; i < mm; ++i) {
           d[i] = alpha[i] - sigma;
           du[i] = i < mm - 1 ? beta[i] : 0.0;
@@ -776,7 +781,7 @@ int origin_pca_run(origin_ctx *ctx, float *d_F, int Nz, long S, int na, const in
   if (ntot == 0) return ORIGIN_OK;
 
   // ---- persistent state on the device
-  DevBuf b_state, b_lists, b_test, b_desc, b_tiles, b_xp, b_g, b_cv, b_bu, b_part;
+  DevBuf b_state, b_lists, b_test, b_desc, b_tiles, b_xp, b_g, b_cv, b_bu, b_part, b_cpart;
   const size_t st_bytes = (size_t)na * (sizeof(double) + 4 * sizeof(int)) + sizeof(int) * 2 +
                           (size_t)(na + 1) * sizeof(long) + 64;
   int rc;
@@ -900,15 +905,23 @@ int origin_pca_run(origin_ctx *ctx, float *d_F, int Nz, long S, int na, const in
       hipLaunchKernelGGL(bmean_kernel, dim3(cdiv(Nz, 4), nw), dim3(64, 4), 0, st, d_F, Nz, S, d_bg,
                          dD, nw, d_b);
     }
+    // z slices of the gather: enough blocks to fill the chip even when few areas iterate
+    int nzb = (int)(((long)ctx->num_cu * 2 + (long)cdiv(ldmax, 64) * nw - 1) /
+                    ((long)cdiv(ldmax, 64) * nw));
+    nzb = std::max(1, std::min(nzb, 16));
+    const int gzper = (cdiv(Nz, nzb) + 15) / 16 * 16;
+    nzb = cdiv(Nz, gzper);
+    if ((rc = b_cpart.reserve(ctx, (size_t)nzb * c * sizeof(double)))) return rc;
+    double *d_cpart = (double *)b_cpart.p;
     {
       ProfScope ps(ctx, K_PCA_GATHER);
-      hipLaunchKernelGGL(gather_xp_kernel, dim3(cdiv(ldmax, 64), nw), dim3(64, 16), 0, st, d_F, Nz,
-                         S, d_nuis, dD, nw, d_b, d_Xp, d_c);
+      hipLaunchKernelGGL(gather_xp_kernel, dim3(cdiv(ldmax, 64), nw, nzb), dim3(64, 16), 0, st,
+                         d_F, Nz, S, d_nuis, dD, nw, d_b, d_Xp, d_cpart, c, gzper);
     }
     {
       ProfScope ps(ctx, K_PCA_PROJECT);
       hipLaunchKernelGGL(project_xp_kernel, dim3(cdiv(Nz, 16), nw), dim3(256), 0, st, d_b, Nz, dD,
-                         nw, d_Xp, d_c);
+                         nw, d_Xp, d_cpart, c, nzb);
     }
     ORIGIN_LAUNCH_CHECK();
     if ((rc = gram_launch(ctx, d_Xp, dXP, dLD, Nz, ntiles, d_ti, d_tj, d_ta, g, d_G, dG))) return rc;

@@ -1,0 +1,313 @@
+"""Spatial tiling of the hot path over the GPUs of one node.
+
+One process per GPU.  The field is cut into a gy x gx grid of tiles whose boundaries follow
+the PCA area grid, so every area lives on exactly one GPU and the greedy PCA needs no
+communication.  Two exchanges remain:
+
+* one all-reduce of 2*Nz float64 (per-channel sum and count of the DCT residual) for the
+  ``nanmean`` over the *whole* field in the standardisation (reference steps.py:442);
+* one halo exchange of ``cube_faint`` before the GLR: strips of P//2 spaxels from the (up to)
+  8 neighbours, done in two phases (x, then y including the fresh x halos, which delivers
+  the corners without diagonal messages).  Outside the true field nothing is exchanged:
+  the kernels zero-pad there exactly as the reference's ``fftconvolve(..., 'same')`` does.
+
+The GLR then runs on the halo-extended tile as if it were a field of its own: spatial sums
+of kept spaxels only touch data inside the extension, and their border class is the class
+with respect to the *true* field border because kept spaxels are at least P//2 away from any
+internal cut.  Only the interior tile is kept.
+
+Collectives go through ``torch.distributed`` -- backend ``nccl`` (RCCL over xGMI) on device
+buffers viewed zero-copy through ``__cuda_array_interface__``, or ``gloo`` with host staging
+(CPU tests; also the fallback if RCCL cannot be initialised).  torch is imported only here
+and only when more than one rank exists.
+"""
+import os
+from collections import namedtuple
+
+import numpy as np
+
+from . import _capi, kernels
+
+Tile = namedtuple("Tile", "rank ty tx y0 y1 x0 x1")
+
+
+def _split(n_units, parts):
+    """Split n_units into `parts` contiguous groups whose sizes differ by at most one."""
+    base, rem = divmod(n_units, parts)
+    sizes = [base + (1 if i < rem else 0) for i in range(parts)]
+    edges = np.concatenate([[0], np.cumsum(sizes)])
+    return edges
+
+
+def grid_shape(world):
+    """gy x gx with gy*gx == world, as square as possible, gx >= gy."""
+    gy = int(np.floor(np.sqrt(world)))
+    while world % gy:
+        gy -= 1
+    return gy, world // gy
+
+
+class Tiling:
+    """Tile grid aligned to the area grid (areas are area_size x area_size squares, the last
+    one absorbs the remainder, as synth.grid_areamap builds them)."""
+
+    def __init__(self, Ny, Nx, world, area_size=100, halo=12):
+        self.Ny, self.Nx, self.world, self.halo = Ny, Nx, world, halo
+        self.gy, self.gx = grid_shape(world)
+        nay, nax = max(1, Ny // area_size), max(1, Nx // area_size)
+        if self.gy > nay or self.gx > nax:
+            raise ValueError(f"{world} tiles do not fit a {nay}x{nax} area grid")
+        ey = _split(nay, self.gy) * area_size
+        ex = _split(nax, self.gx) * area_size
+        ey[-1], ex[-1] = Ny, Nx
+        self.ey, self.ex = ey, ex
+
+    def tile(self, rank):
+        ty, tx = divmod(rank, self.gx)
+        return Tile(rank, ty, tx, int(self.ey[ty]), int(self.ey[ty + 1]), int(self.ex[tx]),
+                    int(self.ex[tx + 1]))
+
+    def neighbour(self, rank, dy, dx):
+        ty, tx = divmod(rank, self.gx)
+        ny_, nx_ = ty + dy, tx + dx
+        if 0 <= ny_ < self.gy and 0 <= nx_ < self.gx:
+            return ny_ * self.gx + nx_
+        return None
+
+    def extended(self, rank):
+        """Extent of the tile plus its halo, clipped to the field: (y0, y1, x0, x1) and the
+        halo widths (top, bottom, left, right) actually present."""
+        t, h = self.tile(rank), self.halo
+        top = h if t.ty > 0 else 0
+        bot = h if t.ty < self.gy - 1 else 0
+        left = h if t.tx > 0 else 0
+        right = h if t.tx < self.gx - 1 else 0
+        return (t.y0 - top, t.y1 + bot, t.x0 - left, t.x1 + right), (top, bot, left, right)
+
+
+# ------------------------------------------------------------------------------- comm
+class TorchComm:
+    """torch.distributed wrapper.  ``device_p2p`` is True when strips can travel GPU to GPU
+    (backend nccl == RCCL); otherwise they are staged through host memory."""
+
+    def __init__(self, rank, world, local_rank, backend=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank, self.world, self.local_rank = rank, world, local_rank
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() and torch.cuda.device_count() >= world \
+                else "gloo"
+        self.note = ""
+        if not dist.is_initialized():
+            try:
+                if backend == "nccl":
+                    torch.cuda.set_device(local_rank)
+                dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            except Exception as exc:  # RCCL unavailable: host staging over gloo
+                if backend != "nccl":
+                    raise
+                self.note = f"nccl init failed ({exc}); gloo host staging"
+                backend = "gloo"
+                dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        self.backend = dist.get_backend()
+        self.device_p2p = self.backend == "nccl"
+        self.dev = torch.device("cuda", local_rank) if self.device_p2p else torch.device("cpu")
+
+    # -- small host collectives ------------------------------------------------
+    def allreduce_sum(self, arr):
+        t = self.torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64).copy())
+        if self.device_p2p:
+            t = t.to(self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t.cpu().numpy()
+
+    def max_float(self, x):
+        t = self.torch.tensor([float(x)], dtype=self.torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.cpu()[0])
+
+    def barrier(self):
+        if self.device_p2p:
+            self.dist.barrier(device_ids=[self.local_rank])
+        else:
+            self.dist.barrier()
+
+    def close(self):
+        if self.dist.is_initialized():
+            self.dist.destroy_process_group()
+
+    # -- strip exchange ----------------------------------------------------------
+    def exchange(self, ctx, sends, recvs):
+        """sends / recvs: lists of (peer_rank, DeviceArray) -- contiguous float32 strips.
+        Every rank posts its receives and sends together (batched point-to-point)."""
+        torch, dist = self.torch, self.dist
+        if not sends and not recvs:
+            return
+        ctx.sync()
+        ops, host_recv = [], []
+        if self.device_p2p:
+            for peer, buf in recvs:
+                ops.append(dist.P2POp(dist.irecv, torch.as_tensor(buf, device=self.dev), peer))
+            for peer, buf in sends:
+                ops.append(dist.P2POp(dist.isend, torch.as_tensor(buf, device=self.dev), peer))
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            torch.cuda.synchronize(self.dev)
+        else:
+            for peer, buf in recvs:
+                t = torch.empty(buf.shape, dtype=torch.float32)
+                host_recv.append((t, buf))
+                ops.append(dist.P2POp(dist.irecv, t, peer))
+            for peer, buf in sends:
+                ops.append(dist.P2POp(dist.isend, torch.from_numpy(buf.to_host()), peer))
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            for t, buf in host_recv:
+                buf.upload(t.numpy())
+
+
+def init_comm(rank, world, local_rank, backend=None):
+    return TorchComm(rank, world, local_rank, backend)
+
+
+# ------------------------------------------------------------------------------- halo
+def _copy_box(ctx, dst, dst_shape, dst_off, src, src_shape, src_off, box):
+    """device->device copy of an (nz, ny, nx) box between float32 cubes of the given shapes."""
+    nz, ny, nx = box
+    es = src.dtype.itemsize
+    sp = src.ptr + ((src_off[0] * src_shape[1] + src_off[1]) * src_shape[2] + src_off[2]) * es
+    dp = dst.ptr + ((dst_off[0] * dst_shape[1] + dst_off[1]) * dst_shape[2] + dst_off[2]) * es
+    import ctypes as C
+    _capi.call("origin_copy_box", ctx.handle, 2, C.c_void_p(dp), dst_shape[2],
+               dst_shape[1] * dst_shape[2], C.c_void_p(sp), src_shape[2],
+               src_shape[1] * src_shape[2], nz, ny, nx, es)
+
+
+def halo_plan(tiling, rank, ny, nx):
+    """The two exchange phases of one rank as plain index boxes (no data):
+    [(phase, peer, send_src, recv_dst, (by, bx)), ...] where phase 0 strips are cut from the
+    bare tile (y, x offsets in tile coordinates) and phase 1 strips from the extended tile
+    (offsets in extended coordinates); recv_dst is always in extended coordinates."""
+    (_, _, _, _), (top, bot, left, right) = tiling.extended(rank)
+    h = tiling.halo
+    nx_e = nx + left + right
+    plan = []
+    for dx, src_x, dst_x in ((-1, 0, 0), (1, nx - h, left + nx)):
+        peer = tiling.neighbour(rank, 0, dx)
+        if peer is not None:
+            plan.append((0, peer, (0, src_x), (top, dst_x), (ny, h)))
+    for dy, src_y, dst_y in ((-1, top, 0), (1, top + ny - h, top + ny)):
+        peer = tiling.neighbour(rank, dy, 0)
+        if peer is not None:
+            plan.append((1, peer, (src_y, 0), (dst_y, 0), (h, nx_e)))
+    return plan
+
+
+def exchange_halo(ctx, comm, tiling, rank, cube, ext=None):
+    """Build the halo-extended copy of this rank's (Nz, ny, nx) device tile.  Returns the
+    extended DeviceArray (Nz, ny + top + bot, nx + left + right)."""
+    Nz, ny, nx = cube.shape
+    (_, _, _, _), (top, bot, left, right) = tiling.extended(rank)
+    eshape = (Nz, ny + top + bot, nx + left + right)
+    if ext is None:
+        ext = ctx.empty(eshape, np.float32)
+    _copy_box(ctx, ext, eshape, (0, top, left), cube, cube.shape, (0, 0, 0), (Nz, ny, nx))
+    plan = halo_plan(tiling, rank, ny, nx)
+    for phase in (0, 1):
+        src, sshape = (cube, cube.shape) if phase == 0 else (ext, eshape)
+        sends, recvs, unpack = [], [], []
+        for ph, peer, (sy, sx), (dy, dx), (by, bx) in plan:
+            if ph != phase:
+                continue
+            sbuf = ctx.empty((Nz, by, bx), np.float32)
+            _copy_box(ctx, sbuf, sbuf.shape, (0, 0, 0), src, sshape, (0, sy, sx), (Nz, by, bx))
+            rbuf = ctx.empty((Nz, by, bx), np.float32)
+            sends.append((peer, sbuf))
+            recvs.append((peer, rbuf))
+            unpack.append((rbuf, (0, dy, dx), (Nz, by, bx)))
+        comm.exchange(ctx, sends, recvs)
+        for rbuf, off, box in unpack:
+            _copy_box(ctx, ext, eshape, off, rbuf, rbuf.shape, (0, 0, 0), box)
+    return ext
+
+
+def exchange_halo_host(comm, tiling, rank, tile):
+    """Same exchange on host ndarrays (float64 allowed) -- used by the CPU (gloo) tests to
+    check the tiling arithmetic against the untiled oracle."""
+    torch, dist = comm.torch, comm.dist
+    Nz, ny, nx = tile.shape
+    (_, _, _, _), (top, bot, left, right) = tiling.extended(rank)
+    ext = np.zeros((Nz, ny + top + bot, nx + left + right), dtype=tile.dtype)
+    ext[:, top: top + ny, left: left + nx] = tile
+    plan = halo_plan(tiling, rank, ny, nx)
+    for phase in (0, 1):
+        src = tile if phase == 0 else ext
+        ops, pending = [], []
+        for ph, peer, (sy, sx), (dy, dx), (by, bx) in plan:
+            if ph != phase:
+                continue
+            sbuf = torch.from_numpy(np.ascontiguousarray(src[:, sy: sy + by, sx: sx + bx]))
+            rbuf = torch.empty((Nz, by, bx), dtype=sbuf.dtype)
+            pending.append((rbuf, dy, dx, by, bx))
+            ops.append(dist.P2POp(dist.irecv, rbuf, peer))
+            ops.append(dist.P2POp(dist.isend, sbuf, peer))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for rbuf, dy, dx, by, bx in pending:
+            ext[:, dy: dy + by, dx: dx + bx] = rbuf.numpy()
+    return ext
+
+
+class TiledGLR:
+    """GLR of one tile of a tiled field: halo exchange + plan on the extended tile + crop."""
+
+    def __init__(self, ctx, comm, tiling, rank, Nz, PSF, profiles, pcut=1e-8, pmeansub=True):
+        self.ctx, self.comm, self.tiling, self.rank, self.Nz = ctx, comm, tiling, rank, Nz
+        (y0, y1, x0, x1), self.halos = tiling.extended(rank)
+        self.eshape = (Nz, y1 - y0, x1 - x0)
+        self.plan = kernels.GLRPlan(ctx, self.eshape, PSF, None, profiles, pcut, pmeansub)
+        t = tiling.tile(rank)
+        self.shape = (Nz, t.y1 - t.y0, t.x1 - t.x0)
+        self.ext = ctx.empty(self.eshape, np.float32)
+        self.emask = ctx.zeros(self.eshape, np.uint8)
+        self.out = dict(correl=ctx.empty(self.eshape, np.float32),
+                        correl_min=ctx.empty(self.eshape, np.float32),
+                        profile=ctx.empty(self.eshape, np.uint8))
+        self._mask_set = False
+
+    def run(self, cube_faint, mask, correl, profile, correl_min):
+        ctx = self.ctx
+        top, bot, left, right = self.halos
+        Nz, ny, nx = self.shape
+        exchange_halo(ctx, self.comm, self.tiling, self.rank, cube_faint, self.ext)
+        if mask is not None and not self._mask_set:  # halo spaxels are discarded: mask 0 there
+            _copy_box(ctx, self.emask, self.eshape, (0, top, left), mask, mask.shape, (0, 0, 0),
+                      (Nz, ny, nx))
+            self._mask_set = True
+        o = self.plan.run(self.ext, mask=self.emask if mask is not None else None,
+                          correl=self.out["correl"], profile=self.out["profile"],
+                          correl_min=self.out["correl_min"], want_maps=True)
+        for name, dst in (("correl", correl), ("correl_min", correl_min), ("profile", profile)):
+            _copy_box(ctx, dst, dst.shape, (0, 0, 0), o[name], self.eshape, (0, top, left),
+                      (Nz, ny, nx))
+        e_ny, e_nx = self.eshape[1:]
+        maps = {}
+        for name in ("maxmap", "minmap"):
+            full = o[name].to_host().reshape(e_ny, e_nx)
+            maps[name] = full[top: top + ny, left: left + nx].copy()
+        return dict(correl=correl, profile=profile, correl_min=correl_min,
+                    maxmap=_HostMap(maps["maxmap"]), minmap=_HostMap(maps["minmap"]))
+
+
+class _HostMap:
+    """Tiny adaptor so tiled and single-GPU results expose ``to_host()`` alike."""
+
+    def __init__(self, arr):
+        self.arr = arr
+
+    def to_host(self):
+        return self.arr

@@ -1,0 +1,96 @@
+"""Worker of the multi-process tiling tests (one process per rank, torch.distributed).
+
+mode 'cpu' : host arrays + the CPU oracle per tile (gloo) -- checks the tiling arithmetic
+             (area-aligned tiles, global per-channel mean, two-phase halo exchange, border
+             classes of the extended tile) against the untiled oracle, bit-for-bit level.
+mode 'gpu' : the same decomposition through the HIP path (all ranks share GPU 0, strips are
+             host-staged over gloo) against the single-context HIP result.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from origin_amd import multigpu, synth  # noqa: E402
+
+
+def field():
+    f = synth.SyntheticField(96, 40, 60, seed=5, psf_size=9, nprof=3, blob_density=1 / 80,
+                             emitter_density=1 / 300, area_size=20)
+    raw, var, mask = f.arrays()
+    mask[10:14, 3, 7] = True
+    mask[:, 25, 41] = True
+    raw[mask] = 0
+    var[mask] = np.inf
+    return f, raw, var, mask
+
+
+def main():
+    mode, out = sys.argv[1], sys.argv[2]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    comm = multigpu.init_comm(rank, world, 0, backend="gloo")
+    f, raw, var, mask = field()
+    Nz, Ny, Nx = raw.shape
+    tiling = multigpu.Tiling(Ny, Nx, world, area_size=20, halo=f.PSF.shape[1] // 2)
+    t = tiling.tile(rank)
+    sl = (slice(None), slice(t.y0, t.y1), slice(t.x0, t.x1))
+    traw, tvar, tmask = raw[sl], var[sl], mask[sl]
+    amap = f.areamap[t.y0:t.y1, t.x0:t.x1]
+    labels = np.unique(amap)
+    lmap = np.searchsorted(labels, amap) + 1
+    res = {}
+    if mode == "cpu":
+        from oracle import cpu_ref
+        r64, v64 = traw.astype(float), tvar.astype(float)
+        cont = cpu_ref.dct_residual(r64, 10, v64, False, tmask)
+        data = r64 - cont
+        data[tmask] = np.nan
+        both = comm.allreduce_sum(np.concatenate([np.nansum(data, axis=(1, 2)),
+                                                  np.sum(~tmask, axis=(1, 2)).astype(float)]))
+        mean = both[:Nz] / both[Nz:]
+        data = (data - mean[:, None, None]) / np.sqrt(v64)
+        data[tmask] = 0
+        thr = cpu_ref.pca_threshold_areas(data, lmap, len(labels), 0.01)
+        faint, mapO2, nstop = cpu_ref.Compute_GreedyPCA_area(len(labels), data, lmap, 50, thr[3],
+                                                             100, thr[0])
+        ext = multigpu.exchange_halo_host(comm, tiling, rank, faint)
+        (_, _, _, _), (top, bot, left, right) = tiling.extended(rank)
+        emask = np.zeros(ext.shape, bool)
+        emask[:, top:top + tmask.shape[1], left:left + tmask.shape[2]] = tmask
+        g = cpu_ref.compute_TGLR(ext, f.PSF.astype(float), None, f.profiles, emask, pcut=1e-8)
+        crop = (slice(None), slice(top, top + tmask.shape[1]), slice(left, left + tmask.shape[2]))
+        res = dict(cube_std=data, cube_faint=faint, correl=g["cube_correl"][crop],
+                   correl_min=g["cube_correl_min"][crop], mapO2=mapO2,
+                   maxmap=g["maxmap"][crop[1:]], thr=np.array(thr[3]))
+    else:
+        from origin_amd import kernels, pipeline
+        from origin_amd.device import Context
+        ctx = Context(0)
+        d_raw, d_var = ctx.to_device(traw, np.float32), ctx.to_device(tvar, np.float32)
+        d_mask = ctx.to_device(tmask.astype(np.uint8))
+        pre = pipeline.preprocess(ctx, d_raw, d_var, d_mask, 10, False,
+                                  allreduce=comm.allreduce_sum)
+        spx = pipeline.area_lists(lmap, len(labels))
+        thr = pipeline.pca_threshold(pre["o2"].to_host(), lmap, len(labels), 0.01, spx=spx)
+        faint, mapO2, nstop, _ = pipeline.greedy_pca(ctx, pre["cube_std"], lmap, len(labels),
+                                                     thr["thresO2"], thr["testO2"], spx=spx)
+        glr = multigpu.TiledGLR(ctx, comm, tiling, rank, Nz, f.PSF.astype(float), f.profiles,
+                                pcut=1e-8)
+        shape = d_raw.shape
+        correl = ctx.empty(shape, np.float32)
+        cmin = ctx.empty(shape, np.float32)
+        prof = ctx.empty(shape, np.uint8)
+        o = glr.run(faint, d_mask, correl, prof, cmin)
+        res = dict(cube_std=pre["cube_std"].to_host(), cube_faint=faint.to_host(),
+                   correl=correl.to_host(), correl_min=cmin.to_host(), mapO2=mapO2,
+                   maxmap=o["maxmap"].to_host(), thr=np.array(thr["thresO2"]))
+    np.savez(f"{out}.rank{rank}.npz", y0=t.y0, y1=t.y1, x0=t.x0, x1=t.x1, **res)
+    comm.barrier()
+    comm.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,110 @@
+"""Tiling / halo-exchange tests: world_size 2 and 4 over gloo.
+
+CPU (always): the decomposition run with the CPU oracle per tile equals the untiled oracle.
+GPU (-m gpu): the same decomposition through the HIP kernels (ranks share GPU 0, host-staged
+strips) equals the single-context HIP chain.
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def run_ranks(mode, world, out):
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests",
+                                                                    "_mp_tiled_worker.py"),
+                                       mode, out], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    logs = []
+    for p in procs:
+        o, _ = p.communicate(timeout=600)
+        logs.append(o.decode()[-3000:])
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    tiles = [np.load(f"{out}.rank{r}.npz") for r in range(world)]
+    return tiles
+
+
+def stitch(tiles, key, shape):
+    full = np.zeros(shape, dtype=tiles[0][key].dtype)
+    for t in tiles:
+        sl = (slice(int(t["y0"]), int(t["y1"])), slice(int(t["x0"]), int(t["x1"])))
+        if len(shape) == 3:
+            full[(slice(None),) + sl] = t[key]
+        else:
+            full[sl] = t[key]
+    return full
+
+
+def test_tiling_follows_area_grid():
+    from origin_amd.multigpu import Tiling
+    for world, (gy, gx) in {1: (1, 1), 2: (1, 2), 4: (2, 2), 8: (2, 4)}.items():
+        tl = Tiling(600, 600, world, area_size=100, halo=12)
+        assert (tl.gy, tl.gx) == (gy, gx)
+        cover = np.zeros((600, 600), int)
+        for r in range(world):
+            t = tl.tile(r)
+            assert t.y0 % 100 == 0 and t.x0 % 100 == 0      # PCA areas never straddle tiles
+            cover[t.y0:t.y1, t.x0:t.x1] += 1
+            (ey0, ey1, ex0, ex1), (top, bot, left, right) = tl.extended(r)
+            assert ey0 >= 0 and ex0 >= 0 and ey1 <= 600 and ex1 <= 600
+            assert top == (12 if t.ty > 0 else 0) and right == (12 if t.tx < gx - 1 else 0)
+        assert np.all(cover == 1)
+    with pytest.raises(ValueError):
+        Tiling(100, 100, 4, area_size=100)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_tiled_oracle_equals_untiled_oracle(tmp_path, world):
+    from _mp_tiled_worker import field
+    from oracle import cpu_ref
+    f, raw, var, mask = field()
+    tiles = run_ranks("cpu", world, str(tmp_path / "cpu"))
+    ref = cpu_ref.run_chain(raw.astype(float), var.astype(float), mask, f.PSF.astype(float), None,
+                            f.profiles, f.areamap, f.nbAreas)
+    shape = raw.shape
+    for key, rk in (("cube_std", "cube_std"), ("cube_faint", "cube_faint"),
+                    ("correl", "cube_correl"), ("correl_min", "cube_correl_min")):
+        got = stitch(tiles, key, shape)
+        assert np.max(np.abs(got - ref[rk])) <= 1e-9 * max(1.0, np.max(np.abs(ref[rk]))), key
+    assert np.array_equal(stitch(tiles, "mapO2", shape[1:]), ref["mapO2"])
+    assert np.max(np.abs(stitch(tiles, "maxmap", shape[1:]) - ref["maxmap"])) <= 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_tiled_hip_equals_single_hip(tmp_path, world):
+    from _mp_tiled_worker import field
+    from oracle import cpu_ref
+    f, raw, var, mask = field()
+    tiles = run_ranks("gpu", world, str(tmp_path / "gpu"))
+    single = run_ranks("gpu", 1, str(tmp_path / "one"))
+    shape = raw.shape
+    for key, tol in (("cube_std", 1e-6), ("cube_faint", 1e-5), ("correl", 1e-4),
+                     ("correl_min", 1e-4)):
+        got, one = stitch(tiles, key, shape), stitch(single, key, shape)
+        assert np.max(np.abs(got - one)) <= tol, key
+    assert np.array_equal(stitch(tiles, "mapO2", shape[1:]), stitch(single, "mapO2", shape[1:]))
+    # and against the oracle
+    ref = cpu_ref.run_chain(raw.astype(float), var.astype(float), mask, f.PSF.astype(float), None,
+                            f.profiles, f.areamap, f.nbAreas)
+    assert np.max(np.abs(stitch(tiles, "correl", shape) - ref["cube_correl"])) <= 2e-4
+    assert np.max(np.abs(stitch(tiles, "maxmap", shape[1:]) - ref["maxmap"])) <= 2e-4
