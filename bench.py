@@ -192,6 +192,10 @@ def main():
         "glr_spatial": ("mfma", 2.0 * 25 * 25 * local_vox),
         "glr_spectral": ("mfma", 2.0 * ntaps * local_vox),
     }
+    if world > 1:  # the GLR runs on the halo-extended tile
+        ext_vox = float(Nz) * glr.eshape[1] * glr.eshape[2]
+        algo["glr_spatial"] = ("mfma", 2.0 * 25 * 25 * ext_vox)
+        algo["glr_spectral"] = ("mfma", 2.0 * ntaps * ext_vox)
     dominant = max(prof.items(), key=lambda kv: kv[1][0])[0] if prof else None
     roofline = None
     if dominant in algo:
@@ -246,7 +250,8 @@ def main():
             "config": {"workload": f"synthetic {Nz}x{N}x{N} cube, Dico_FWHM_2_12 "
                                    f"({args.nprof} profiles), PSF 25x25, 100x100 areas, "
                                    "dct_order 10, pfa 0.01, Noise_population 50, itermax 100",
-                       "tiles": world, "pca": info,
+                       "tiles": world, "comm": (comm.backend + (" " + comm.note if comm.note else ""))
+                       if comm is not None else None, "pca": info,
                        "gen_seconds": round(t_gen, 1)},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,

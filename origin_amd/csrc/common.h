@@ -27,6 +27,7 @@ enum OriginKernelId {
   K_PCA_DEFLATE_UPDATE,
   K_GLR_SPATIAL,
   K_GLR_SPECTRAL,
+  K_GLR_BORDER,
   K_GLR_TABLES,
   K_LOCAL_MAX,
   K_SMALL,
@@ -61,6 +62,13 @@ struct origin_ctx {
 
 void origin_prof_begin(origin_ctx *ctx, int id);
 void origin_prof_end(origin_ctx *ctx);
+// close the open scope and open a new one of class `id` (no-op when profiling is off)
+static inline void origin_prof_end_begin(origin_ctx *ctx, int id) {
+  if (ctx->prof_on) {
+    origin_prof_end(ctx);
+    origin_prof_begin(ctx, id);
+  }
+}
 
 // RAII: times everything enqueued on ctx->stream during its lifetime as kernel class `id`
 struct ProfScope {

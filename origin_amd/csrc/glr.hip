@@ -1056,6 +1056,7 @@ int origin_glr_run(origin_ctx *ctx, origin_glr_plan *pl, const float *d_cube,
       default: LAUNCH3(32); break;
     }
     if (pl->nborder > 0) {  // border spaxels: exact per-class normalisation
+      origin_prof_end_begin(ctx, K_GLR_BORDER);
       // few spaxels: cut z finer so that the pass still fills the chip (its maps are redone
       // from the final cubes below, so it writes no partials)
       const long bb = cdiv(pl->nborder, 256);
