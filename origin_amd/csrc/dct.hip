@@ -478,6 +478,7 @@ int origin_dct_fit(origin_ctx *ctx, const float *d_raw, const float *d_var,
   int ZS = 1;
   while (ZS < 8 && waves * ZS < (long)ctx->num_cu * 16) ZS *= 2;
   const int NACC = (2 * order + 1) + 2 * (order + 1);
+  while (ZS > 1 && (size_t)(ZS - 1) * (NACC + 1) * 64 * sizeof(double) > 64 * 1024) ZS /= 2;
   const size_t lds = (size_t)(ZS - 1) * (NACC + 1) * 64 * sizeof(double);
   dim3 grid((unsigned)waves), block(64, ZS);
   ProfScope ps(ctx, K_DCT_FIT);

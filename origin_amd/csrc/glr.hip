@@ -714,30 +714,49 @@ __global__ __launch_bounds__(256) void maxmap_final_kernel(const float *__restri
   if (minmap) minmap[s] = b;
 }
 
-// maxmap / minmap of the listed spaxels straight from the final cubes (border fix-up)
+// maxmap / minmap of the listed spaxels straight from the final cubes (border fix-up).
+// Lanes run over list entries (border rows are contiguous in memory), z is cut in slices
+// whose partial extrema are merged with ordered-int atomics (max/min are order independent,
+// so the result is deterministic).
+__device__ __forceinline__ void atomic_max_f(float *addr, float v) {
+  if (v >= 0.0f)
+    atomicMax(reinterpret_cast<int *>(addr), __float_as_int(v));
+  else
+    atomicMin(reinterpret_cast<unsigned *>(addr), __float_as_uint(v));
+}
+__device__ __forceinline__ void atomic_min_f(float *addr, float v) {
+  if (v >= 0.0f)
+    atomicMin(reinterpret_cast<int *>(addr), __float_as_int(v));
+  else
+    atomicMax(reinterpret_cast<unsigned *>(addr), __float_as_uint(v));
+}
+
+__global__ __launch_bounds__(256) void list_maps_init_kernel(const int *__restrict__ list, int nlist,
+                                                             float *__restrict__ maxmap,
+                                                             float *__restrict__ minmap) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nlist) return;
+  if (maxmap) maxmap[list[i]] = -INFINITY;
+  if (minmap) minmap[list[i]] = INFINITY;
+}
+
 __global__ __launch_bounds__(256) void list_maps_kernel(const float *__restrict__ correl,
                                                         const float *__restrict__ correl_min,
-                                                        int Nz, long S, const int *__restrict__ list,
-                                                        int nlist, float *__restrict__ maxmap,
+                                                        int Nz, long S, int zper,
+                                                        const int *__restrict__ list, int nlist,
+                                                        float *__restrict__ maxmap,
                                                         float *__restrict__ minmap) {
-  // one wave per listed spaxel: lanes stride over z, then a wave reduction
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= nlist) return;
   const long s = list[i];
+  const int z0 = blockIdx.y * zper, z1 = min(Nz, z0 + zper);
   float a = -INFINITY, b = INFINITY;
-  for (int z = threadIdx.x & 63; z < Nz; z += 64) {
+  for (int z = z0; z < z1; ++z) {
     a = fmaxf(a, correl[(long)z * S + s]);
     b = fminf(b, correl_min[(long)z * S + s]);
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    a = fmaxf(a, __shfl_xor(a, off, 64));
-    b = fminf(b, __shfl_xor(b, off, 64));
-  }
-  if ((threadIdx.x & 63) == 0) {
-    if (maxmap) maxmap[s] = a;
-    if (minmap) minmap[s] = b;
-  }
+  if (maxmap) atomic_max_f(maxmap + s, a);
+  if (minmap) atomic_min_f(minmap + s, b);
 }
 
 int spectral_zchunks(origin_ctx *ctx, long S, int Nz, int lwmax) {
@@ -1091,10 +1110,14 @@ int origin_glr_run(origin_ctx *ctx, origin_glr_plan *pl, const float *d_cube,
     ProfScope ps(ctx, K_SMALL);
     hipLaunchKernelGGL(maxmap_final_kernel, dim3(cdiv(S, 256)), dim3(256), 0, ctx->stream, pmax,
                        pmin, nzc, S, d_maxmap, d_minmap);
-    if (border_fix)
-      hipLaunchKernelGGL(list_maps_kernel, dim3(cdiv(pl->nborder, 4)), dim3(256), 0, ctx->stream,
-                         d_correl, d_correl_min, Nz, S, pl->d_border, pl->nborder, d_maxmap,
-                         d_minmap);
+    if (border_fix) {
+      const int zper = 64;
+      hipLaunchKernelGGL(list_maps_init_kernel, dim3(cdiv(pl->nborder, 256)), dim3(256), 0,
+                         ctx->stream, pl->d_border, pl->nborder, d_maxmap, d_minmap);
+      hipLaunchKernelGGL(list_maps_kernel, dim3(cdiv(pl->nborder, 256), cdiv(Nz, zper)), dim3(256),
+                         0, ctx->stream, d_correl, d_correl_min, Nz, S, zper, pl->d_border,
+                         pl->nborder, d_maxmap, d_minmap);
+    }
     ORIGIN_LAUNCH_CHECK();
   }
   return ORIGIN_OK;

@@ -1,0 +1,180 @@
+"""GPU edge cases of the HIP path: ragged / odd sizes (which select the non-vectorised and
+unpacked kernel variants), PSF sizes without a specialised kernel, one profile, weights with
+the production PSF, degenerate PCA inputs, fully masked channels, and cross-checks between the
+table-normalised and the explicit-norm GLR paths.  Oracle: oracle/cpu_ref.py."""
+import numpy as np
+import pytest
+
+from oracle import cpu_ref
+from origin_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import origin_amd.lib_origin as lib
+    return lib
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from origin_amd.device import default_context
+    return default_context(0)
+
+
+def noise(shape, seed):
+    return np.random.default_rng(seed).standard_normal(shape, dtype=np.float32).astype(float)
+
+
+@pytest.mark.parametrize("Ny,Nx,P,nprof", [(27, 31, 9, 3), (26, 30, 7, 3), (9, 11, 3, 1),
+                                           (33, 34, 5, 20), (40, 44, 25, 3), (25, 25, 25, 3)])
+def test_glr_ragged_shapes_vs_oracle(hip, Ny, Nx, P, nprof):
+    Nz = 90
+    cube = noise((Nz, Ny, Nx), 1000 + Ny)
+    psf = synth.moffat_psf(Nz, P).astype(float)
+    profs = synth.dico_fwhm(nprof)
+    got = hip.Correlation_GLR_test(cube, psf, None, profs, pcut=1e-8)
+    ref = cpu_ref.Correlation_GLR_test_direct(cube, psf, None, profs, pcut=1e-8)
+    assert np.max(np.abs(got[0] - ref[0])) <= 1e-4
+    assert np.max(np.abs(got[2] - ref[2])) <= 1e-4
+    assert np.mean(got[1] != ref[1]) <= 2e-4
+
+
+def test_glr_weights_production_psf(hip):
+    Nz, Ny, Nx = 60, 30, 32
+    cube = noise((Nz, Ny, Nx), 7)
+    p0 = synth.moffat_psf(Nz, 25).astype(float)
+    p1 = synth.moffat_psf(Nz, 25, fwhm0=2.7, fwhm1=3.4).astype(float)
+    w0 = (0.2 + 0.6 * np.linspace(0, 1, Ny)[:, None] * np.ones((1, Nx))).astype(np.float32)
+    w = [w0.astype(float), 1.0 - w0.astype(float)]
+    got = hip.Correlation_GLR_test(cube, [p0, p1], w, synth.dico_fwhm(3), pcut=1e-8)
+    ref = cpu_ref.Correlation_GLR_test_direct(cube, [p0, p1], w, synth.dico_fwhm(3), pcut=1e-8)
+    assert np.max(np.abs(got[0] - ref[0])) <= 1e-4 and np.max(np.abs(got[2] - ref[2])) <= 1e-4
+
+
+def test_glr_table_path_equals_explicit_norm_path(hip):
+    """weights=None (border-class tables + packed kernels) vs one field with weights == 1
+    (explicit norm cube + generic kernels): same algebra, two code paths."""
+    Nz, Ny, Nx = 400, 64, 72
+    cube = noise((Nz, Ny, Nx), 11)
+    psf = synth.moffat_psf(Nz, 25).astype(float)
+    profs = synth.dico_fwhm(20)
+    a = hip.Correlation_GLR_test(cube, psf, None, profs, pcut=1e-8)
+    b = hip.Correlation_GLR_test(cube, [psf], [np.ones((Ny, Nx))], profs, pcut=1e-8)
+    assert np.max(np.abs(a[0] - b[0])) <= 5e-5 and np.max(np.abs(a[2] - b[2])) <= 5e-5
+    assert np.mean(a[1] != b[1]) <= 2e-4
+
+
+def test_glr_mask_glue_and_maps(ctx):
+    from origin_amd import kernels
+    Nz, Ny, Nx = 80, 28, 30
+    cube = noise((Nz, Ny, Nx), 13)
+    mask = np.random.default_rng(5).random((Nz, Ny, Nx)) < 0.05
+    psf = synth.moffat_psf(Nz, 9).astype(float)
+    profs = synth.dico_fwhm(3)
+    plan = kernels.GLRPlan(ctx, cube.shape, psf, None, profs, 1e-8, True)
+    out = plan.run(ctx.to_device(cube, np.float32), mask=ctx.to_device(mask.astype(np.uint8)))
+    ref = cpu_ref.compute_TGLR(cube, psf, None, profs, mask, pcut=1e-8)
+    correl = out["correl"].to_host()
+    assert np.all(correl[mask] == 0) and np.all(out["profile"].to_host()[mask] == 0)
+    assert np.max(np.abs(correl - ref["cube_correl"])) <= 1e-4
+    assert np.max(np.abs(out["maxmap"].to_host() - ref["maxmap"])) <= 1e-4
+    assert np.max(np.abs(out["minmap"].to_host() - ref["minmap"])) <= 1e-4
+    plan.close()
+
+
+def test_pca_degenerate_inputs(hip):
+    rng = np.random.default_rng(3)
+    cube = rng.standard_normal((120, 150)).astype(np.float32).astype(float)
+    test = cpu_ref.O2test(cube)
+    # threshold above every O2: nothing to do
+    faint, mapO2, nstop = hip.Compute_GreedyPCA(cube, test, 1e9, 50, 100)
+    assert np.array_equal(faint, cube) and not mapO2.any() and nstop == 0
+    # itermax = 0: every area with a nuisance stops at once
+    faint, mapO2, nstop = hip.Compute_GreedyPCA(cube, test, float(np.median(test)), 50, 0)
+    r = cpu_ref.Compute_GreedyPCA(cube, test, float(np.median(test)), 50, 0)
+    assert np.array_equal(faint, cube) and nstop == r[2] == 1 and np.array_equal(mapO2, r[1])
+    # exactly one nuisance spaxel: the reference breaks without touching the data
+    thr = float(np.sort(test)[-2])
+    faint, mapO2, nstop = hip.Compute_GreedyPCA(cube, test, thr, 50, 100)
+    r = cpu_ref.Compute_GreedyPCA(cube, test, thr, 50, 100)
+    assert np.array_equal(faint, cube) and np.array_equal(mapO2, r[1]) and nstop == r[2]
+    # fractional Noise_population and a spaxel with O2 == 0 (filtered-index quirk, lib :908-917)
+    cube2 = cube.copy()
+    cube2[:, 4] = 0.0
+    cube2[:, 7] *= 6
+    cube2[:, 90] *= 4
+    test2 = cpu_ref.O2test(cube2)
+    thr2 = 2.0
+    got = hip.Compute_GreedyPCA(cube2, test2, thr2, 33.3, 100)
+    ref = cpu_ref.Compute_GreedyPCA(cube2, test2, thr2, 33.3, 100, svd="dense")
+    assert np.array_equal(got[1], ref[1]) and got[2] == ref[2]
+    assert np.max(np.abs(got[0] - ref[0])) <= 1e-4
+
+
+def test_pca_area_with_unassigned_spaxels(hip):
+    """areamap label 0 (outside every area, reference steps.py:559-565) is left untouched."""
+    rng = np.random.default_rng(8)
+    cube = rng.standard_normal((100, 12, 14)).astype(np.float32).astype(float)
+    cube[:, 3, 3] *= 5
+    cube[:, 8, 9] *= 7
+    areamap = np.ones((12, 14), int)
+    areamap[:, 7:] = 2
+    areamap[0, :] = 0
+    res = [cpu_ref.Compute_PCA_threshold(cube[:, areamap == i], 0.01) for i in (1, 2)]
+    thr = [1.5, 1.5]
+    got = hip.Compute_GreedyPCA_area(2, cube, areamap, 50, thr, 100, [r[0] for r in res])
+    ref = cpu_ref.Compute_GreedyPCA_area(2, cube, areamap, 50, thr, 100, [r[0] for r in res],
+                                         svd="dense")
+    assert np.array_equal(got[1], ref[1]) and got[2] == ref[2]
+    assert np.max(np.abs(got[0] - ref[0])) <= 1e-4
+    assert np.array_equal(got[0][:, 0, :], cube[:, 0, :])
+
+
+def test_preprocess_fully_masked_channel_and_spaxel(ctx):
+    from origin_amd import pipeline
+    f, raw, var, mask = synth.small_case(Nz=96, Ny=10, Nx=13, seed=21, psf_size=7)
+    mask[17] = True          # a whole channel
+    mask[:, 2, 5] = True     # a whole spaxel
+    raw[mask] = 0
+    var[mask] = np.inf
+    out = pipeline.preprocess(ctx, ctx.to_device(raw), ctx.to_device(var),
+                              ctx.to_device(mask.astype(np.uint8)))
+    with np.errstate(all="ignore"):
+        ref = cpu_ref.preprocessing(raw.astype(float), var.astype(float), mask)
+    got = out["cube_std"].to_host()
+    assert np.all(np.isfinite(got)) and np.all(got[mask] == 0)
+    err = np.abs(got - ref["cube_std"]) / np.maximum(1, np.abs(ref["cube_std"]))
+    assert err.max() <= 1e-5
+    assert out["o2"].to_host()[2, 5] == 0
+
+
+@pytest.mark.parametrize("order", [1, 4, 12])
+def test_dct_other_orders(hip, order):
+    f, raw, var, mask = synth.small_case(Nz=150, Ny=6, Nx=9, seed=order, psf_size=7)
+    got = hip.dct_residual(raw, order, var, False, mask)
+    ref = cpu_ref.dct_residual(raw.astype(float), order, var.astype(float), False, mask)
+    assert np.max(np.abs(got - ref) / np.maximum(1, np.abs(ref))) <= 1e-5
+
+
+def test_local_max_sizes(hip):
+    a = noise((20, 9, 11), 2).astype(np.float32)
+    b = noise((20, 9, 11), 3).astype(np.float32)
+    mask = np.zeros(a.shape, bool)
+    mask[3, 4, 5] = True
+    for size in (1, 2, 3, 5):
+        got = hip.compute_local_max(a, b, mask, size)
+        ref = cpu_ref.compute_local_max(a.astype(float), b.astype(float), mask, size)
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+
+
+def test_bad_arguments_raise(ctx, hip):
+    from origin_amd import _capi, kernels
+    with pytest.raises(_capi.OriginHipError):
+        kernels.GLRPlan(ctx, (10, 8, 8), np.ones((10, 5, 5)), None, [np.ones(7)] * 300)  # K > 255
+    with pytest.raises(ValueError):
+        kernels.GLRPlan(ctx, (10, 8, 8), np.ones((9, 5, 5)), None, [np.ones(7)])  # Nz mismatch
+    with pytest.raises(ValueError):
+        hip.Compute_GreedyPCA_area(1, np.zeros((5, 2, 2)), np.ones((2, 2), int), 50, [1.0], 10,
+                                   [np.zeros(3)])  # testO2 length != area size
