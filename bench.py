@@ -130,7 +130,10 @@ def main():
     profile = ctx.empty((Nz, ny, nx), np.uint8)
     info = {}
 
+    phase = {}
+
     def one_step():
+        t0 = time.perf_counter()
         coef = kernels.dct_fit(ctx, raw, var, mask, 10, False)
         zsum, zcnt = kernels.dct_resid_sums(ctx, raw, mask, coef)
         if allreduce is not None:
@@ -139,11 +142,15 @@ def main():
             zcnt.upload(both[Nz:])
         pre = kernels.dct_standardize(ctx, raw, var, mask, coef, zsum, zcnt, cube_std=cube_std,
                                       cont_dct=cont_dct)
-        thr = pipeline.pca_threshold(pre["o2"].to_host(), local_map, nb_local, 0.01, spx=spx)
+        o2 = pre["o2"].to_host()
+        t1 = time.perf_counter()
+        thr = pipeline.pca_threshold(o2, local_map, nb_local, 0.01, spx=spx)
+        t2 = time.perf_counter()
         cube_faint.copy_from(cube_std)
         F, mapO2, nstop, drv = pipeline.greedy_pca(ctx, cube_faint, local_map, nb_local,
                                                    thr["thresO2"], thr["testO2"], 50, 100,
                                                    spx=spx, inplace=True)
+        t3 = time.perf_counter()
         if world > 1:
             out = glr.run(cube_faint, mask, correl, profile, correl_min)
         else:
@@ -152,6 +159,10 @@ def main():
         if args.local_max:
             kernels.local_max(ctx, correl, correl_min, mask, 3)
         ctx.sync()
+        t4 = time.perf_counter()
+        for k, v in (("dct_std", t1 - t0), ("threshold_fit_host", t2 - t1),
+                     ("greedy_pca", t3 - t2), ("glr", t4 - t3)):
+            phase[k] = phase.get(k, 0.0) + v
         info["pca_iters"] = drv.iterations
         info["n_nuis_first"] = drv.trace[0][1] if drv.trace else 0
         info["nstop"] = nstop
@@ -167,6 +178,7 @@ def main():
         one_step()
     ctx.prof_reset()
     ctx.prof_enable(True)
+    phase.clear()
     barrier()
     ctx.sync()
     t0 = time.perf_counter()
@@ -194,7 +206,7 @@ def main():
         "dct_plane_sums": ("hbm", 5.0 * local_vox),     # raw 4 + mask 1
         "dct_standardize": ("hbm", 17.0 * local_vox),   # + cube_std 4 + cont_dct 4
         "pca_deflate_dot": ("hbm", 4.0),                # per voxel of the launch's areas
-        "pca_deflate_update": ("hbm", 8.0),
+        "pca_flush": ("hbm", 8.0 * local_vox),
         # flops per launch for the compute-bound GLR stages (fp32 FMA = 2 flop)
         "glr_spatial": ("mfma", 2.0 * 25 * 25 * local_vox),
         "glr_spectral": ("mfma", 2.0 * ntaps * local_vox),
@@ -265,6 +277,8 @@ def main():
                        "gen_seconds": round(t_gen, 1)},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
+            "wall_ms_per_step_by_phase": {k: round(1e3 * v / max(1, args.steps), 2)
+                                          for k, v in phase.items()},
             "kernels_ms_per_step": {k: round(v[0] / max(1, args.steps), 3)
                                     for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
             "kernel_launches_per_step": {k: v[1] // max(1, args.steps) for k, v in prof.items()},

@@ -25,6 +25,7 @@ enum OriginKernelId {
   K_PCA_UVEC,
   K_PCA_DEFLATE_DOT,
   K_PCA_DEFLATE_UPDATE,
+  K_PCA_FLUSH,
   K_GLR_SPATIAL,
   K_GLR_SPECTRAL,
   K_GLR_BORDER,

@@ -91,7 +91,7 @@ static const char *kKernelNames[K_COUNT] = {
     "dct_fit",         "dct_plane_sums",     "dct_standardize", "dct_continuum", "o2",
     "pca_select",      "pca_bmean",          "pca_gather",      "pca_project",   "pca_gram",
     "pca_eig",         "pca_uvec",
-    "pca_deflate_dot", "pca_deflate_update", "glr_spatial",     "glr_spectral",  "glr_border", "glr_tables",
+    "pca_deflate_dot", "pca_deflate_finish", "pca_flush", "glr_spatial",     "glr_spectral",  "glr_border", "glr_tables",
     "local_max",       "small"};
 
 extern "C" {

@@ -10,6 +10,15 @@
 //   u   = leading left singular vector of Xp (ARPACK svds(k=1, tol=0))         (:940)
 //   F  -= u (u^T F) over the whole area; test = mean_z F^2                     (:943-946)
 //
+// Coefficient form.  The cube is NOT rewritten every iteration.  With X the input (cube_std)
+// the deflated cube after t iterations is  F_t = X - sum_{k<t} u_k c_k^T,  c_k = F_{k-1}^T u_k,
+// so the library keeps the vectors U (per area) and the coefficient rows C (per spaxel) and
+// evaluates columns of F_t on the fly where an iteration needs them (background mean, nuisance
+// block).  One iteration then reads the area once (c_t = X^T u_t - C^T (U^T u_t)) instead of
+// reading it twice and writing it once, and the O2 test follows from Pythagoras:
+// |F_t|^2 = |F_{t-1}|^2 - c_t^2 exactly (u_t has unit norm).  The cube itself is produced by
+// one final pass F = X - U C (single float32 rounding instead of one per iteration).
+//
 // All areas advance in lock step (they are independent, lib :806-819), every kernel is
 // batched over the areas still iterating, and the control flow (which spaxels are
 // nuisances, which background spectra feed the mean, when an area stops) runs on the device:
@@ -23,6 +32,7 @@
 //
 // A block never straddles two areas, so per-area vectors (b, u) are wave-uniform.
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "common.h"
@@ -38,7 +48,13 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 }
 
 // descriptor fields of the per-iteration work list (int64 [DF_COUNT][nw])
-enum { DF_AREA = 0, DF_LIST0, DF_N, DF_NB, DF_LD, DF_XP, DF_C, DF_G, DF_Q, DF_NS, DF_CBASE, DF_COUNT };
+enum {
+  DF_AREA = 0, DF_LIST0, DF_N, DF_NB, DF_LD, DF_XP, DF_C, DF_G, DF_Q, DF_NS, DF_CBASE,
+  DF_T,    // vectors already removed from this area (rows of C / columns of U in use)
+  DF_CN,   // offset of the gathered coefficient block Cn[T][ld] of this area
+  DF_COUNT
+};
+constexpr int PCA_CAP = 64;  // vectors kept per area before the cube is flushed (F = X - U C)
 #define DSC(f, k) (D[(long)(f) * nw + (k)])
 
 // ------------------------------------------------------------------------------------
@@ -69,8 +85,8 @@ __global__ __launch_bounds__(1024) void pca_select_kernel(
     const int *__restrict__ spx, const long *__restrict__ spx_off, const double *__restrict__ test,
     const double *__restrict__ thr_, double noise_pop, int itermax, int *__restrict__ active,
     int *__restrict__ nbiter, int *__restrict__ nstop, int *__restrict__ mapO2,
-    int *__restrict__ nuis, int *__restrict__ bg, int *__restrict__ n_out,
-    int *__restrict__ nb_out) {
+    int *__restrict__ nuis, int *__restrict__ bg, int *__restrict__ nuis_pos,
+    int *__restrict__ bg_pos, int *__restrict__ n_out, int *__restrict__ nb_out) {
   __shared__ int wtot[16];
   __shared__ int hist[256];
   __shared__ unsigned long long s_prefix;
@@ -99,6 +115,7 @@ __global__ __launch_bounds__(1024) void pca_select_kernel(
     const int r = scan.exclusive(isn, tot);
     if (isn) {
       nuis[o0 + n + r] = sp;
+      nuis_pos[o0 + n + r] = (int)(o0 + i);
       mapO2[sp] += 1;  // mapO2[pypx] += 1                                       (lib :901)
     }
     n += tot;
@@ -178,7 +195,10 @@ __global__ __launch_bounds__(1024) void pca_select_kernel(
       const int re = scan.exclusive(eq, te);
       const bool emit = cand && (key < tau || (eq && (neq + re) < need_equal));
       const int rm = scan.exclusive(emit, tm);
-      if (emit) bg[o0 + nemit + rm] = spx[o0 + nfilt + rf];
+      if (emit) {
+        bg[o0 + nemit + rm] = spx[o0 + nfilt + rf];
+        bg_pos[o0 + nemit + rm] = (int)(o0 + nfilt + rf);
+      }
       nfilt += tf;
       neq += te;
       nemit += tm;
@@ -196,52 +216,86 @@ __global__ __launch_bounds__(1024) void pca_select_kernel(
 }
 
 // ------------------------------------------------------------------------------------
-// b_k[z] = mean_{i in bg_k} F[z, bg[i]]        grid (ceil(Nz/4), nw), block (64,4)
+// cbar_k[q] = mean_{i in bg_k} C[q][bg_pos_i], q < T_k           grid (nw), block 1024
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bmean_kernel(const float *__restrict__ F, int Nz, long S,
+__global__ __launch_bounds__(1024) void cbar_kernel(const double *__restrict__ C, long ntot,
+                                                    const int *__restrict__ bg_pos,
+                                                    const long *__restrict__ D, int nw,
+                                                    double *__restrict__ cbar) {
+  const int k = blockIdx.x;
+  const int T = (int)DSC(DF_T, k);
+  const int nb = (int)DSC(DF_NB, k);
+  const long o0 = DSC(DF_LIST0, k);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int q = wave; q < T; q += 16) {
+    const double *row = C + (long)q * ntot;
+    double acc = 0.0;
+    for (int i = lane; i < nb; i += 64) acc += row[bg_pos[o0 + i]];
+    acc = wave_sum_d(acc);
+    if (lane == 0) cbar[(long)k * PCA_CAP + q] = acc / (double)nb;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// b_k[z] = mean_{i in bg_k} F_t[z, bg_i] = mean_i X[z, bg_i] - sum_q U[z][q] cbar[q]
+// grid (ceil(Nz/4), nw), block (64,4).  U layout: [area][z][PCA_CAP].
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bmean_kernel(const float *__restrict__ X, int Nz, long S,
                                                     const int *__restrict__ bg,
                                                     const long *__restrict__ D, int nw,
+                                                    const double *__restrict__ U,
+                                                    const double *__restrict__ cbar,
                                                     double *__restrict__ b) {
   const int k = blockIdx.y;
   const int z = blockIdx.x * 4 + threadIdx.y;
   if (z >= Nz) return;
   const long o0 = DSC(DF_LIST0, k);
-  const int nb = (int)DSC(DF_NB, k);
-  const float *row = F + (long)z * S;
+  const int nb = (int)DSC(DF_NB, k), T = (int)DSC(DF_T, k);
+  const float *row = X + (long)z * S;
   double acc = 0.0;
   for (int i = threadIdx.x; i < nb; i += 64) acc += (double)row[bg[o0 + i]];
+  acc /= (double)nb;
+  if ((int)threadIdx.x < T)  // T <= PCA_CAP == 64 lanes
+    acc -= U[((long)DSC(DF_AREA, k) * Nz + z) * PCA_CAP + threadIdx.x] *
+           cbar[(long)k * PCA_CAP + threadIdx.x];
   acc = wave_sum_d(acc);
-  if (threadIdx.x == 0) b[(long)k * Nz + z] = acc / (double)nb;
+  if (threadIdx.x == 0) b[(long)k * Nz + z] = acc;
 }
 
 // ------------------------------------------------------------------------------------
-// gather the nuisance columns into X (float64, [Nz][ld]) and c_j = b^T X_j
-// grid (ceil(ldmax/64), nw), block (64 columns, 16 waves over z)
+// Nuisance block of F_t (float64, [Nz][ld]):  Xp[z][j] = X[z, col_j] - sum_q U[z][q] C[q][pos_j]
+// and the partial c_j = b^T Xp_j of the block's z slice.
+// grid (ceil(ldmax/64), nw, z slices), block (64 columns, 16 waves over z)
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void gather_xp_kernel(const float *__restrict__ F, int Nz,
-                                                         long S, const int *__restrict__ nuis,
-                                                         const long *__restrict__ D, int nw,
-                                                         const double *__restrict__ b,
-                                                         double *__restrict__ Xp,
-                                                         double *__restrict__ cpart, long ctot,
-                                                         int zper) {
+__global__ __launch_bounds__(1024) void gather_xp_kernel(
+    const float *__restrict__ X, int Nz, long S, const int *__restrict__ nuis,
+    const int *__restrict__ nuis_pos, const long *__restrict__ D, int nw,
+    const double *__restrict__ b, const double *__restrict__ U, const double *__restrict__ C,
+    long ntot, double *__restrict__ Xp, double *__restrict__ cpart, long ctot, int zper) {
   __shared__ double red[16][64];
+  __shared__ double Cn[PCA_CAP][64];  // coefficients of this block's 64 columns
   const int k = blockIdx.y;
   const int ld = (int)DSC(DF_LD, k);
   const int j = blockIdx.x * 64 + threadIdx.x;
   if (blockIdx.x * 64 >= ld) return;  // whole block out of range (uniform)
-  const int n = (int)DSC(DF_N, k);
+  const int n = (int)DSC(DF_N, k), T = (int)DSC(DF_T, k);
   const bool live = j < n;   // real nuisance column
   const bool inld = j < ld;  // padded column (stored as zeros)
   const long col = live ? (long)nuis[DSC(DF_LIST0, k) + j] : 0;
+  const long pos = live ? (long)nuis_pos[DSC(DF_LIST0, k) + j] : 0;
   const double *bk = b + (long)k * Nz;
-  double *X = Xp + DSC(DF_XP, k);
+  const double *Ua = U + (long)DSC(DF_AREA, k) * Nz * PCA_CAP;
+  double *Xk = Xp + DSC(DF_XP, k);
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  for (int q = w; q < T; q += 16) Cn[q][threadIdx.x] = live ? C[(long)q * ntot + pos] : 0.0;
+  __syncthreads();
   const int z0 = blockIdx.z * zper, z1 = min(Nz, z0 + zper);
   double acc = 0.0;
   for (int z = z0 + w; z < z1; z += 16) {
-    const double v = live ? (double)F[(long)z * S + col] : 0.0;
-    if (inld) X[(long)z * ld + j] = v;
+    double v = live ? (double)X[(long)z * S + col] : 0.0;
+    const double *uz = Ua + (long)z * PCA_CAP;  // wave-uniform row of U -> scalar loads
+    for (int q = 0; q < T; ++q) v = fma(-uz[q], Cn[q][threadIdx.x], v);
+    if (inld) Xk[(long)z * ld + j] = v;
     acc = fma(bk[z], v, acc);
   }
   red[threadIdx.y][threadIdx.x] = acc;
@@ -580,7 +634,7 @@ __global__ __launch_bounds__(1024) void lanczos_kernel(const double *__restrict_
 }
 
 // ------------------------------------------------------------------------------------
-// u = Xp v, then normalised.     grid (ceil(Nz/4), nw), block (64,4)
+// u = Xp v, then normalised and appended to U.     grid (ceil(Nz/4), nw), block (64,4)
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void xv_kernel(const double *__restrict__ Xp,
                                                  const long *__restrict__ D, int nw, int Nz,
@@ -598,22 +652,48 @@ __global__ __launch_bounds__(256) void xv_kernel(const double *__restrict__ Xp,
   if (threadIdx.x == 0) u[(long)k * Nz + z] = acc;
 }
 
-__global__ __launch_bounds__(1024) void normalize_kernel(double *__restrict__ u, int Nz) {
+// normalise u_k, store it as column T_k of U, and w_k[q] = u_k . U[:, q] for q < T_k
+__global__ __launch_bounds__(1024) void normalize_kernel(double *__restrict__ u, int Nz,
+                                                         const long *__restrict__ D, int nw,
+                                                         double *__restrict__ U,
+                                                         double *__restrict__ wq) {
   __shared__ double red[16];
-  double *uk = u + (long)blockIdx.x * Nz;
+  __shared__ double wred[16][PCA_CAP];
+  const int k = blockIdx.x;
+  const int T = (int)DSC(DF_T, k);
+  double *uk = u + (long)k * Nz;
+  double *Ua = U + (long)DSC(DF_AREA, k) * Nz * PCA_CAP;
   double acc = 0.0;
   for (int z = threadIdx.x; z < Nz; z += 1024) acc = fma(uk[z], uk[z], acc);
   const double t = block_sum(acc, red);
   const double inv = t > 0.0 ? 1.0 / sqrt(t) : 0.0;
-  for (int z = threadIdx.x; z < Nz; z += 1024) uk[z] *= inv;
+  for (int z = threadIdx.x; z < Nz; z += 1024) {
+    const double x = uk[z] * inv;
+    uk[z] = x;
+    Ua[(long)z * PCA_CAP + T] = x;
+  }
+  __syncthreads();
+  // w[q] = sum_z u[z] U[z][q]: lanes over q (T <= 64), waves over z
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double a = 0.0;
+  if (lane < T)
+    for (int z = wave; z < Nz; z += 16) a = fma(uk[z], Ua[(long)z * PCA_CAP + lane], a);
+  wred[wave][lane] = a;
+  __syncthreads();
+  if (wave == 0 && lane < T) {
+    double sacc = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) sacc += wred[q][lane];
+    wq[(long)k * PCA_CAP + lane] = sacc;
+  }
 }
 
 // ------------------------------------------------------------------------------------
-// deflation of whole areas.
-//   dot    : cpart[zs][i] = sum_{z in slice zs} u_k[z] F[z, spx[i]]
-//   update : c_i = sum_zs cpart ; F[z, spx[i]] -= u_k[z] c_i ; o2part[zs][i] = sum F_new^2
-//   final  : test[spx[i]] = sum_zs o2part / Nz
-// grid (ceil(nsmax/256), ZS, nw); block 256 lanes over the area's spaxel list
+// deflation of whole areas in coefficient form.
+//   dot    : cpart[zs][i] = sum_{z in slice zs} u_k[z] X[z, spx[i]]
+//   finish : c_i = sum_zs cpart - sum_q w[q] C[q][i] (= u^T F_{t-1,i});  C[T][i] = c_i;
+//            test[spx[i]] -= c_i^2 / Nz          (|F_t|^2 = |F_{t-1}|^2 - c^2, |u| = 1)
+// grid (ceil(nsmax/256), ZS, nw) / (ceil(nsmax/256), nw); 256 lanes over the area's list
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void deflate_dot_kernel(const float *__restrict__ F, int Nz,
                                                           long S, const int *__restrict__ spx,
@@ -634,48 +714,69 @@ __global__ __launch_bounds__(256) void deflate_dot_kernel(const float *__restric
   if (live) cpart[(long)blockIdx.y * ntot + DSC(DF_CBASE, k) + li] = acc;
 }
 
-__global__ __launch_bounds__(256) void deflate_update_kernel(float *__restrict__ F, int Nz, long S,
-                                                             const int *__restrict__ spx,
+__global__ __launch_bounds__(256) void deflate_finish_kernel(const int *__restrict__ spx,
                                                              const long *__restrict__ D, int nw,
-                                                             const double *__restrict__ u,
-                                                             int zper, int nzs,
+                                                             int nzs, int Nz, long cb_tot,
                                                              const double *__restrict__ cpart,
-                                                             double *__restrict__ o2part,
-                                                             long ntot) {
-  const int k = blockIdx.z;
-  const int ns = (int)DSC(DF_NS, k);
-  const int li = blockIdx.x * 256 + threadIdx.x;
-  if (li >= ns) return;
-  const long col = spx[DSC(DF_LIST0, k) + li];
-  const long ci = DSC(DF_CBASE, k) + li;
-  const double *uk = u + (long)k * Nz;
-  double c = 0.0;
-  for (int q = 0; q < nzs; ++q) c += cpart[(long)q * ntot + ci];
-  const int z0 = blockIdx.y * zper, z1 = min(Nz, z0 + zper);
-  double acc = 0.0;
-#pragma unroll 4
-  for (int z = z0; z < z1; ++z) {
-    const long idx = (long)z * S + col;
-    const float nv = (float)fma(-uk[z], c, (double)F[idx]);
-    F[idx] = nv;
-    acc = fma((double)nv, (double)nv, acc);
-  }
-  o2part[(long)blockIdx.y * ntot + ci] = acc;
-}
-
-__global__ __launch_bounds__(256) void deflate_final_kernel(const int *__restrict__ spx,
-                                                            const long *__restrict__ D, int nw,
-                                                            int nzs, int Nz, long ntot,
-                                                            const double *__restrict__ o2part,
-                                                            double *__restrict__ test) {
+                                                             const double *__restrict__ wq,
+                                                             double *__restrict__ C, long ntot,
+                                                             double *__restrict__ test) {
   const int k = blockIdx.y;
   const int ns = (int)DSC(DF_NS, k);
   const int li = blockIdx.x * 256 + threadIdx.x;
   if (li >= ns) return;
+  const int T = (int)DSC(DF_T, k);
+  const long pos = DSC(DF_LIST0, k) + li;
   const long ci = DSC(DF_CBASE, k) + li;
-  double acc = 0.0;
-  for (int q = 0; q < nzs; ++q) acc += o2part[(long)q * ntot + ci];
-  test[spx[DSC(DF_LIST0, k) + li]] = acc / (double)Nz;
+  double c = 0.0;
+  for (int q = 0; q < nzs; ++q) c += cpart[(long)q * cb_tot + ci];
+  const double *w = wq + (long)k * PCA_CAP;
+  for (int q = 0; q < T; ++q) c = fma(-w[q], C[(long)q * ntot + pos], c);
+  C[(long)T * ntot + pos] = c;
+  const long sp = spx[pos];
+  test[sp] = test[sp] - c * c / (double)Nz;
+}
+
+// ------------------------------------------------------------------------------------
+// flush: F[z, s] = X[z, s] - sum_{q < T_a} U[z][q] C[q][i]  (in place; one float32 rounding)
+// grid (ceil(nsmax/256), ceil(Nz/16), na_flush); thread = one spaxel x 16 channels
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void flush_kernel(float *__restrict__ F, int Nz, long S,
+                                                    const int *__restrict__ spx,
+                                                    const long *__restrict__ FD, int nf,
+                                                    const double *__restrict__ U,
+                                                    const double *__restrict__ C, long ntot) {
+  // FD: [4][nf] = area, list0, ns, T
+  const int k = blockIdx.z;
+  const int ns = (int)FD[(long)2 * nf + k], T = (int)FD[(long)3 * nf + k];
+  const int li = blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x * 256 >= ns) return;
+  const bool live = li < ns;
+  const long pos = FD[(long)1 * nf + k] + (live ? li : ns - 1);
+  const long col = spx[pos];
+  const double *Ua = U + FD[k] * (long)Nz * PCA_CAP;
+  const int z0 = blockIdx.y * 16;
+  double acc[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0;
+  for (int q = 0; q < T; ++q) {
+    const double c = C[(long)q * ntot + pos];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int z = min(z0 + r, Nz - 1);
+      acc[r] = fma(Ua[(long)z * PCA_CAP + q], c, acc[r]);  // wave-uniform -> scalar loads
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int z = z0 + r;
+      if (z < Nz) {
+        const long idx = (long)z * S + col;
+        F[idx] = (float)((double)F[idx] - acc[r]);
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------
@@ -781,7 +882,9 @@ int origin_pca_run(origin_ctx *ctx, float *d_F, int Nz, long S, int na, const in
   if (ntot == 0) return ORIGIN_OK;
 
   // ---- persistent state on the device
-  DevBuf b_state, b_lists, b_test, b_desc, b_tiles, b_xp, b_g, b_cv, b_bu, b_part, b_cpart;
+  DevBuf b_state, b_lists, b_test, b_desc, b_tiles, b_xp, b_g, b_cv, b_bu, b_part, b_cpart, b_info;
+  DevBuf b_U, b_C, b_small, b_fd;
+  const bool debug = getenv("ORIGIN_PCA_DEBUG") != nullptr;
   const size_t st_bytes = (size_t)na * (sizeof(double) + 4 * sizeof(int)) + sizeof(int) * 2 +
                           (size_t)(na + 1) * sizeof(long) + 64;
   int rc;
@@ -809,12 +912,18 @@ int origin_pca_run(origin_ctx *ctx, float *d_F, int Nz, long S, int na, const in
   ORIGIN_HIP(hipMemsetAsync(d_nbiter, 0, (size_t)na * sizeof(int), st));
   ORIGIN_HIP(hipMemsetAsync(d_nstop, 0, sizeof(int), st));
   ORIGIN_HIP(hipStreamSynchronize(st));  // `ones` goes out of use
-  if ((rc = b_lists.reserve(ctx, (size_t)2 * ntot * sizeof(int)))) return rc;
+  if ((rc = b_lists.reserve(ctx, (size_t)4 * ntot * sizeof(int)))) return rc;
   int *d_nuis = (int *)b_lists.p, *d_bg = d_nuis + ntot;
+  int *d_nuis_pos = d_bg + ntot, *d_bg_pos = d_nuis_pos + ntot;
   if ((rc = b_test.reserve(ctx, (size_t)S * sizeof(double)))) return rc;
   double *d_test = (double *)b_test.p;
   ORIGIN_HIP(hipMemcpyAsync(d_test, d_test0, (size_t)S * sizeof(double), hipMemcpyDeviceToDevice,
                             st));
+  // removed vectors U[area][z][PCA_CAP] and coefficient rows C[PCA_CAP][list position]
+  if ((rc = b_U.reserve(ctx, (size_t)na * Nz * PCA_CAP * sizeof(double)))) return rc;
+  if ((rc = b_C.reserve(ctx, (size_t)PCA_CAP * ntot * sizeof(double)))) return rc;
+  double *d_U = (double *)b_U.p, *d_C = (double *)b_C.p;
+  std::vector<int> T(na, 0);  // vectors held per area since the last flush
 
   int *h_nnb = nullptr;  // pinned read-back buffer [2*na]
   ORIGIN_HIP(hipHostMalloc((void **)&h_nnb, (size_t)2 * na * sizeof(int), hipHostMallocDefault));
@@ -823,25 +932,60 @@ int origin_pca_run(origin_ctx *ctx, float *d_F, int Nz, long S, int na, const in
     ~Pinned() { (void)hipHostFree(p); }
   } pinned{h_nnb};
 
+  // F = X - U C for every area that holds vectors; afterwards T = 0 everywhere
+  auto flush = [&]() -> int {
+    std::vector<long> fd;
+    int nf = 0, nsmax = 0;
+    for (int a = 0; a < na; ++a) nf += T[a] > 0;
+    if (nf == 0) return ORIGIN_OK;
+    fd.assign((size_t)4 * nf, 0);
+    int k = 0;
+    for (int a = 0; a < na; ++a) {
+      if (T[a] == 0) continue;
+      const int ns = (int)(h_spx_off[a + 1] - h_spx_off[a]);
+      fd[k] = a;
+      fd[(size_t)nf + k] = h_spx_off[a];
+      fd[(size_t)2 * nf + k] = ns;
+      fd[(size_t)3 * nf + k] = T[a];
+      nsmax = std::max(nsmax, ns);
+      T[a] = 0;
+      ++k;
+    }
+    int r;
+    if ((r = b_fd.reserve(ctx, fd.size() * sizeof(long)))) return r;
+    ORIGIN_HIP(hipMemcpyAsync(b_fd.p, fd.data(), fd.size() * sizeof(long), hipMemcpyHostToDevice,
+                              st));
+    ORIGIN_HIP(hipStreamSynchronize(st));
+    ProfScope ps(ctx, K_PCA_FLUSH);
+    hipLaunchKernelGGL(flush_kernel, dim3(cdiv(nsmax, 256), cdiv(Nz, 16), nf), dim3(256), 0, st,
+                       d_F, Nz, S, d_spx, (const long *)b_fd.p, nf, d_U, d_C, ntot);
+    ORIGIN_LAUNCH_CHECK();
+    return ORIGIN_OK;
+  };
+
   std::vector<long> D;
-  std::vector<int> tiles;
   int iters = 0;
   for (;;) {
     {
       ProfScope ps(ctx, K_PCA_SELECT);
       hipLaunchKernelGGL(pca_select_kernel, dim3(na), dim3(1024), 0, st, d_spx, d_spx_off, d_test,
                          d_thr, noise_pop, itermax, d_active, d_nbiter, d_nstop, d_mapO2, d_nuis,
-                         d_bg, d_n, d_nb);
+                         d_bg, d_nuis_pos, d_bg_pos, d_n, d_nb);
     }
     ORIGIN_LAUNCH_CHECK();
     ORIGIN_HIP(hipMemcpyAsync(h_nnb, d_n, (size_t)2 * na * sizeof(int), hipMemcpyDeviceToHost, st));
     ORIGIN_HIP(hipStreamSynchronize(st));
     // ---- work list of this iteration
     int nw = 0;
-    for (int a = 0; a < na; ++a) nw += h_nnb[a] >= 2;
+    bool full = false;
+    for (int a = 0; a < na; ++a)
+      if (h_nnb[a] >= 2) {
+        ++nw;
+        full = full || T[a] >= PCA_CAP;
+      }
     if (nw == 0) break;
+    if (full && (rc = flush())) return rc;  // an area used up its PCA_CAP slots
     D.assign((size_t)DF_COUNT * nw, 0);
-    tiles.clear();
     long xp = 0, c = 0, g = 0, q = 0, cb = 0;
     int ldmax = 0, nsmax = 0, k = 0;
     std::vector<int> ti, tj, ta;
@@ -862,6 +1006,7 @@ int origin_pca_run(origin_ctx *ctx, float *d_F, int Nz, long S, int na, const in
       D[(size_t)DF_Q * nw + k] = q;
       D[(size_t)DF_NS * nw + k] = ns;
       D[(size_t)DF_CBASE * nw + k] = cb;
+      D[(size_t)DF_T * nw + k] = T[a];
       xp += (long)Nz * ld;
       c += ld;
       g += (long)ld * ld;
@@ -870,9 +1015,9 @@ int origin_pca_run(origin_ctx *ctx, float *d_F, int Nz, long S, int na, const in
       ldmax = std::max(ldmax, ld);
       nsmax = std::max(nsmax, ns);
       nsum += n;
-      const int T = (ld + 31) / 32;
-      for (int i = 0; i < T; ++i)
-        for (int j = i; j < T; ++j) ti.push_back(i), tj.push_back(j), ta.push_back(k);
+      const int Tt = (ld + 31) / 32;
+      for (int i = 0; i < Tt; ++i)
+        for (int j = i; j < Tt; ++j) ti.push_back(i), tj.push_back(j), ta.push_back(k);
       ++k;
     }
     if (h_trace && iters < trace_cap) {
@@ -891,19 +1036,23 @@ int origin_pca_run(origin_ctx *ctx, float *d_F, int Nz, long S, int na, const in
     ORIGIN_HIP(hipStreamSynchronize(st));  // pageable sources are reused next iteration
     if ((rc = b_xp.reserve(ctx, (size_t)xp * sizeof(double)))) return rc;
     if ((rc = b_g.reserve(ctx, (size_t)g * sizeof(double)))) return rc;
-    if ((rc = b_cv.reserve(ctx, (size_t)2 * c * sizeof(double)))) return rc;
+    if ((rc = b_cv.reserve(ctx, (size_t)c * sizeof(double)))) return rc;
     if ((rc = b_bu.reserve(ctx, (size_t)2 * nw * Nz * sizeof(double)))) return rc;
+    if ((rc = b_small.reserve(ctx, (size_t)2 * nw * PCA_CAP * sizeof(double)))) return rc;
     double *d_Xp = (double *)b_xp.p, *d_G = (double *)b_g.p;
-    double *d_c = (double *)b_cv.p, *d_v = d_c + c;
+    double *d_v = (double *)b_cv.p;
     double *d_b = (double *)b_bu.p, *d_u = d_b + (size_t)nw * Nz;
+    double *d_cbar = (double *)b_small.p, *d_wq = d_cbar + (size_t)nw * PCA_CAP;
     const long *dLD = dD + (size_t)DF_LD * nw, *dXP = dD + (size_t)DF_XP * nw;
     const long *dG = dD + (size_t)DF_G * nw, *dQ = dD + (size_t)DF_Q * nw;
     const long *dN = dD + (size_t)DF_N * nw, *dC = dD + (size_t)DF_C * nw;
 
     {
       ProfScope ps(ctx, K_PCA_BMEAN);
+      hipLaunchKernelGGL(cbar_kernel, dim3(nw), dim3(1024), 0, st, d_C, ntot, d_bg_pos, dD, nw,
+                         d_cbar);
       hipLaunchKernelGGL(bmean_kernel, dim3(cdiv(Nz, 4), nw), dim3(64, 4), 0, st, d_F, Nz, S, d_bg,
-                         dD, nw, d_b);
+                         dD, nw, d_U, d_cbar, d_b);
     }
     // z slices of the gather: enough blocks to fill the chip even when few areas iterate
     int nzb = (int)(((long)ctx->num_cu * 2 + (long)cdiv(ldmax, 64) * nw - 1) /
@@ -916,7 +1065,8 @@ int origin_pca_run(origin_ctx *ctx, float *d_F, int Nz, long S, int na, const in
     {
       ProfScope ps(ctx, K_PCA_GATHER);
       hipLaunchKernelGGL(gather_xp_kernel, dim3(cdiv(ldmax, 64), nw, nzb), dim3(64, 16), 0, st,
-                         d_F, Nz, S, d_nuis, dD, nw, d_b, d_Xp, d_cpart, c, gzper);
+                         d_F, Nz, S, d_nuis, d_nuis_pos, dD, nw, d_b, d_U, d_C, ntot, d_Xp, d_cpart,
+                         c, gzper);
     }
     {
       ProfScope ps(ctx, K_PCA_PROJECT);
@@ -929,18 +1079,41 @@ int origin_pca_run(origin_ctx *ctx, float *d_F, int Nz, long S, int na, const in
       void *scr = nullptr;
       if ((rc = b_part.reserve(ctx, (size_t)q * sizeof(double)))) return rc;
       scr = b_part.p;
-      ProfScope ps(ctx, K_PCA_EIG);
-      hipLaunchKernelGGL(lanczos_kernel, dim3(nw), dim3(1024), 0, st, d_G, dG, dLD, dN,
-                         (double *)scr, dQ, d_v, dC, 60, 1e-14, (double *)nullptr);
+      double *d_info = nullptr;
+      if (debug) {
+        if ((rc = b_info.reserve(ctx, (size_t)3 * nw * sizeof(double)))) return rc;
+        d_info = (double *)b_info.p;
+      }
+      {
+        ProfScope ps(ctx, K_PCA_EIG);
+        hipLaunchKernelGGL(lanczos_kernel, dim3(nw), dim3(1024), 0, st, d_G, dG, dLD, dN,
+                           (double *)scr, dQ, d_v, dC, 60, 1e-14, d_info);
+      }
+      if (debug) {
+        std::vector<double> info((size_t)3 * nw);
+        ORIGIN_HIP(hipMemcpyAsync(info.data(), d_info, info.size() * sizeof(double),
+                                  hipMemcpyDeviceToHost, st));
+        ORIGIN_HIP(hipStreamSynchronize(st));
+        double rmax = 0, rsum = 0, resmax = 0;
+        int nmax = 0;
+        for (int w = 0; w < nw; ++w) {
+          rmax = std::max(rmax, info[3 * w + 2]);
+          rsum += info[3 * w + 2];
+          resmax = std::max(resmax, info[3 * w + 1] / std::max(info[3 * w], 1e-300));
+          nmax = std::max(nmax, (int)D[(size_t)DF_N * nw + w]);
+        }
+        fprintf(stderr, "[pca] iter %3d areas %3d nmax %4d restarts max %2.0f mean %.2f relres max %.1e\n",
+                iters, nw, nmax, rmax, rsum / nw, resmax);
+      }
     }
     {
       ProfScope ps(ctx, K_PCA_UVEC);
       hipLaunchKernelGGL(xv_kernel, dim3(cdiv(Nz, 4), nw), dim3(64, 4), 0, st, d_Xp, dD, nw, Nz,
                          d_v, d_u);
-      hipLaunchKernelGGL(normalize_kernel, dim3(nw), dim3(1024), 0, st, d_u, Nz);
+      hipLaunchKernelGGL(normalize_kernel, dim3(nw), dim3(1024), 0, st, d_u, Nz, dD, nw, d_U, d_wq);
     }
     ORIGIN_LAUNCH_CHECK();
-    // ---- deflation
+    // ---- deflation (coefficient form): one read pass over the iterating areas
     const long blocks = (long)cdiv(nsmax, 256) * nw;
     int nzs = (int)(((long)ctx->num_cu * 8 + blocks - 1) / blocks);
     nzs = std::max(1, std::min(nzs, 32));
@@ -948,27 +1121,23 @@ int origin_pca_run(origin_ctx *ctx, float *d_F, int Nz, long S, int na, const in
     const int zper = cdiv(Nz, nzs);
     nzs = cdiv(Nz, zper);
     void *scr = nullptr;
-    if ((rc = origin_scratch(ctx, (size_t)2 * nzs * cb * sizeof(double), &scr))) return rc;
-    double *cpart = (double *)scr, *o2part = cpart + (size_t)nzs * cb;
-    dim3 grid(cdiv(nsmax, 256), nzs, nw);
+    if ((rc = origin_scratch(ctx, (size_t)nzs * cb * sizeof(double), &scr))) return rc;
+    double *cpart = (double *)scr;
     {
       ProfScope ps(ctx, K_PCA_DEFLATE_DOT);
-      hipLaunchKernelGGL(deflate_dot_kernel, grid, dim3(256), 0, st, d_F, Nz, S, d_spx, dD, nw, d_u,
-                         zper, cpart, cb);
+      hipLaunchKernelGGL(deflate_dot_kernel, dim3(cdiv(nsmax, 256), nzs, nw), dim3(256), 0, st, d_F,
+                         Nz, S, d_spx, dD, nw, d_u, zper, cpart, cb);
     }
     {
       ProfScope ps(ctx, K_PCA_DEFLATE_UPDATE);
-      hipLaunchKernelGGL(deflate_update_kernel, grid, dim3(256), 0, st, d_F, Nz, S, d_spx, dD, nw,
-                         d_u, zper, nzs, cpart, o2part, cb);
-    }
-    {
-      ProfScope ps(ctx, K_SMALL);
-      hipLaunchKernelGGL(deflate_final_kernel, dim3(cdiv(nsmax, 256), nw), dim3(256), 0, st, d_spx,
-                         dD, nw, nzs, Nz, cb, o2part, d_test);
+      hipLaunchKernelGGL(deflate_finish_kernel, dim3(cdiv(nsmax, 256), nw), dim3(256), 0, st, d_spx,
+                         dD, nw, nzs, Nz, cb, cpart, d_wq, d_C, ntot, d_test);
     }
     ORIGIN_LAUNCH_CHECK();
+    for (int w = 0; w < nw; ++w) T[(int)D[(size_t)DF_AREA * nw + w]] += 1;
     ++iters;
   }
+  if ((rc = flush())) return rc;
   ORIGIN_HIP(hipMemcpyAsync(h_nnb, d_nstop, sizeof(int), hipMemcpyDeviceToHost, st));
   ORIGIN_HIP(hipStreamSynchronize(st));
   *h_nstop = h_nnb[0];

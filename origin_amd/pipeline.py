@@ -7,6 +7,9 @@ Cubes stay in HBM between stages (``DeviceArray``); only per-spaxel maps, thresh
 what a caller asks for cross PCIe.  ``origin_amd.steps`` wraps these behind the reference's
 Step API, ``bench.py`` times them directly.
 """
+import concurrent.futures as _futures
+import os
+
 import numpy as np
 
 from . import kernels
@@ -46,10 +49,18 @@ def pca_threshold(o2_map, areamap, nbAreas, pfa_test=0.01, spx=None):
     """``ComputePCAThreshold.run`` (steps.py:610-631) on the O2 map of cube_std."""
     spx = area_lists(areamap, nbAreas) if spx is None else spx
     flat = np.asarray(o2_map, dtype=np.float64).reshape(-1)
-    results = []
-    for s in spx:
+
+    def one(s):
         test = flat[s]
-        results.append((test,) + tuple(compute_thresh_gaussfit(test, pfa_test)))
+        return (test,) + tuple(compute_thresh_gaussfit(test, pfa_test))
+
+    # the fits are independent per area and spend their time in NumPy/SciPy calls that
+    # release the GIL: a small thread pool keeps this host step off the critical path
+    if len(spx) >= 4:
+        with _futures.ThreadPoolExecutor(max_workers=min(16, len(spx), os.cpu_count() or 1)) as ex:
+            results = list(ex.map(one, spx))
+    else:
+        results = [one(s) for s in spx]
     testO2, histO2, binO2, thresO2, meaO2, stdO2 = zip(*results)
     return dict(testO2=testO2, histO2=histO2, binO2=binO2, thresO2=thresO2, meaO2=meaO2,
                 stdO2=stdO2)

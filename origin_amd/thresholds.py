@@ -8,7 +8,8 @@ muse_origin/lib_origin.py:977-1024, with astropy's ``sigma_clip`` / ``LevMarLSQF
 ``Gaussian1D`` restated on NumPy/SciPy (astropy is not needed at run time).
 """
 import numpy as np
-from scipy import optimize, stats
+from scipy import optimize
+from scipy.special import ndtri
 
 _SIGMA_TO_FWHM = 2.0 * np.sqrt(2.0 * np.log(2.0))
 
@@ -64,7 +65,7 @@ def compute_thresh_gaussfit(data, pfa, bins='fd', sigclip=10):
     ind2 = np.argmin((histO2[ind] / 2 - histO2[:ind]) ** 2)
     fwhm = mod - frecO2[ind2]
     sigma = fwhm / np.sqrt(2 * np.log(2))
-    coef = stats.norm.ppf(pfa)
+    coef = ndtri(pfa)  # == scipy.stats.norm.ppf(pfa) without the distribution machinery
     x = (frecO2[1:] + frecO2[:-1]) / 2
     xcut = mod + _SIGMA_TO_FWHM * sigma / 2
     ksel = x < xcut

@@ -1,0 +1,67 @@
+"""CPU: host-side pieces of the product (no GPU needed): the threshold fit that stays on the
+host by design, profile preparation, area lists, synthetic inputs."""
+import os
+
+import numpy as np
+
+from oracle import cpu_ref
+from oracle import golden_cases as gc
+from origin_amd import kernels, pipeline, synth, thresholds
+
+
+def test_threshold_fit_matches_reference_goldens():
+    g = np.load(os.path.join(gc.GOLDEN_DIR, "g3_thresh.npz"))
+    for name in "abc":
+        t = g["in_" + name]
+        for pfa in (0.01, 0.2):
+            key = f"{name}_{str(pfa).replace('.', 'p')}"
+            h, e, thr, mea, std = thresholds.compute_thresh_gaussfit(t, pfa)
+            np.testing.assert_allclose([thr, mea, std], g[key + "_res"], rtol=1e-10)
+            np.testing.assert_allclose(h, g[key + "_hist"], rtol=1e-12)
+            np.testing.assert_allclose(e, g[key + "_edges"], rtol=1e-12)
+            assert isinstance(thr, float)
+
+
+def test_prepare_profiles_matches_oracle():
+    for pcut, sub in ((1e-8, True), (None, True), (1e-3, False)):
+        a = kernels.prepare_profiles(synth.dico_fwhm(20), pcut, sub)
+        b = cpu_ref.prepare_profiles(synth.dico_fwhm(20), pcut, sub)
+        assert [len(x) for x in a] == [len(x) for x in b]
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
+    taps = [len(p) for p in kernels.prepare_profiles(synth.dico_fwhm(20), 1e-8)]
+    assert sum(taps) == 704 and taps[0] == 11 and taps[-1] == 59
+
+
+def test_area_lists_follow_boolean_mask_order():
+    rng = np.random.default_rng(0)
+    areamap = rng.integers(0, 5, (13, 17))
+    lists = pipeline.area_lists(areamap, 4)
+    cube = rng.standard_normal((3, 13, 17))
+    for i, s in enumerate(lists, start=1):
+        np.testing.assert_array_equal(cube.reshape(3, -1)[:, s], cube[:, areamap == i])
+
+
+def test_pca_threshold_threaded_equals_serial():
+    rng = np.random.default_rng(1)
+    o2 = (rng.standard_normal((200, 60 * 60)) ** 2).mean(0).reshape(60, 60)
+    areamap, nb = synth.grid_areamap(60, 60, 20)
+    res = pipeline.pca_threshold(o2, areamap, nb, 0.01)
+    for i in range(nb):
+        ref = cpu_ref.compute_thresh_gaussfit(o2[areamap == i + 1], 0.01)
+        assert res["thresO2"][i] == ref[2]
+        np.testing.assert_array_equal(res["testO2"][i], o2[areamap == i + 1])
+
+
+def test_synthetic_field_is_deterministic_and_windowed():
+    f = synth.SyntheticField(70, 20, 24, seed=9, psf_size=7, nprof=3)
+    a = f.chunk(1)
+    b = synth.SyntheticField(70, 20, 24, seed=9, psf_size=7, nprof=3).chunk(1)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+    w = f.chunk(1, window=(4, 15, 6, 20))
+    np.testing.assert_array_equal(w[0], a[0][:, 4:15, 6:20])
+    np.testing.assert_array_equal(w[1], a[1][:, 4:15, 6:20])
+    assert a[0].dtype == np.float32 and a[2].dtype == np.uint8
+    psf = synth.moffat_psf(10, 25)
+    np.testing.assert_allclose(psf.sum(axis=(1, 2)), 1, rtol=1e-6)
