@@ -41,10 +41,28 @@ namespace {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
+// Sum of a double over the 64 lanes of a wave, returned in every lane.  Within each row of
+// 16 lanes the exchange uses DPP moves (quad_perm / row_ror: a few cycles each) instead of
+// ds_bpermute; the four row sums are then combined through v_readlane.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_d(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double wave_sum_d(double v) {
+  v += dpp_mov_d<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov_d<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov_d<0x124>(v);  // row_ror:4
+  v += dpp_mov_d<0x128>(v);  // row_ror:8  -> every lane holds the sum of its row of 16
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  double t = 0.0;
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  for (int r = 0; r < 4; ++r)
+    t += __hiloint2double(__builtin_amdgcn_readlane(hi, 16 * r),
+                          __builtin_amdgcn_readlane(lo, 16 * r));
+  return t;
 }
 
 // descriptor fields of the per-iteration work list (int64 [DF_COUNT][nw])
@@ -86,11 +104,12 @@ __global__ __launch_bounds__(1024) void pca_select_kernel(
     const double *__restrict__ thr_, double noise_pop, int itermax, int *__restrict__ active,
     int *__restrict__ nbiter, int *__restrict__ nstop, int *__restrict__ mapO2,
     int *__restrict__ nuis, int *__restrict__ bg, int *__restrict__ nuis_pos,
-    int *__restrict__ bg_pos, int *__restrict__ n_out, int *__restrict__ nb_out) {
+    int *__restrict__ bg_pos, int *__restrict__ n_out, int *__restrict__ nb_out, int lds_cap) {
   __shared__ int wtot[16];
   __shared__ int hist[256];
   __shared__ unsigned long long s_prefix;
   __shared__ int s_remaining, s_ncand;
+  extern __shared__ double tcache[];  // the area's O2 values (when they fit: lds_cap > 0)
   const int a = blockIdx.x;
   const int tid = threadIdx.x;
   const long o0 = spx_off[a];
@@ -101,15 +120,22 @@ __global__ __launch_bounds__(1024) void pca_select_kernel(
   }
   const double thr = thr_[a];
   BlockScan scan{wtot};
+  // the selection makes ~11 passes over the area's O2 values: keep them in LDS
+  const bool cached = ns <= lds_cap;
+  if (cached) {
+    for (int i = tid; i < ns; i += 1024) tcache[i] = test[spx[o0 + i]];
+    __syncthreads();
+  }
+  auto tval = [&](int i) -> double { return cached ? tcache[i] : test[spx[o0 + i]]; };
 
   // ---- pass 1: nuisance compaction in index order (np.where(test > thr)), candidates count
   int n = 0, ncand = 0;
   for (int c0 = 0; c0 < ns; c0 += 1024) {
     const int i = c0 + tid;
     const bool valid = i < ns;
-    const int sp = valid ? spx[o0 + i] : 0;
-    const double t = valid ? test[sp] : 0.0;
+    const double t = valid ? tval(i) : 0.0;
     const bool isn = valid && (t > thr);
+    const int sp = isn ? spx[o0 + i] : 0;
     const bool cand = valid && (t > 0.0) && (t <= thr);
     int tot;
     const int r = scan.exclusive(isn, tot);
@@ -157,21 +183,37 @@ __global__ __launch_bounds__(1024) void pca_select_kernel(
       __syncthreads();
       const unsigned long long prefix = s_prefix;
       for (int i = tid; i < ns; i += 1024) {
-        const double t = test[spx[o0 + i]];
+        const double t = tval(i);
         if ((t > 0.0) && (t <= thr)) {
           const unsigned long long key = (unsigned long long)__double_as_longlong(t);
           if ((key & maskbits) == prefix) atomicAdd(&hist[(int)((key >> shift) & 255ull)], 1);
         }
       }
       __syncthreads();
-      if (tid == 0) {
-        int rem = s_remaining, b = 0;
-        for (; b < 256; ++b) {
-          if (rem < hist[b]) break;
-          rem -= hist[b];
+      if (tid < 64) {  // wave 0: bucket holding rank `remaining` via a 64-lane prefix scan
+        const int rem0 = s_remaining;
+        const int h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2],
+                  h3 = hist[4 * tid + 3];
+        const int mine = h0 + h1 + h2 + h3;
+        int incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const int v = __shfl_up(incl, off, 64);
+          if ((int)tid >= off) incl += v;
         }
-        s_remaining = rem;
-        s_prefix = prefix | ((unsigned long long)b << shift);
+        const int excl = incl - mine;
+        if (rem0 >= excl && rem0 < incl) {  // exactly one lane
+          int rem = rem0 - excl, b = 4 * tid;
+          if (rem >= h0) {
+            rem -= h0, ++b;
+            if (rem >= h1) {
+              rem -= h1, ++b;
+              if (rem >= h2) rem -= h2, ++b;
+            }
+          }
+          s_remaining = rem;
+          s_prefix = prefix | ((unsigned long long)b << shift);
+        }
       }
       maskbits |= 255ull << shift;
       __syncthreads();
@@ -185,7 +227,7 @@ __global__ __launch_bounds__(1024) void pca_select_kernel(
     for (int c0 = 0; c0 < ns; c0 += 1024) {
       const int i = c0 + tid;
       const bool valid = i < ns;
-      const double t = valid ? test[spx[o0 + i]] : 0.0;
+      const double t = valid ? tval(i) : 0.0;
       const bool pos = valid && (t > 0.0);
       const bool cand = pos && (t <= thr);
       const unsigned long long key = (unsigned long long)__double_as_longlong(t);
@@ -457,6 +499,7 @@ __global__ __launch_bounds__(1024) void lanczos_kernel(const double *__restrict_
   __shared__ double alpha[LANCZOS_M], beta[LANCZOS_M], svec[LANCZOS_M], h[LANCZOS_M + 1];
   __shared__ double x[LANCZOS_M], d[LANCZOS_M], du[LANCZOS_M], du2[LANCZOS_M], dl[LANCZOS_M];
   __shared__ double red[16];
+  __shared__ double upd[4][256];
   __shared__ double s_theta, s_lo, s_hi;
   __shared__ int s_m;
   const int k = blockIdx.x;
@@ -493,33 +536,55 @@ __global__ __launch_bounds__(1024) void lanczos_kernel(const double *__restrict_
     for (int j = 0; j < mmax; ++j) {
       const double *qj = Qk + (long)j * ld;
       double *w = Qk + (long)(j + 1) * ld;
-      // w = G q_j   (rows over waves, columns over lanes: coalesced, G symmetric)
-      for (int r = wave; r < n; r += 16) {
-        const double *row = Gk + (long)r * ld;
-        double acc = 0.0;
-        for (int c = lane; c < n; c += 64) acc = fma(row[c], qj[c], acc);
-        acc = wave_sum_d(acc);
-        if (lane == 0) w[r] = acc;
+      // w = G q_j.  G is symmetric: thread r accumulates sum_c G[c][r] q_j[c], so that lanes
+      // read consecutive addresses and no cross-lane reduction is needed; the columns are
+      // split over 4 groups of 256 threads and combined through LDS.
+      {
+        const int part = tid >> 8, r0 = tid & 255;
+        for (int rb = 0; rb < n; rb += 256) {
+          const int r = rb + r0;
+          double acc = 0.0;
+          if (r < n) {
+#pragma unroll 4
+            for (int c = part; c < n; c += 4) acc = fma(Gk[(long)c * ld + r], qj[c], acc);
+          }
+          upd[part][r0] = acc;
+          __syncthreads();
+          if (part == 0 && r < n) w[r] = (upd[0][r0] + upd[1][r0]) + (upd[2][r0] + upd[3][r0]);
+          __syncthreads();
+        }
       }
-      __syncthreads();
       // classical Gram-Schmidt against q_0..q_j, twice; alpha_j = first-pass h_j (+ fix)
       double aj = 0.0;
       for (int pass = 0; pass < 2; ++pass) {
         for (int i = wave; i <= j; i += 16) {
           const double *qi = Qk + (long)i * ld;
           double acc = 0.0;
+#pragma unroll 4
           for (int c = lane; c < n; c += 64) acc = fma(qi[c], w[c], acc);
           acc = wave_sum_d(acc);
           if (lane == 0) h[i] = acc;
         }
         __syncthreads();
         aj += h[j];
-        for (int e = tid; e < n; e += 1024) {
-          double we = w[e];
-          for (int i = 0; i <= j; ++i) we = fma(-h[i], Qk[(long)i * ld + e], we);
-          w[e] = we;
+        // w -= Q h with the j+1 rows split over 4 thread groups (independent loads in
+        // flight instead of one dependent chain per element), combined through LDS
+        {
+          const int part = tid >> 8, e0 = tid & 255;
+          for (int eb = 0; eb < n; eb += 256) {
+            const int e = eb + e0;
+            double acc = 0.0;
+            if (e < n) {
+#pragma unroll 4
+              for (int i = part; i <= j; i += 4) acc = fma(h[i], Qk[(long)i * ld + e], acc);
+            }
+            upd[part][e0] = acc;
+            __syncthreads();
+            if (part == 0 && e < n)
+              w[e] -= (upd[0][e0] + upd[1][e0]) + (upd[2][e0] + upd[3][e0]);
+            __syncthreads();
+          }
         }
-        __syncthreads();
       }
       double pw = 0.0;
       for (int e = tid; e < n; e += 1024) pw = fma(w[e], w[e], pw);
@@ -612,6 +677,7 @@ __global__ __launch_bounds__(1024) void lanczos_kernel(const double *__restrict_
     // y = Q s
     for (int e = tid; e < n; e += 1024) {
       double acc = 0.0;
+#pragma unroll 8
       for (int i = 0; i < m; ++i) acc = fma(svec[i], Qk[(long)i * ld + e], acc);
       y[e] = acc;
     }
@@ -963,14 +1029,36 @@ int origin_pca_run(origin_ctx *ctx, float *d_F, int Nz, long S, int na, const in
     return ORIGIN_OK;
   };
 
+  // LDS cache of the select kernel: the largest area, if it fits in 120 KiB
+  int nsmax_all = 0;
+  for (int a = 0; a < na; ++a) nsmax_all = std::max(nsmax_all, (int)(h_spx_off[a + 1] - h_spx_off[a]));
+  int sel_cap = nsmax_all <= 15360 ? nsmax_all : 0;
+  size_t sel_lds = (size_t)sel_cap * sizeof(double);
+  if (sel_lds > 48 * 1024 &&
+      hipFuncSetAttribute((const void *)pca_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)sel_lds) != hipSuccess) {
+    (void)hipGetLastError();
+    sel_cap = 0;
+    sel_lds = 0;
+  }
+
+  // pinned staging for the per-iteration descriptors (async upload, no extra sync)
+  long *h_desc = nullptr;
+  const size_t desc_cap = (size_t)DF_COUNT * na * sizeof(long);
+  ORIGIN_HIP(hipHostMalloc((void **)&h_desc, desc_cap, hipHostMallocDefault));
+  struct PinnedL {
+    long *p;
+    ~PinnedL() { (void)hipHostFree(p); }
+  } pinned_desc{h_desc};
+
   std::vector<long> D;
   int iters = 0;
   for (;;) {
     {
       ProfScope ps(ctx, K_PCA_SELECT);
-      hipLaunchKernelGGL(pca_select_kernel, dim3(na), dim3(1024), 0, st, d_spx, d_spx_off, d_test,
-                         d_thr, noise_pop, itermax, d_active, d_nbiter, d_nstop, d_mapO2, d_nuis,
-                         d_bg, d_nuis_pos, d_bg_pos, d_n, d_nb);
+      hipLaunchKernelGGL(pca_select_kernel, dim3(na), dim3(1024), sel_lds, st, d_spx, d_spx_off,
+                         d_test, d_thr, noise_pop, itermax, d_active, d_nbiter, d_nstop, d_mapO2,
+                         d_nuis, d_bg, d_nuis_pos, d_bg_pos, d_n, d_nb, sel_cap);
     }
     ORIGIN_LAUNCH_CHECK();
     ORIGIN_HIP(hipMemcpyAsync(h_nnb, d_n, (size_t)2 * na * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1029,7 +1117,8 @@ int origin_pca_run(origin_ctx *ctx, float *d_F, int Nz, long S, int na, const in
     if ((rc = b_tiles.reserve(ctx, (size_t)3 * ntiles * sizeof(int)))) return rc;
     long *dD = (long *)b_desc.p;
     int *d_ti = (int *)b_tiles.p, *d_tj = d_ti + ntiles, *d_ta = d_tj + ntiles;
-    ORIGIN_HIP(hipMemcpyAsync(dD, D.data(), D.size() * sizeof(long), hipMemcpyHostToDevice, st));
+    memcpy(h_desc, D.data(), D.size() * sizeof(long));  // free again: last sync was after select
+    ORIGIN_HIP(hipMemcpyAsync(dD, h_desc, D.size() * sizeof(long), hipMemcpyHostToDevice, st));
     ORIGIN_HIP(hipMemcpyAsync(d_ti, ti.data(), (size_t)ntiles * sizeof(int), hipMemcpyHostToDevice, st));
     ORIGIN_HIP(hipMemcpyAsync(d_tj, tj.data(), (size_t)ntiles * sizeof(int), hipMemcpyHostToDevice, st));
     ORIGIN_HIP(hipMemcpyAsync(d_ta, ta.data(), (size_t)ntiles * sizeof(int), hipMemcpyHostToDevice, st));

@@ -7,9 +7,6 @@ Cubes stay in HBM between stages (``DeviceArray``); only per-spaxel maps, thresh
 what a caller asks for cross PCIe.  ``origin_amd.steps`` wraps these behind the reference's
 Step API, ``bench.py`` times them directly.
 """
-import concurrent.futures as _futures
-import os
-
 import numpy as np
 
 from . import kernels
@@ -54,13 +51,9 @@ def pca_threshold(o2_map, areamap, nbAreas, pfa_test=0.01, spx=None):
         test = flat[s]
         return (test,) + tuple(compute_thresh_gaussfit(test, pfa_test))
 
-    # the fits are independent per area and spend their time in NumPy/SciPy calls that
-    # release the GIL: a small thread pool keeps this host step off the critical path
-    if len(spx) >= 4:
-        with _futures.ThreadPoolExecutor(max_workers=min(16, len(spx), os.cpu_count() or 1)) as ex:
-            results = list(ex.map(one, spx))
-    else:
-        results = [one(s) for s in spx]
+    # (a thread pool was measured slower than the serial loop on the 256-thread GPU host:
+    # the fit is dominated by short NumPy calls holding the GIL)
+    results = [one(s) for s in spx]
     testO2, histO2, binO2, thresO2, meaO2, stdO2 = zip(*results)
     return dict(testO2=testO2, histO2=histO2, binO2=binO2, thresO2=thresO2, meaO2=meaO2,
                 stdO2=stdO2)

@@ -42,7 +42,7 @@ def test_area_lists_follow_boolean_mask_order():
         np.testing.assert_array_equal(cube.reshape(3, -1)[:, s], cube[:, areamap == i])
 
 
-def test_pca_threshold_threaded_equals_serial():
+def test_pca_threshold_per_area_equals_oracle():
     rng = np.random.default_rng(1)
     o2 = (rng.standard_normal((200, 60 * 60)) ** 2).mean(0).reshape(60, 60)
     areamap, nb = synth.grid_areamap(60, 60, 20)
