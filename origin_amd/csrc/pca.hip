@@ -486,6 +486,144 @@ __device__ __forceinline__ int sturm_count(const double *alpha, const double *be
   return cnt;
 }
 
+// Largest eigenpair of the symmetric tridiagonal T (alpha[0..m), beta[0..m-1)), executed by
+// ONE wave: 64-way multisection on Sturm counts for the eigenvalue, then inverse iteration with
+// partial pivoting (lane 0) for the unit eigenvector, left in ws.x.  Returns the eigenvalue.
+struct TriWork {
+  double x[LANCZOS_M], d[LANCZOS_M], du[LANCZOS_M], du2[LANCZOS_M], dl[LANCZOS_M];
+};
+
+__device__ __forceinline__ double tridiag_top(const double *alpha, const double *beta, int m,
+                                              int lane, TriWork &ws) {
+  double lo = 1e300, hi = -1e300, tn = 0.0;
+  for (int i = 0; i < m; ++i) {
+    const double r = (i > 0 ? fabs(beta[i - 1]) : 0.0) + (i < m - 1 ? fabs(beta[i]) : 0.0);
+    lo = fmin(lo, alpha[i] - r);
+    hi = fmax(hi, alpha[i] + r);
+    tn = fmax(tn, fabs(alpha[i]) + r);
+  }
+  const double pivmin = fmax(tn * tn, 1.0) * 1e-300 + 1e-290;
+  hi += 1e-14 * tn + 1e-300;
+  for (int it = 0; it < 12; ++it) {
+    // lane l tests x_l = lo + (l+1) (hi-lo)/65 ; count(x) == m  <=>  x > theta_max
+    const double x = lo + (hi - lo) * (double)(lane + 1) / 65.0;
+    const bool above = sturm_count(alpha, beta, m, x, pivmin) >= m;
+    const unsigned long long bal = __ballot(above);
+    const int first = bal ? __ffsll((long long)bal) - 1 : 64;  // first lane above
+    const double nlo = first == 0 ? lo : lo + (hi - lo) * (double)first / 65.0;
+    const double nhi = first == 64 ? hi : lo + (hi - lo) * (double)(first + 1) / 65.0;
+    lo = nlo;
+    hi = nhi;
+  }
+  const double theta = 0.5 * (lo + hi);
+  if (lane == 0) {
+    double *x = ws.x, *d = ws.d, *du = ws.du, *du2 = ws.du2, *dl = ws.dl;
+    const int mm = m;
+    double tnorm = 0.0;
+    for (int i = 0; i < mm; ++i)
+      tnorm = fmax(tnorm, fabs(alpha[i]) + (i < mm - 1 ? fabs(beta[i]) : 0.0));
+    const double sigma = theta + 4e-16 * tnorm;
+    for (int i = 0; i < mm; ++i) x[i] = 1.0 / sqrt((double)mm);
+    for (int iter = 0; iter < 2; ++iter) {
+      for (int i = 0; i < mm; ++i) {
+        d[i] = alpha[i] - sigma;
+        du[i] = i < mm - 1 ? beta[i] : 0.0;
+        dl[i] = du[i];
+        du2[i] = 0.0;
+      }
+      // LU with partial pivoting (dgtsv), solving in place
+      for (int i = 0; i < mm - 1; ++i) {
+        if (fabs(d[i]) >= fabs(dl[i])) {
+          if (d[i] == 0.0) d[i] = 1e-300;
+          const double f = dl[i] / d[i];
+          d[i + 1] -= f * du[i];
+          x[i + 1] -= f * x[i];
+          dl[i] = 0.0;
+        } else {
+          const double f = d[i] / dl[i];
+          d[i] = dl[i];
+          const double t = d[i + 1];
+          d[i + 1] = du[i] - f * t;
+          du2[i] = (i < mm - 2) ? du[i + 1] : 0.0;
+          if (i < mm - 2) du[i + 1] = -f * du2[i];
+          du[i] = t;
+          const double tx = x[i];
+          x[i] = x[i + 1];
+          x[i + 1] = tx - f * x[i + 1];
+        }
+      }
+      if (d[mm - 1] == 0.0) d[mm - 1] = 1e-300;
+      x[mm - 1] /= d[mm - 1];
+      if (mm > 1) x[mm - 2] = (x[mm - 2] - du[mm - 2] * x[mm - 1]) / d[mm - 2];
+      for (int i = mm - 3; i >= 0; --i)
+        x[i] = (x[i] - du[i] * x[i + 1] - du2[i] * x[i + 2]) / d[i];
+      double nx = 0.0;
+      for (int i = 0; i < mm; ++i) nx += x[i] * x[i];
+      nx = 1.0 / sqrt(nx);
+      for (int i = 0; i < mm; ++i) x[i] *= nx;
+    }
+  }
+  return theta;
+}
+
+// Small matrices (n <= LANCZOS_M): the Krylov space is the whole space, so one Lanczos pass of
+// n steps is exact.  It runs inside ONE wave without any workgroup barrier: lane l owns
+// element l of every vector, G and the basis sit in LDS, matrix-vector products and the
+// Gram-Schmidt coefficients are lane-local loops over broadcast LDS reads.
+struct SmallWork {
+  double G[LANCZOS_M][LANCZOS_M + 1];
+  double Q[LANCZOS_M + 1][LANCZOS_M + 1];
+  double w[LANCZOS_M + 1], h[LANCZOS_M + 1];
+  double alpha[LANCZOS_M], beta[LANCZOS_M];
+  TriWork tri;
+};
+
+__device__ void lanczos_small_wave(const double *__restrict__ Gk, int n, int ld, int lane,
+                                   SmallWork &sw, double *__restrict__ v, double *info3) {
+  const bool own = lane < n;
+  for (int c = 0; c < n; ++c)
+    if (own) sw.G[c][lane] = Gk[(long)c * ld + lane];
+  // start vector G * ones
+  double y = 0.0;
+  for (int c = 0; c < n; ++c) y += own ? sw.G[c][lane] : 0.0;
+  double nrm = sqrt(wave_sum_d(own ? y * y : 0.0));
+  if (own) sw.Q[0][lane] = nrm > 0.0 ? y / nrm : (lane == 0 ? 1.0 : 0.0);
+  int m = 0;
+  double beta_last = 0.0;
+  for (int j = 0; j < n; ++j) {
+    double w = 0.0;  // w_l = sum_c G[c][l] q_j[c]   (G symmetric)
+    for (int c = 0; c < n; ++c) w = fma(own ? sw.G[c][lane] : 0.0, sw.Q[j][c], w);
+    double aj = 0.0;
+    for (int pass = 0; pass < 2; ++pass) {
+      if (own) sw.w[lane] = w;
+      // lane i <= j: h_i = q_i . w
+      double hi = 0.0;
+      if (lane <= j)
+        for (int e = 0; e < n; ++e) hi = fma(sw.Q[lane][e], sw.w[e], hi);
+      if (lane <= j) sw.h[lane] = hi;
+      aj += sw.h[j];
+      for (int i = 0; i <= j; ++i) w = fma(-sw.h[i], own ? sw.Q[i][lane] : 0.0, w);
+    }
+    const double bj = sqrt(wave_sum_d(own ? w * w : 0.0));
+    if (lane == 0) sw.alpha[j] = aj, sw.beta[j] = bj;
+    m = j + 1;
+    beta_last = bj;
+    if (bj <= 1e-300 || bj <= 1e-15 * fabs(aj)) break;
+    if (j + 1 < n && own) sw.Q[j + 1][lane] = w / bj;
+  }
+  const double theta = tridiag_top(sw.alpha, sw.beta, m, lane, sw.tri);
+  double yl = 0.0;
+  for (int i = 0; i < m; ++i) yl = fma(sw.tri.x[i], own ? sw.Q[i][lane] : 0.0, yl);
+  nrm = sqrt(wave_sum_d(own ? yl * yl : 0.0));
+  if (own) v[lane] = nrm > 0.0 ? yl / nrm : 0.0;
+  for (int e = n + lane; e < ld; e += 64) v[e] = 0.0;
+  if (lane == 0 && info3) {
+    info3[0] = theta;
+    info3[1] = fabs(beta_last * sw.tri.x[m - 1]);
+    info3[2] = 0.0;
+  }
+}
+
 __global__ __launch_bounds__(1024) void lanczos_kernel(const double *__restrict__ G,
                                                        const long *__restrict__ g_off,
                                                        const long *__restrict__ ld_,
@@ -496,12 +634,12 @@ __global__ __launch_bounds__(1024) void lanczos_kernel(const double *__restrict_
                                                        const long *__restrict__ v_off,
                                                        int max_restart, double tol,
                                                        double *__restrict__ info) {
-  __shared__ double alpha[LANCZOS_M], beta[LANCZOS_M], svec[LANCZOS_M], h[LANCZOS_M + 1];
-  __shared__ double x[LANCZOS_M], d[LANCZOS_M], du[LANCZOS_M], du2[LANCZOS_M], dl[LANCZOS_M];
+  __shared__ double alpha[LANCZOS_M], beta[LANCZOS_M], h[LANCZOS_M + 1];
+  __shared__ TriWork ws;
   __shared__ double red[16];
   __shared__ double upd[4][256];
-  __shared__ double s_theta, s_lo, s_hi;
-  __shared__ int s_m;
+  __shared__ double s_theta;
+  double *svec = ws.x;
   const int k = blockIdx.x;
   const int n = (int)n_[k], ld = (int)ld_[k];
   const double *Gk = G + g_off[k];
@@ -509,6 +647,11 @@ __global__ __launch_bounds__(1024) void lanczos_kernel(const double *__restrict_
   double *y = Qk + (long)(LANCZOS_M + 1) * ld;
   double *v = vout + v_off[k];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (n <= LANCZOS_M) {  // whole-space Lanczos inside one wave, no barriers
+    __shared__ SmallWork sw;
+    if (wave == 0) lanczos_small_wave(Gk, n, ld, lane, sw, v, info ? info + 3 * k : nullptr);
+    return;
+  }
   const int mfull = min(LANCZOS_M, n);
 
   // start vector: G * ones (a few power-like steps come for free in the Krylov space)
@@ -601,76 +744,10 @@ __global__ __launch_bounds__(1024) void lanczos_kernel(const double *__restrict_
       __syncthreads();
     }
     __syncthreads();
-    // ---- largest eigenvalue of T_m by multisection (wave 0)
+    // ---- largest eigenpair of T_m (wave 0)
     if (wave == 0) {
-      double lo = 1e300, hi = -1e300, tn = 0.0;
-      for (int i = 0; i < m; ++i) {
-        const double r = (i > 0 ? fabs(beta[i - 1]) : 0.0) + (i < m - 1 ? fabs(beta[i]) : 0.0);
-        lo = fmin(lo, alpha[i] - r);
-        hi = fmax(hi, alpha[i] + r);
-        tn = fmax(tn, fabs(alpha[i]) + r);
-      }
-      const double pivmin = fmax(tn * tn, 1.0) * 1e-300 + 1e-290;
-      hi += 1e-14 * tn + 1e-300;
-      for (int it = 0; it < 12; ++it) {
-        // lane l tests x_l = lo + (l+1) (hi-lo)/65 ; count(x) == m  <=>  x > theta_max
-        const double x = lo + (hi - lo) * (double)(lane + 1) / 65.0;
-        const bool above = sturm_count(alpha, beta, m, x, pivmin) >= m;
-        const unsigned long long bal = __ballot(above);
-        const int first = bal ? __ffsll((long long)bal) - 1 : 64;  // first lane above
-        const double nlo = first == 0 ? lo : lo + (hi - lo) * (double)first / 65.0;
-        const double nhi = first == 64 ? hi : lo + (hi - lo) * (double)(first + 1) / 65.0;
-        lo = nlo;
-        hi = nhi;
-      }
-      if (lane == 0) s_theta = 0.5 * (lo + hi), s_lo = lo, s_hi = hi, s_m = m;
-    }
-    __syncthreads();
-    // ---- Ritz vector of T_m: inverse iteration with partial pivoting (thread 0)
-    if (tid == 0) {
-      const int mm = s_m;
-      double tnorm = 0.0;
-      for (int i = 0; i < mm; ++i) tnorm = fmax(tnorm, fabs(alpha[i]) + (i < mm - 1 ? fabs(beta[i]) : 0.0));
-      const double sigma = s_theta + 4e-16 * tnorm;
-      for (int i = 0; i < mm; ++i) x[i] = 1.0 / sqrt((double)mm);
-      for (int iter = 0; iter < 2; ++iter) {
-        for (int i = 0; i < mm; ++i) {
-          d[i] = alpha[i] - sigma;
-          du[i] = i < mm - 1 ? beta[i] : 0.0;
-          dl[i] = du[i];
-          du2[i] = 0.0;
-        }
-        // LU with partial pivoting (dgtsv), solving in place
-        for (int i = 0; i < mm - 1; ++i) {
-          if (fabs(d[i]) >= fabs(dl[i])) {
-            if (d[i] == 0.0) d[i] = 1e-300;
-            const double f = dl[i] / d[i];
-            d[i + 1] -= f * du[i];
-            x[i + 1] -= f * x[i];
-            dl[i] = 0.0;
-          } else {
-            const double f = d[i] / dl[i];
-            d[i] = dl[i];
-            const double t = d[i + 1];
-            d[i + 1] = du[i] - f * t;
-            du2[i] = (i < mm - 2) ? du[i + 1] : 0.0;
-            if (i < mm - 2) du[i + 1] = -f * du2[i];
-            du[i] = t;
-            const double tx = x[i];
-            x[i] = x[i + 1];
-            x[i + 1] = tx - f * x[i + 1];
-          }
-        }
-        if (d[mm - 1] == 0.0) d[mm - 1] = 1e-300;
-        x[mm - 1] /= d[mm - 1];
-        if (mm > 1) x[mm - 2] = (x[mm - 2] - du[mm - 2] * x[mm - 1]) / d[mm - 2];
-        for (int i = mm - 3; i >= 0; --i) x[i] = (x[i] - du[i] * x[i + 1] - du2[i] * x[i + 2]) / d[i];
-        double nx = 0.0;
-        for (int i = 0; i < mm; ++i) nx += x[i] * x[i];
-        nx = 1.0 / sqrt(nx);
-        for (int i = 0; i < mm; ++i) x[i] *= nx;
-      }
-      for (int i = 0; i < mm; ++i) svec[i] = x[i];
+      const double th = tridiag_top(alpha, beta, m, lane, ws);
+      if (lane == 0) s_theta = th;
     }
     __syncthreads();
     theta = s_theta;
