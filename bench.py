@@ -131,6 +131,8 @@ def main():
     info = {}
 
     phase = {}
+    from origin_amd.pca import GreedyPCA
+    pca_driver = GreedyPCA(ctx)
 
     def one_step():
         t0 = time.perf_counter()
@@ -149,7 +151,8 @@ def main():
         cube_faint.copy_from(cube_std)
         F, mapO2, nstop, drv = pipeline.greedy_pca(ctx, cube_faint, local_map, nb_local,
                                                    thr["thresO2"], thr["testO2"], 50, 100,
-                                                   spx=spx, inplace=True)
+                                                   spx=spx, inplace=True, driver=pca_driver,
+                                                   o2_dev=pre["o2"])
         t3 = time.perf_counter()
         if world > 1:
             out = glr.run(cube_faint, mask, correl, profile, correl_min)

@@ -59,6 +59,9 @@ struct origin_ctx {
   std::vector<hipEvent_t> prof_free;
   double prof_ms[K_COUNT];
   long prof_n[K_COUNT];
+  // persistent workspace of origin_pca_run (owned by pca.hip)
+  void *pca_ws;
+  void (*pca_ws_free)(void *);
 };
 
 void origin_prof_begin(origin_ctx *ctx, int id);

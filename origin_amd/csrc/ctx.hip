@@ -159,6 +159,8 @@ int origin_ctx_create(int device, origin_ctx **out) {
   ctx->ctab = nullptr;
   ctx->ctab_nz = ctx->ctab_order = 0;
   ctx->prof_on = false;
+  ctx->pca_ws = nullptr;
+  ctx->pca_ws_free = nullptr;
   memset(ctx->prof_ms, 0, sizeof(ctx->prof_ms));
   memset(ctx->prof_n, 0, sizeof(ctx->prof_n));
   hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
@@ -185,6 +187,7 @@ int origin_ctx_destroy(origin_ctx *ctx) {
     }
   if (ctx->scratch) hipFree(ctx->scratch);
   if (ctx->ctab) hipFree(ctx->ctab);
+  if (ctx->pca_ws && ctx->pca_ws_free) ctx->pca_ws_free(ctx->pca_ws);
   prof_drain(ctx);
   for (hipEvent_t e : ctx->prof_free) hipEventDestroy(e);
   hipStreamDestroy(ctx->stream);

@@ -216,25 +216,49 @@ __global__ __launch_bounds__(256) void spatial4x4_kernel(const float *__restrict
         rowE[2 * q] = (f32x2){v.x, v.y};
         rowE[2 * q + 1] = (f32x2){v.z, v.w};
       }
+      // odd-aligned pairs (2q+1, 2q+2) are assembled from neighbouring even pairs in
+      // registers (one v_pk_mov_b32 each): reading them from LDS with ds_read2_b32 costs
+      // 8-way bank conflicts and made the LDS, not the VALU, the bottleneck
 #pragma unroll
-      for (int q = 0; q < (3 + H + 1) / 2; ++q)  // pairs (2q+1, 2q+2), up to column 3+H
-        rowO[q] = (f32x2){rbase[2 * q + 1], rbase[2 * q + 2]};
+      for (int q = 0; q + 1 < 2 * NV; ++q)
+        rowO[q] = __builtin_shufflevector(rowE[q], rowE[q + 1], 1, 2);
+      rowO[2 * NV - 1] = (f32x2){rowE[2 * NV - 1].y, 0.0f};
+      // output rows are processed in pairs so that four independent accumulators are in
+      // flight (a packed FMA then never waits for the previous one on the same register)
+      auto single = [&](int ry) {
+        const float *kr = kz + (i - ry) * P;
 #pragma unroll
-      for (int ry = 0; ry < 4; ++ry) {
-        const int dy = i - ry;
-        if (dy >= 0 && dy < P) {  // wave-uniform
-          const float *kr = kz + dy * P;
+        for (int dx = 0; dx < P; ++dx) {
+          const float kv = kr[dx];
+          const f32x2 k2 = (f32x2){kv, kv};
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int j = 2 * h + dx;  // first column of the pair
+            const f32x2 in = (j & 1) ? rowO[j >> 1] : rowE[j >> 1];
+            acc[ry][h] = __builtin_elementwise_fma(k2, in, acc[ry][h]);
+          }
+        }
+      };
+#pragma unroll
+      for (int rp = 0; rp < 4; rp += 2) {
+        const int dya = i - rp, dyb = i - rp - 1;
+        const bool va = dya >= 0 && dya < P, vb = dyb >= 0 && dyb < P;  // wave-uniform
+        if (va && vb) {
+          const float *ka = kz + dya * P, *kb = kz + dyb * P;
 #pragma unroll
           for (int dx = 0; dx < P; ++dx) {
-            const float kv = kr[dx];
-            const f32x2 k2 = (f32x2){kv, kv};
+            const f32x2 a2 = (f32x2){ka[dx], ka[dx]}, b2 = (f32x2){kb[dx], kb[dx]};
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-              const int j = 2 * h + dx;  // first column of the pair
+              const int j = 2 * h + dx;
               const f32x2 in = (j & 1) ? rowO[j >> 1] : rowE[j >> 1];
-              acc[ry][h] = __builtin_elementwise_fma(k2, in, acc[ry][h]);
+              acc[rp][h] = __builtin_elementwise_fma(a2, in, acc[rp][h]);
+              acc[rp + 1][h] = __builtin_elementwise_fma(b2, in, acc[rp + 1][h]);
             }
           }
+        } else {
+          if (va) single(rp);
+          if (vb) single(rp + 1);
         }
       }
     }

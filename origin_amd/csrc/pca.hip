@@ -949,6 +949,10 @@ struct DevBuf {
   ~DevBuf() { release(); }
 };
 
+struct PcaWorkspace {
+  DevBuf b[16];
+};
+
 int gram_launch(origin_ctx *ctx, const double *d_Xp, const long *d_xp_off, const long *d_ld, int Nz,
                 int ntiles, const int *d_ti, const int *d_tj, const int *d_ta, long g_total,
                 double *d_G, const long *d_g_off) {
@@ -1025,8 +1029,17 @@ int origin_pca_run(origin_ctx *ctx, float *d_F, int Nz, long S, int na, const in
   if (ntot == 0) return ORIGIN_OK;
 
   // ---- persistent state on the device
-  DevBuf b_state, b_lists, b_test, b_desc, b_tiles, b_xp, b_g, b_cv, b_bu, b_part, b_cpart, b_info;
-  DevBuf b_U, b_C, b_small, b_fd;
+  // device buffers are kept in the context between calls (hipMalloc/hipFree of a few hundred
+  // MB per call cost milliseconds)
+  if (!ctx->pca_ws) {
+    ctx->pca_ws = new PcaWorkspace();
+    ctx->pca_ws_free = [](void *p) { delete (PcaWorkspace *)p; };
+  }
+  PcaWorkspace &W = *(PcaWorkspace *)ctx->pca_ws;
+  DevBuf &b_state = W.b[0], &b_lists = W.b[1], &b_test = W.b[2], &b_desc = W.b[3],
+         &b_tiles = W.b[4], &b_xp = W.b[5], &b_g = W.b[6], &b_cv = W.b[7], &b_bu = W.b[8],
+         &b_part = W.b[9], &b_cpart = W.b[10], &b_info = W.b[11], &b_U = W.b[12], &b_C = W.b[13],
+         &b_small = W.b[14], &b_fd = W.b[15];
   const bool debug = getenv("ORIGIN_PCA_DEBUG") != nullptr;
   const size_t st_bytes = (size_t)na * (sizeof(double) + 4 * sizeof(int)) + sizeof(int) * 2 +
                           (size_t)(na + 1) * sizeof(long) + 64;

@@ -21,10 +21,28 @@ class GreedyPCA:
         self.trace = []      # per lock-step iteration: (areas iterating, nuisance spaxels)
         self.iterations = 0
 
-    def run(self, F, area_spx, tests, thresholds, Noise_population=50, itermax=100):
+    def prepare(self, area_spx, S):
+        """Upload the area lists once; they are reused by every later ``run``."""
+        lens = np.array([len(s) for s in area_spx], dtype=np.int64)
+        off = np.zeros(len(area_spx) + 1, dtype=np.int64)
+        off[1:] = np.cumsum(lens)
+        spx = (np.concatenate([np.asarray(s, dtype=np.int32) for s in area_spx])
+               if off[-1] else np.zeros(0, np.int32))
+        if spx.size and (spx.min() < 0 or spx.max() >= S):
+            raise ValueError("spaxel index outside the cube")
+        self._area_spx = area_spx
+        self._off = off
+        self._d_spx = self.ctx.to_device(spx if spx.size else np.zeros(1, np.int32))
+        self._S = S
+        return self
+
+    def run(self, F, area_spx, tests, thresholds, Noise_population=50, itermax=100,
+            test_map=None, want_map=True):
         """F: DeviceArray (Nz, Ny, Nx) float32, updated in place (cube_faint).
         area_spx: per area, int32 flat spaxel indices in C order (``areamap == i``).
-        tests: per area float64 O2 values in the same order (``testO2``).
+        tests: per area float64 O2 values in the same order (``testO2``); alternatively
+        ``test_map``: a float64 DeviceArray [Ny*Nx] holding the O2 test of every spaxel (what
+        dct_standardize produces), which avoids a host round trip.
         Returns (mapO2 per area as float64 arrays, nstop)."""
         ctx = self.ctx
         Nz = F.shape[0]
@@ -32,22 +50,20 @@ class GreedyPCA:
         na = len(area_spx)
         if na == 0:
             return [], 0
-        lens = np.array([len(s) for s in area_spx], dtype=np.int64)
-        off = np.zeros(na + 1, dtype=np.int64)
-        off[1:] = np.cumsum(lens)
-        spx = (np.concatenate([np.asarray(s, dtype=np.int32) for s in area_spx])
-               if off[-1] else np.zeros(0, np.int32))
-        if spx.size and (spx.min() < 0 or spx.max() >= S):
-            raise ValueError("spaxel index outside the cube")
-        test0 = np.zeros(S, dtype=np.float64)
-        for s, t in zip(area_spx, tests):
-            t = np.asarray(t, dtype=np.float64).reshape(-1)
-            if len(t) != len(s):
-                raise ValueError("testO2 and area size differ")
-            test0[np.asarray(s)] = t
+        if getattr(self, "_area_spx", None) is not area_spx or getattr(self, "_S", None) != S:
+            self.prepare(area_spx, S)
+        off, d_spx = self._off, self._d_spx
+        if test_map is not None:
+            d_test = test_map
+        else:
+            test0 = np.zeros(S, dtype=np.float64)
+            for s, t in zip(area_spx, tests):
+                t = np.asarray(t, dtype=np.float64).reshape(-1)
+                if len(t) != len(s):
+                    raise ValueError("testO2 and area size differ")
+                test0[np.asarray(s)] = t
+            d_test = ctx.to_device(test0)
         thr = np.ascontiguousarray(thresholds, dtype=np.float64)
-        d_spx = ctx.to_device(spx if spx.size else np.zeros(1, np.int32))
-        d_test = ctx.to_device(test0)
         d_map = ctx.empty((S,), np.int32)
         nstop, iters = C.c_int(0), C.c_int(0)
         cap = int(itermax) + 2
@@ -56,8 +72,11 @@ class GreedyPCA:
                    off.ctypes.data_as(C.c_void_p), d_test.p, thr.ctypes.data_as(C.c_void_p),
                    float(Noise_population), int(itermax), d_map.p, C.byref(nstop),
                    C.byref(iters), trace.ctypes.data_as(C.c_void_p), cap)
-        hmap = d_map.to_host()
         self.iterations = iters.value
         self.trace = [(int(trace[2 * i]), int(trace[2 * i + 1]))
                       for i in range(min(iters.value, cap))]
+        self.map_dev = d_map
+        if not want_map:
+            return None, nstop.value
+        hmap = d_map.to_host()
         return [hmap[np.asarray(s)].astype(np.float64) for s in area_spx], nstop.value
