@@ -148,11 +148,10 @@ def main():
         t1 = time.perf_counter()
         thr = pipeline.pca_threshold(o2, local_map, nb_local, 0.01, spx=spx)
         t2 = time.perf_counter()
-        cube_faint.copy_from(cube_std)
-        F, mapO2, nstop, drv = pipeline.greedy_pca(ctx, cube_faint, local_map, nb_local,
+        F, mapO2, nstop, drv = pipeline.greedy_pca(ctx, cube_std, local_map, nb_local,
                                                    thr["thresO2"], thr["testO2"], 50, 100,
-                                                   spx=spx, inplace=True, driver=pca_driver,
-                                                   o2_dev=pre["o2"])
+                                                   spx=spx, inplace=False, driver=pca_driver,
+                                                   o2_dev=pre["o2"], out=cube_faint)
         t3 = time.perf_counter()
         if world > 1:
             out = glr.run(cube_faint, mask, correl, profile, correl_min)

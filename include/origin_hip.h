@@ -114,8 +114,9 @@ int origin_dct_standardize(origin_ctx *ctx, const float *d_raw, const float *d_v
 int origin_o2(origin_ctx *ctx, const float *d_cube, int Nz, long S, double *d_out);
 
 /* Compute_GreedyPCA_area / Compute_GreedyPCA (lib_origin.py:769-821, :848-954): the whole
- * greedy loop for `na` areas, in place on d_F (float32 (Nz, S), S = Ny*Nx), all areas in lock
- * step, control flow on the device.
+ * greedy loop for `na` areas: d_X (float32 (Nz, S), S = Ny*Nx) is cube_std, d_F receives
+ * cube_faint; d_X == d_F or d_X == NULL means in place.  All areas advance in lock step,
+ * control flow on the device, cube kept in coefficient form F = X - U C until the end.
  *   d_spx      int32 device: concatenated flat spaxel indices s = y*Nx + x of the areas, each
  *              in the column order of cube[:, areamap == i]; h_spx_off: host int64 [na+1].
  *   d_test0    float64 device [S]: O2 test per spaxel (testO2, lib :840) -- not modified.
@@ -129,7 +130,8 @@ int origin_o2(origin_ctx *ctx, const float *d_cube, int Nz, long S, double *d_ou
  * (:920-923; the division by sum(b^2) at :924 only rescales Xp), G = Xp^T Xp with
  * v_mfma_f64_16x16x4_f64 and its leading eigenvector by restarted Lanczos in place of
  * svds(k=1) (:940), u = Xp v/|Xp v|, F -= u u^T F and the new O2 test (:943-946). */
-int origin_pca_run(origin_ctx *ctx, float *d_F, int Nz, long S, int na, const int *d_spx,
+int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S, int na,
+                   const int *d_spx,
                    const long *h_spx_off, const double *d_test0, const double *h_thr,
                    double noise_pop, int itermax, int *d_mapO2, int *h_nstop, int *h_iters,
                    long *h_trace, int trace_cap);

@@ -881,10 +881,10 @@ __global__ __launch_bounds__(256) void deflate_finish_kernel(const int *__restri
 }
 
 // ------------------------------------------------------------------------------------
-// flush: F[z, s] = X[z, s] - sum_{q < T_a} U[z][q] C[q][i]  (in place; one float32 rounding)
+// flush: F[z, s] = X[z, s] - sum_{q < T_a} U[z][q] C[q][i]  (X may alias F; one float32 rounding)
 // grid (ceil(nsmax/256), ceil(Nz/16), na_flush); thread = one spaxel x 16 channels
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void flush_kernel(float *__restrict__ F, int Nz, long S,
+__global__ __launch_bounds__(256) void flush_kernel(const float *X, float *F, int Nz, long S,
                                                     const int *__restrict__ spx,
                                                     const long *__restrict__ FD, int nf,
                                                     const double *__restrict__ U,
@@ -916,7 +916,7 @@ __global__ __launch_bounds__(256) void flush_kernel(float *__restrict__ F, int N
       const int z = z0 + r;
       if (z < Nz) {
         const long idx = (long)z * S + col;
-        F[idx] = (float)((double)F[idx] - acc[r]);
+        F[idx] = (float)((double)X[idx] - acc[r]);
       }
     }
   }
@@ -1011,7 +1011,8 @@ int origin_pca_eig(origin_ctx *ctx, const double *d_G, const long *d_g_off, cons
 int origin_pca_eig_qrows(void) { return LANCZOS_M + 2; }
 
 // The whole greedy PCA of `na` areas, in place on d_F.
-int origin_pca_run(origin_ctx *ctx, float *d_F, int Nz, long S, int na, const int *d_spx,
+int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S, int na,
+                   const int *d_spx,
                    const long *h_spx_off, const double *d_test0, const double *h_thr,
                    double noise_pop, int itermax, int *d_mapO2, int *h_nstop, int *h_iters,
                    long *h_trace, int trace_cap) {
@@ -1020,12 +1021,16 @@ int origin_pca_run(origin_ctx *ctx, float *d_F, int Nz, long S, int na, const in
                        Nz > 0 && S > 0 && na > 0,
                    "bad arguments");
   ORIGIN_CHECK_ARG(noise_pop > 0 && itermax >= 0, "bad Noise_population / itermax");
+  if (!d_X) d_X = d_F;
+  const float *src = d_X;  // where the not-yet-deflated cube is read from
   const long ntot = h_spx_off[na];
   ORIGIN_CHECK_ARG(ntot >= 0 && ntot <= S, "area lists longer than the field");
   hipStream_t st = ctx->stream;
   if (h_iters) *h_iters = 0;
   *h_nstop = 0;
   ORIGIN_HIP(hipMemsetAsync(d_mapO2, 0, (size_t)S * sizeof(int), st));
+  if (src != d_F && ntot < S)  // spaxels outside every area are simply copied
+    ORIGIN_HIP(hipMemcpyAsync(d_F, d_X, (size_t)Nz * S * sizeof(float), hipMemcpyDeviceToDevice, st));
   if (ntot == 0) return ORIGIN_OK;
 
   // ---- persistent state on the device
@@ -1088,34 +1093,39 @@ int origin_pca_run(origin_ctx *ctx, float *d_F, int Nz, long S, int na, const in
     ~Pinned() { (void)hipHostFree(p); }
   } pinned{h_nnb};
 
-  // F = X - U C for every area that holds vectors; afterwards T = 0 everywhere
+  // F = X - U C for every area that holds vectors (every area at all when the output is a
+  // different buffer and has not been written yet); afterwards T = 0 and the cube is read
+  // from d_F
   auto flush = [&]() -> int {
+    const bool all = src != d_F;
     std::vector<long> fd;
     int nf = 0, nsmax = 0;
-    for (int a = 0; a < na; ++a) nf += T[a] > 0;
-    if (nf == 0) return ORIGIN_OK;
-    fd.assign((size_t)4 * nf, 0);
-    int k = 0;
-    for (int a = 0; a < na; ++a) {
-      if (T[a] == 0) continue;
-      const int ns = (int)(h_spx_off[a + 1] - h_spx_off[a]);
-      fd[k] = a;
-      fd[(size_t)nf + k] = h_spx_off[a];
-      fd[(size_t)2 * nf + k] = ns;
-      fd[(size_t)3 * nf + k] = T[a];
-      nsmax = std::max(nsmax, ns);
-      T[a] = 0;
-      ++k;
+    for (int a = 0; a < na; ++a) nf += (all || T[a] > 0) && h_spx_off[a + 1] > h_spx_off[a];
+    if (nf > 0) {
+      fd.assign((size_t)4 * nf, 0);
+      int k = 0;
+      for (int a = 0; a < na; ++a) {
+        const int ns = (int)(h_spx_off[a + 1] - h_spx_off[a]);
+        if (!((all || T[a] > 0) && ns > 0)) continue;
+        fd[k] = a;
+        fd[(size_t)nf + k] = h_spx_off[a];
+        fd[(size_t)2 * nf + k] = ns;
+        fd[(size_t)3 * nf + k] = T[a];
+        nsmax = std::max(nsmax, ns);
+        ++k;
+      }
+      int r;
+      if ((r = b_fd.reserve(ctx, fd.size() * sizeof(long)))) return r;
+      ORIGIN_HIP(hipMemcpyAsync(b_fd.p, fd.data(), fd.size() * sizeof(long), hipMemcpyHostToDevice,
+                                st));
+      ORIGIN_HIP(hipStreamSynchronize(st));
+      ProfScope ps(ctx, K_PCA_FLUSH);
+      hipLaunchKernelGGL(flush_kernel, dim3(cdiv(nsmax, 256), cdiv(Nz, 16), nf), dim3(256), 0, st,
+                         src, d_F, Nz, S, d_spx, (const long *)b_fd.p, nf, d_U, d_C, ntot);
+      ORIGIN_LAUNCH_CHECK();
     }
-    int r;
-    if ((r = b_fd.reserve(ctx, fd.size() * sizeof(long)))) return r;
-    ORIGIN_HIP(hipMemcpyAsync(b_fd.p, fd.data(), fd.size() * sizeof(long), hipMemcpyHostToDevice,
-                              st));
-    ORIGIN_HIP(hipStreamSynchronize(st));
-    ProfScope ps(ctx, K_PCA_FLUSH);
-    hipLaunchKernelGGL(flush_kernel, dim3(cdiv(nsmax, 256), cdiv(Nz, 16), nf), dim3(256), 0, st,
-                       d_F, Nz, S, d_spx, (const long *)b_fd.p, nf, d_U, d_C, ntot);
-    ORIGIN_LAUNCH_CHECK();
+    for (int a = 0; a < na; ++a) T[a] = 0;
+    src = d_F;
     return ORIGIN_OK;
   };
 
@@ -1230,7 +1240,7 @@ int origin_pca_run(origin_ctx *ctx, float *d_F, int Nz, long S, int na, const in
       ProfScope ps(ctx, K_PCA_BMEAN);
       hipLaunchKernelGGL(cbar_kernel, dim3(nw), dim3(1024), 0, st, d_C, ntot, d_bg_pos, dD, nw,
                          d_cbar);
-      hipLaunchKernelGGL(bmean_kernel, dim3(cdiv(Nz, 4), nw), dim3(64, 4), 0, st, d_F, Nz, S, d_bg,
+      hipLaunchKernelGGL(bmean_kernel, dim3(cdiv(Nz, 4), nw), dim3(64, 4), 0, st, src, Nz, S, d_bg,
                          dD, nw, d_U, d_cbar, d_b);
     }
     // z slices of the gather: enough blocks to fill the chip even when few areas iterate
@@ -1244,7 +1254,7 @@ int origin_pca_run(origin_ctx *ctx, float *d_F, int Nz, long S, int na, const in
     {
       ProfScope ps(ctx, K_PCA_GATHER);
       hipLaunchKernelGGL(gather_xp_kernel, dim3(cdiv(ldmax, 64), nw, nzb), dim3(64, 16), 0, st,
-                         d_F, Nz, S, d_nuis, d_nuis_pos, dD, nw, d_b, d_U, d_C, ntot, d_Xp, d_cpart,
+                         src, Nz, S, d_nuis, d_nuis_pos, dD, nw, d_b, d_U, d_C, ntot, d_Xp, d_cpart,
                          c, gzper);
     }
     {
@@ -1304,7 +1314,7 @@ int origin_pca_run(origin_ctx *ctx, float *d_F, int Nz, long S, int na, const in
     double *cpart = (double *)scr;
     {
       ProfScope ps(ctx, K_PCA_DEFLATE_DOT);
-      hipLaunchKernelGGL(deflate_dot_kernel, dim3(cdiv(nsmax, 256), nzs, nw), dim3(256), 0, st, d_F,
+      hipLaunchKernelGGL(deflate_dot_kernel, dim3(cdiv(nsmax, 256), nzs, nw), dim3(256), 0, st, src,
                          Nz, S, d_spx, dD, nw, d_u, zper, cpart, cb);
     }
     {

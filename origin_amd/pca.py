@@ -37,8 +37,9 @@ class GreedyPCA:
         return self
 
     def run(self, F, area_spx, tests, thresholds, Noise_population=50, itermax=100,
-            test_map=None, want_map=True):
-        """F: DeviceArray (Nz, Ny, Nx) float32, updated in place (cube_faint).
+            test_map=None, want_map=True, src=None):
+        """F: DeviceArray (Nz, Ny, Nx) float32 receiving cube_faint; ``src`` (cube_std) is
+        read instead of F when given (out of place), else F is updated in place.
         area_spx: per area, int32 flat spaxel indices in C order (``areamap == i``).
         tests: per area float64 O2 values in the same order (``testO2``); alternatively
         ``test_map``: a float64 DeviceArray [Ny*Nx] holding the O2 test of every spaxel (what
@@ -68,7 +69,8 @@ class GreedyPCA:
         nstop, iters = C.c_int(0), C.c_int(0)
         cap = int(itermax) + 2
         trace = np.zeros(2 * cap, dtype=np.int64)
-        _capi.call("origin_pca_run", ctx.handle, F.p, Nz, S, na, d_spx.p,
+        _capi.call("origin_pca_run", ctx.handle, (src.p if src is not None else F.p), F.p, Nz, S,
+                   na, d_spx.p,
                    off.ctypes.data_as(C.c_void_p), d_test.p, thr.ctypes.data_as(C.c_void_p),
                    float(Noise_population), int(itermax), d_map.p, C.byref(nstop),
                    C.byref(iters), trace.ctypes.data_as(C.c_void_p), cap)

@@ -60,17 +60,19 @@ def pca_threshold(o2_map, areamap, nbAreas, pfa_test=0.01, spx=None):
 
 
 def greedy_pca(ctx, cube_std, areamap, nbAreas, thresholds, testO2, Noise_population=50,
-               itermax=100, spx=None, inplace=False, driver=None, o2_dev=None):
+               itermax=100, spx=None, inplace=False, driver=None, o2_dev=None, out=None):
     """``Compute_GreedyPCA_area`` (lib_origin.py:769-821) on a device cube.  Returns
     (cube_faint DeviceArray, mapO2 (Ny,Nx) float64, nstop, driver).  ``o2_dev``: the O2 map of
     cube_std still on the device (float64 [Ny,Nx]) -- used instead of ``testO2`` when given;
     ``driver``: a GreedyPCA to reuse (keeps the area lists on the device between calls)."""
     Nz, Ny, Nx = cube_std.shape
     spx = area_lists(areamap, nbAreas) if spx is None else spx
-    F = cube_std if inplace else cube_std.copy()      # cube_faint = cube_std.copy() (:799)
+    # cube_faint = cube_std.copy() (:799): the copy is folded into the final F = X - U C pass
+    F = cube_std if inplace else (out if out is not None else ctx.empty(cube_std.shape,
+                                                                        np.float32))
     drv = driver or GreedyPCA(ctx)
     maps, nstop = drv.run(F, spx, testO2, [float(t) for t in thresholds], Noise_population,
-                          itermax, test_map=o2_dev)
+                          itermax, test_map=o2_dev, src=None if inplace else cube_std)
     mapO2 = np.zeros(Ny * Nx)
     for s, m in zip(spx, maps):
         mapO2[s] = m
