@@ -150,6 +150,19 @@ int origin_pca_eig(origin_ctx *ctx, const double *d_G, const long *d_g_off, cons
                    const long *d_v_off, double *d_info);
 int origin_pca_eig_qrows(void);
 
+/* Host-only helper of Compute_PCA_threshold (lib_origin.py:999-1002): data > 0, sigma clip
+ * (median / std, <= maxiters iterations), np.histogram(bins='fd', density=True).  h_hist gets
+ * *nbins values, h_edges *nbins + 1; cap_bins = capacity of h_hist.  No GPU involved. */
+int origin_o2_histogram(const double *h_data, long n, double sigclip, int maxiters,
+                        double *h_hist, double *h_edges, long cap_bins, long *nbins,
+                        long *nkept);
+
+/* the same for `na` areas (values of area a at h_data[h_off[a] .. h_off[a+1])) on host threads;
+ * results of area a start at a * (cap_bins + 1) in h_hist / h_edges. */
+int origin_o2_histogram_batch(const double *h_data, const long *h_off, int na, double sigclip,
+                              int maxiters, double *h_hist, double *h_edges, long cap_bins,
+                              long *h_nbins);
+
 /* ---- C. GLR correlation ------------------------------------------------------------
  * Replaces Correlation_GLR_test (lib_origin.py:1070-1217) and the dense lines of
  * ComputeTGLR.run (steps.py:781-793).

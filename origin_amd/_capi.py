@@ -51,6 +51,8 @@ SIGNATURES = {
     "origin_pca_gram": [vp, vp, vp, vp, i32, i32, vp, vp, vp, i64, vp, vp],
     "origin_pca_eig": [vp, vp, vp, vp, vp, i32, i64, vp, vp, vp, vp],
     "origin_pca_eig_qrows": [],
+    "origin_o2_histogram": [vp, i64, C.c_double, i32, vp, vp, i64, PP(i64), PP(i64)],
+    "origin_o2_histogram_batch": [vp, vp, i32, C.c_double, i32, vp, vp, i64, vp],
     "origin_glr_plan_create": [vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, PP(vp)],
     "origin_glr_plan_destroy": [vp],
     "origin_glr_plan_bytes": [vp, PP(sz)],

@@ -11,7 +11,7 @@ import numpy as np
 
 from . import kernels
 from .pca import GreedyPCA
-from .thresholds import compute_thresh_gaussfit
+from .thresholds import clipped_histograms, compute_thresh_gaussfit
 
 
 def preprocess(ctx, raw, var, mask, dct_order=10, dct_approx=False, allreduce=None,
@@ -47,13 +47,12 @@ def pca_threshold(o2_map, areamap, nbAreas, pfa_test=0.01, spx=None):
     spx = area_lists(areamap, nbAreas) if spx is None else spx
     flat = np.asarray(o2_map, dtype=np.float64).reshape(-1)
 
-    def one(s):
-        test = flat[s]
-        return (test,) + tuple(compute_thresh_gaussfit(test, pfa_test))
-
-    # (a thread pool was measured slower than the serial loop on the 256-thread GPU host:
-    # the fit is dominated by short NumPy calls holding the GIL)
-    results = [one(s) for s in spx]
+    tests = [flat[s] for s in spx]
+    # clip + histogram of all areas in one native multi-threaded call, then the (SciPy /
+    # MINPACK) Gaussian fit per area
+    hists = clipped_histograms(tests) if tests else []
+    results = [(t,) + tuple(compute_thresh_gaussfit(t, pfa_test, _hist=h))
+               for t, h in zip(tests, hists)]
     testO2, histO2, binO2, thresO2, meaO2, stdO2 = zip(*results)
     return dict(testO2=testO2, histO2=histO2, binO2=binO2, thresO2=thresO2, meaO2=meaO2,
                 stdO2=stdO2)

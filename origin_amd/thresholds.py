@@ -7,6 +7,8 @@ half.  It is scalar work on a tiny vector and stays on the host by design; the d
 muse_origin/lib_origin.py:977-1024, with astropy's ``sigma_clip`` / ``LevMarLSQFitter`` /
 ``Gaussian1D`` restated on NumPy/SciPy (astropy is not needed at run time).
 """
+import ctypes as C
+
 import numpy as np
 from scipy import optimize
 from scipy.special import ndtri
@@ -53,13 +55,55 @@ def fit_gauss1d(x, y, amplitude, mean, stddev):
     return unpack(p)
 
 
-def compute_thresh_gaussfit(data, pfa, bins='fd', sigclip=10):
-    """Same signature and return tuple as the reference (lib_origin.py:977-1024):
-    histO2, frecO2, thresO2 (python float), mea, std."""
+def clipped_histogram(data, bins='fd', sigclip=10):
+    """data[data > 0] -> sigma clip -> density histogram (lib_origin.py:999-1002).  For the
+    default 'fd' bins this runs as native host code in liborigin_hip.so (bit-identical to
+    the NumPy path below, tests/test_host_logic.py); other estimators use NumPy."""
+    data = np.ascontiguousarray(data, dtype=np.float64).ravel()
+    if bins == 'fd' and data.size:
+        from . import _capi
+        cap = max(4096, data.size)
+        hist = np.empty(cap)
+        edges = np.empty(cap + 1)
+        nb, nk = C.c_long(0), C.c_long(0)
+        _capi.call("origin_o2_histogram", data.ctypes.data_as(C.c_void_p), data.size,
+                   float(sigclip), 5, hist.ctypes.data_as(C.c_void_p),
+                   edges.ctypes.data_as(C.c_void_p), cap, C.byref(nb), C.byref(nk))
+        return hist[:nb.value].copy(), edges[:nb.value + 1].copy()
+    return clipped_histogram_numpy(data, bins, sigclip)
+
+
+def clipped_histograms(tests, sigclip=10):
+    """``clipped_histogram`` for a list of per-area O2 vectors in one native call that spreads
+    the areas over host threads."""
+    from . import _capi
+    lens = np.array([len(t) for t in tests], dtype=np.int64)
+    off = np.zeros(len(tests) + 1, dtype=np.int64)
+    off[1:] = np.cumsum(lens)
+    data = np.ascontiguousarray(np.concatenate([np.asarray(t, dtype=np.float64).ravel()
+                                                for t in tests]))
+    cap = int(max(4096, lens.max()))
+    hist = np.empty((len(tests), cap + 1))
+    edges = np.empty((len(tests), cap + 1))
+    nb = np.zeros(len(tests), dtype=np.int64)
+    _capi.call("origin_o2_histogram_batch", data.ctypes.data_as(C.c_void_p),
+               off.ctypes.data_as(C.c_void_p), len(tests), float(sigclip), 5,
+               hist.ctypes.data_as(C.c_void_p), edges.ctypes.data_as(C.c_void_p), cap,
+               nb.ctypes.data_as(C.c_void_p))
+    return [(hist[a, :nb[a]].copy(), edges[a, :nb[a] + 1].copy()) for a in range(len(tests))]
+
+
+def clipped_histogram_numpy(data, bins='fd', sigclip=10):
     data = np.asarray(data, dtype=float)
     data = data[data > 0]
     data = sigma_clip_compressed(data, sigclip)
-    histO2, frecO2 = np.histogram(data, bins=bins, density=True)
+    return np.histogram(data, bins=bins, density=True)
+
+
+def compute_thresh_gaussfit(data, pfa, bins='fd', sigclip=10, _hist=None):
+    """Same signature and return tuple as the reference (lib_origin.py:977-1024):
+    histO2, frecO2, thresO2 (python float), mea, std."""
+    histO2, frecO2 = _hist if _hist is not None else clipped_histogram(data, bins, sigclip)
     ind = np.argmax(histO2)
     mod = frecO2[ind]
     ind2 = np.argmin((histO2[ind] / 2 - histO2[:ind]) ** 2)

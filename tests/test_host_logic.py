@@ -65,3 +65,28 @@ def test_synthetic_field_is_deterministic_and_windowed():
     assert a[0].dtype == np.float32 and a[2].dtype == np.uint8
     psf = synth.moffat_psf(10, 25)
     np.testing.assert_allclose(psf.sum(axis=(1, 2)), 1, rtol=1e-6)
+
+
+def test_native_clipped_histogram_is_bit_identical_to_numpy():
+    """origin_o2_histogram (native host code in liborigin_hip.so) vs
+    sigma_clip + np.histogram(bins='fd', density=True)."""
+    from origin_amd import build
+    build.build()
+    rng = np.random.default_rng(0)
+    tests = []
+    for trial in range(60):
+        n = int(rng.integers(30, 9000))
+        t = (rng.standard_normal((int(rng.integers(20, 300)), n)) ** 2).mean(0)
+        k = max(1, n // 40)
+        t[rng.integers(0, n, k)] *= np.exp(rng.uniform(0.1, 4, k))
+        if trial % 7 == 0:
+            t[rng.integers(0, n, 3)] = 0
+        tests.append(t)
+        a = thresholds.clipped_histogram(t)
+        b = thresholds.clipped_histogram_numpy(t)
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])
+    for (h, e), t in zip(thresholds.clipped_histograms(tests), tests):
+        b = thresholds.clipped_histogram_numpy(t)
+        np.testing.assert_array_equal(h, b[0])
+        np.testing.assert_array_equal(e, b[1])
