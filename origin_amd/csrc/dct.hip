@@ -75,12 +75,12 @@ struct CtabGuard {  // the table is cached in the context; nothing to release pe
 // pass 1: moments + solve.  block = (64 lanes, ZS waves); wave w marches z = w, w+ZS, ...
 // ------------------------------------------------------------------------------------
 template <int ORDER>
-__global__ __launch_bounds__(512) void dct_fit_kernel(const float *__restrict__ raw,
-                                                      const float *__restrict__ var,
-                                                      const uint8_t *__restrict__ mask,
-                                                      const double *__restrict__ ctab, int Nz,
-                                                      long S, int approx,
-                                                      double *__restrict__ coef) {
+__global__ __launch_bounds__(512) void dct_moments_kernel(const float *__restrict__ raw,
+                                                          const float *__restrict__ var,
+                                                          const uint8_t *__restrict__ mask,
+                                                          const double *__restrict__ ctab,
+                                                          int Nz, long S,
+                                                          double *__restrict__ mom) {
   constexpr int NA = ORDER + 1;
   constexpr int NK = 2 * ORDER + 1;
   constexpr int NACC = NK + 2 * NA;
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(512) void dct_fit_kernel(const float *__restrict__ 
   for (int a = 0; a < NA; ++a) Rw[a] = R0[a] = 0.0;
   int anymask = 0;
 
-#pragma unroll 2
+#pragma unroll 4
   for (int z = wave; z < Nz; z += ZS) {
     const long idx = (long)z * S + sc;
     const float r = raw[idx];
@@ -147,6 +147,40 @@ __global__ __launch_bounds__(512) void dct_fit_kernel(const float *__restrict__ 
     }
   }
 
+  // moments of this spaxel -> global (the solve runs in a second, register-hungry kernel so
+  // that this streaming kernel keeps a high occupancy)
+  if (live) {
+#pragma unroll
+    for (int k = 0; k < NK; ++k) mom[(long)k * S + s] = M[k];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+      mom[(long)(NK + a) * S + s] = Rw[a];
+      mom[(long)(NK + NA + a) * S + s] = R0[a];
+    }
+    mom[(long)NACC * S + s] = (double)anymask;
+  }
+}
+
+// per spaxel: H y = 2 Rw by Cholesky (valid spaxels) or the plain DCT coefficients
+template <int ORDER>
+__global__ __launch_bounds__(256) void dct_solve_kernel(const double *__restrict__ mom, int Nz,
+                                                        long S, int approx,
+                                                        double *__restrict__ coef) {
+  constexpr int NA = ORDER + 1;
+  constexpr int NK = 2 * ORDER + 1;
+  constexpr int NACC = NK + 2 * NA;
+  const long s = (long)blockIdx.x * 256 + threadIdx.x;
+  if (s >= S) return;
+  double M[NK], Rw[NA], R0[NA];
+#pragma unroll
+  for (int k = 0; k < NK; ++k) M[k] = mom[(long)k * S + s];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) {
+    Rw[a] = mom[(long)(NK + a) * S + s];
+    R0[a] = mom[(long)(NK + NA + a) * S + s];
+  }
+  const int anymask = mom[(long)NACC * S + s] != 0.0;
+  const bool live = true;
   double y[NA];
   bool weighted = !approx && !anymask;  // valid = ~any(mask, axis=0)   (lib :226)
   if (weighted) {
@@ -481,10 +515,16 @@ int origin_dct_fit(origin_ctx *ctx, const float *d_raw, const float *d_var,
   while (ZS > 1 && (size_t)(ZS - 1) * (NACC + 1) * 64 * sizeof(double) > 64 * 1024) ZS /= 2;
   const size_t lds = (size_t)(ZS - 1) * (NACC + 1) * 64 * sizeof(double);
   dim3 grid((unsigned)waves), block(64, ZS);
+  void *scr = nullptr;
+  rc = origin_scratch(ctx, (size_t)(NACC + 1) * S * sizeof(double), &scr);
+  if (rc) return rc;
+  double *mom = (double *)scr;
   ProfScope ps(ctx, K_DCT_FIT);
-#define CALL(O)                                                                             \
-  hipLaunchKernelGGL(dct_fit_kernel<O>, grid, block, lds, ctx->stream, d_raw, d_var, d_mask, \
-                     tab.p, Nz, S, approx, d_coef)
+#define CALL(O)                                                                                 \
+  hipLaunchKernelGGL(dct_moments_kernel<O>, grid, block, lds, ctx->stream, d_raw, d_var, d_mask, \
+                     tab.p, Nz, S, mom);                                                        \
+  hipLaunchKernelGGL(dct_solve_kernel<O>, dim3(cdiv(S, 256)), dim3(256), 0, ctx->stream, mom,   \
+                     Nz, S, approx, d_coef)
   DISPATCH_ORDER(order, CALL)
 #undef CALL
   ORIGIN_LAUNCH_CHECK();
