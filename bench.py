@@ -120,7 +120,8 @@ def main():
     else:
         plan = kernels.GLRPlan(ctx, (Nz, ny, nx), field.PSF.astype(np.float64), None,
                                field.profiles, pcut=1e-8, pmeansub=True)
-    allreduce = comm.allreduce_sum if comm is not None else None
+    if comm is not None:
+        comm.attach(ctx)  # RCCL communicator on this context (collective)
 
     cube_std = ctx.empty((Nz, ny, nx), np.float32)
     cont_dct = ctx.empty((Nz, ny, nx), np.float32)
@@ -138,10 +139,8 @@ def main():
         t0 = time.perf_counter()
         coef = kernels.dct_fit(ctx, raw, var, mask, 10, False)
         zsum, zcnt = kernels.dct_resid_sums(ctx, raw, mask, coef)
-        if allreduce is not None:
-            both = allreduce(np.concatenate([zsum.to_host(), zcnt.to_host()]))
-            zsum.upload(both[:Nz])
-            zcnt.upload(both[Nz:])
+        if comm is not None:
+            comm.allreduce_sum_device(ctx, [zsum, zcnt])
         pre = kernels.dct_standardize(ctx, raw, var, mask, coef, zsum, zcnt, cube_std=cube_std,
                                       cont_dct=cont_dct)
         o2 = pre["o2"].to_host()

@@ -65,6 +65,25 @@ int origin_copy_box(origin_ctx *ctx, int kind, void *dst, long dst_pitch_y, long
                     const void *src, long src_pitch_y, long src_pitch_z, int nz, int ny,
                     int nx, int elem);
 
+/* ---- inter-GPU exchange (one process per GPU; RCCL over xGMI on the context's stream) ----
+ * The reference has no multi-GPU path (its only parallelism is the joblib pool of
+ * lib_origin.py:1150-1160); these serve the spatial tiling of origin_amd/multigpu.py.
+ * librccl.so is opened on first use.  origin_comm_unique_id is called on ONE rank and the
+ * ORIGIN_COMM_ID_BYTES blob handed to every rank by any host channel; origin_comm_create is
+ * collective.  allreduce / exchange are asynchronous on the context's stream. */
+#define ORIGIN_COMM_ID_BYTES 128
+typedef struct origin_comm origin_comm;
+int origin_comm_unique_id(char *id /* [ORIGIN_COMM_ID_BYTES] */);
+int origin_comm_create(origin_ctx *ctx, const char *id, int rank, int world, origin_comm **out);
+int origin_comm_destroy(origin_comm *comm);
+/* in-place sum over all ranks of n float64 (per-channel sum / count, steps.py:442) */
+int origin_comm_allreduce_f64(origin_comm *comm, double *d_buf, long n);
+/* grouped point-to-point: contiguous device buffers, sizes in bytes; every rank posts all
+ * its receives and sends in one group (halo strips of cube_faint before the GLR) */
+int origin_comm_exchange(origin_comm *comm, int nsend, const int *send_peer,
+                         const void *const *d_send, const long *send_bytes, int nrecv,
+                         const int *recv_peer, void *const *d_recv, const long *recv_bytes);
+
 /* HIP-event timers on the context's stream: slot in [0, 64). */
 int origin_timer_start(origin_ctx *ctx, int slot);
 int origin_timer_stop(origin_ctx *ctx, int slot);

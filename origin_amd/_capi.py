@@ -15,6 +15,7 @@ i32 = C.c_int
 i64 = C.c_long
 sz = C.c_size_t
 PP = C.POINTER
+COMM_ID_BYTES = 128  # ORIGIN_COMM_ID_BYTES
 
 # name -> argtypes  (every function returns int unless listed in _RESTYPE)
 SIGNATURES = {
@@ -34,6 +35,11 @@ SIGNATURES = {
     "origin_d2h": [vp, vp, vp, sz],
     "origin_d2d": [vp, vp, vp, sz],
     "origin_copy_box": [vp, i32, vp, i64, i64, vp, i64, i64, i32, i32, i32, i32],
+    "origin_comm_unique_id": [vp],
+    "origin_comm_create": [vp, vp, i32, i32, PP(vp)],
+    "origin_comm_destroy": [vp],
+    "origin_comm_allreduce_f64": [vp, vp, i64],
+    "origin_comm_exchange": [vp, i32, vp, vp, vp, i32, vp, vp, vp],
     "origin_timer_start": [vp, i32],
     "origin_timer_stop": [vp, i32],
     "origin_timer_ms": [vp, i32, PP(C.c_float)],

@@ -16,10 +16,10 @@ of kept spaxels only touch data inside the extension, and their border class is 
 with respect to the *true* field border because kept spaxels are at least P//2 away from any
 internal cut.  Only the interior tile is kept.
 
-Collectives go through ``torch.distributed`` -- backend ``nccl`` (RCCL over xGMI) on device
-buffers viewed zero-copy through ``__cuda_array_interface__``, or ``gloo`` with host staging
-(CPU tests; also the fallback if RCCL cannot be initialised).  torch is imported only here
-and only when more than one rank exists.
+Strips and the all-reduce go through RCCL called natively on the library's own stream
+(``origin_comm_*``, csrc/comm.hip); ``torch.distributed`` (gloo) is only the host-side
+rendezvous that carries the RCCL unique id, barriers and a few scalars -- see ``TileComm``.
+torch is imported only here and only when more than one rank exists.
 """
 import os
 from collections import namedtuple
@@ -86,9 +86,23 @@ class Tiling:
 
 
 # ------------------------------------------------------------------------------- comm
-class TorchComm:
-    """torch.distributed wrapper.  ``device_p2p`` is True when strips can travel GPU to GPU
-    (backend nccl == RCCL); otherwise they are staged through host memory."""
+class TileComm:
+    """Exchange layer of the tiled path.
+
+    Host side: a ``torch.distributed`` **gloo** group (rendezvous, barrier, a handful of host
+    scalars).  torch's GPU runtime is never touched: the wheel bundles its own ROCr/HIP, and
+    two ROCr instances cannot both acquire the GPU VM in one process -- whichever initialises
+    second reports "no GPU".  The cubes are this library's, so the device side is this
+    library's too:
+
+    * ``backend="rccl"`` (default): a native RCCL communicator on the context's stream
+      (``origin_comm_*`` in include/origin_hip.h), created lazily at the first device
+      operation (the context exists only then); its unique id travels over the gloo group.
+      Strips go GPU to GPU over xGMI; nothing is synchronised on the host.
+    * ``backend="gloo"``: strips are staged through host memory (CPU tests; one-GPU
+      rehearsal with several ranks on the same card, which RCCL refuses; fallback when the
+      RCCL communicator cannot be created on *any* rank -- all ranks then switch together).
+    """
 
     def __init__(self, rank, world, local_rank, backend=None):
         import torch
@@ -97,80 +111,133 @@ class TorchComm:
         self.rank, self.world, self.local_rank = rank, world, local_rank
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() and torch.cuda.device_count() >= world \
-                else "gloo"
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL
+        backend = backend or "rccl"
+        if backend not in ("rccl", "gloo"):
+            raise ValueError(f"backend must be 'rccl' or 'gloo', not {backend!r}")
         self.note = ""
         if not dist.is_initialized():
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        self._want_rccl = backend == "rccl"
+        self._native = None          # origin_comm* once attached
+        self._ctx = None
+        self.backend = backend
+
+    @property
+    def device_p2p(self):
+        return self._native is not None
+
+    # -- native communicator -----------------------------------------------------
+    def attach(self, ctx):
+        """Create the RCCL communicator on ``ctx`` (collective; no-op for gloo or when
+        already attached).  If any rank fails, every rank falls back to host staging."""
+        if not self._want_rccl or self._native is not None:
+            return
+        import ctypes as C
+        torch, dist = self.torch, self.dist
+        ident = torch.zeros(_capi.COMM_ID_BYTES + 1, dtype=torch.uint8)
+        err = ""
+        if self.rank == 0:
+            buf = C.create_string_buffer(_capi.COMM_ID_BYTES)
             try:
-                if backend == "nccl":
-                    torch.cuda.set_device(local_rank)
-                dist.init_process_group(backend=backend, rank=rank, world_size=world)
-            except Exception as exc:  # RCCL unavailable: host staging over gloo
-                if backend != "nccl":
-                    raise
-                self.note = f"nccl init failed ({exc}); gloo host staging"
-                backend = "gloo"
-                dist.init_process_group(backend=backend, rank=rank, world_size=world)
-        self.backend = dist.get_backend()
-        self.device_p2p = self.backend == "nccl"
-        self.dev = torch.device("cuda", local_rank) if self.device_p2p else torch.device("cpu")
+                _capi.call("origin_comm_unique_id", buf)
+                ident[:-1] = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8)
+                ident[-1] = 1
+            except Exception as exc:  # noqa: BLE001 -- reported through `note`
+                err = str(exc)
+        dist.broadcast(ident, src=0)
+        handle, ok = C.c_void_p(), 0
+        if int(ident[-1]) == 1:
+            try:
+                _capi.call("origin_comm_create", ctx.handle, bytes(ident[:-1].numpy().tobytes()),
+                           self.rank, self.world, C.byref(handle))
+                ok = 1
+            except Exception as exc:  # noqa: BLE001
+                err = str(exc)
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag[0]) == 1:
+            self._native, self._ctx = handle, ctx
+        else:
+            if ok:
+                _capi.call("origin_comm_destroy", handle)
+            self._want_rccl = False
+            self.backend = "gloo"
+            self.note = "rccl unavailable (" + (err or "failed on another rank") + \
+                        "); host staging over gloo"
 
     # -- small host collectives ------------------------------------------------
     def allreduce_sum(self, arr):
         t = self.torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64).copy())
-        if self.device_p2p:
-            t = t.to(self.dev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        return t.cpu().numpy()
+        return t.numpy()
+
+    def allreduce_sum_device(self, ctx, arrays):
+        """In-place sum over ranks of float64 DeviceArrays (per-channel sum and count)."""
+        self.attach(ctx)
+        if self._native is not None:
+            for a in arrays:
+                _capi.call("origin_comm_allreduce_f64", self._native, a.ptr, a.size)
+            return
+        host = self.allreduce_sum(np.concatenate([a.to_host().reshape(-1) for a in arrays]))
+        o = 0
+        for a in arrays:
+            a.upload(host[o: o + a.size].reshape(a.shape))
+            o += a.size
 
     def max_float(self, x):
-        t = self.torch.tensor([float(x)], dtype=self.torch.float64, device=self.dev)
+        t = self.torch.tensor([float(x)], dtype=self.torch.float64)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t.cpu()[0])
+        return float(t[0])
 
     def barrier(self):
-        if self.device_p2p:
-            self.dist.barrier(device_ids=[self.local_rank])
-        else:
-            self.dist.barrier()
+        self.dist.barrier()
 
     def close(self):
+        if self._native is not None:
+            _capi.call("origin_comm_destroy", self._native)
+            self._native = None
         if self.dist.is_initialized():
             self.dist.destroy_process_group()
 
     # -- strip exchange ----------------------------------------------------------
     def exchange(self, ctx, sends, recvs):
-        """sends / recvs: lists of (peer_rank, DeviceArray) -- contiguous float32 strips.
-        Every rank posts its receives and sends together (batched point-to-point)."""
-        torch, dist = self.torch, self.dist
+        """sends / recvs: lists of (peer_rank, DeviceArray) -- contiguous strips.  Every
+        rank posts its receives and sends together (grouped point-to-point)."""
         if not sends and not recvs:
             return
-        ctx.sync()
+        self.attach(ctx)
+        if self._native is not None:
+            import ctypes as C
+
+            def pack(items):
+                n = len(items)
+                return (n, (C.c_int * n)(*[p for p, _ in items]),
+                        (C.c_void_p * n)(*[b.ptr for _, b in items]),
+                        (C.c_long * n)(*[b.nbytes for _, b in items]))
+            ns, sp, sb, sl = pack(sends)
+            nr, rp, rb, rl = pack(recvs)
+            _capi.call("origin_comm_exchange", self._native, ns, sp, sb, sl, nr, rp, rb, rl)
+            return
+        torch, dist = self.torch, self.dist
         ops, host_recv = [], []
-        if self.device_p2p:
-            for peer, buf in recvs:
-                ops.append(dist.P2POp(dist.irecv, torch.as_tensor(buf, device=self.dev), peer))
-            for peer, buf in sends:
-                ops.append(dist.P2POp(dist.isend, torch.as_tensor(buf, device=self.dev), peer))
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-            torch.cuda.synchronize(self.dev)
-        else:
-            for peer, buf in recvs:
-                t = torch.empty(buf.shape, dtype=torch.float32)
-                host_recv.append((t, buf))
-                ops.append(dist.P2POp(dist.irecv, t, peer))
-            for peer, buf in sends:
-                ops.append(dist.P2POp(dist.isend, torch.from_numpy(buf.to_host()), peer))
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-            for t, buf in host_recv:
-                buf.upload(t.numpy())
+        for peer, buf in recvs:
+            t = torch.empty(buf.shape, dtype=torch.float32)
+            host_recv.append((t, buf))
+            ops.append(dist.P2POp(dist.irecv, t, peer))
+        for peer, buf in sends:
+            ops.append(dist.P2POp(dist.isend, torch.from_numpy(buf.to_host()), peer))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        for t, buf in host_recv:
+            buf.upload(t.numpy())
+
+
+TorchComm = TileComm  # earlier name
 
 
 def init_comm(rank, world, local_rank, backend=None):
-    return TorchComm(rank, world, local_rank, backend)
+    return TileComm(rank, world, local_rank, backend)
 
 
 # ------------------------------------------------------------------------------- halo
@@ -206,9 +273,10 @@ def halo_plan(tiling, rank, ny, nx):
     return plan
 
 
-def exchange_halo(ctx, comm, tiling, rank, cube, ext=None):
+def exchange_halo(ctx, comm, tiling, rank, cube, ext=None, bufs=None):
     """Build the halo-extended copy of this rank's (Nz, ny, nx) device tile.  Returns the
-    extended DeviceArray (Nz, ny + top + bot, nx + left + right)."""
+    extended DeviceArray (Nz, ny + top + bot, nx + left + right).  ``bufs``: a dict the
+    caller keeps between calls so that the strip buffers are allocated once."""
     Nz, ny, nx = cube.shape
     (_, _, _, _), (top, bot, left, right) = tiling.extended(rank)
     eshape = (Nz, ny + top + bot, nx + left + right)
@@ -222,9 +290,15 @@ def exchange_halo(ctx, comm, tiling, rank, cube, ext=None):
         for ph, peer, (sy, sx), (dy, dx), (by, bx) in plan:
             if ph != phase:
                 continue
-            sbuf = ctx.empty((Nz, by, bx), np.float32)
+            key = (phase, peer, Nz, by, bx)
+            if bufs is not None and key in bufs:
+                sbuf, rbuf = bufs[key]
+            else:
+                sbuf = ctx.empty((Nz, by, bx), np.float32)
+                rbuf = ctx.empty((Nz, by, bx), np.float32)
+                if bufs is not None:
+                    bufs[key] = (sbuf, rbuf)
             _copy_box(ctx, sbuf, sbuf.shape, (0, 0, 0), src, sshape, (0, sy, sx), (Nz, by, bx))
-            rbuf = ctx.empty((Nz, by, bx), np.float32)
             sends.append((peer, sbuf))
             recvs.append((peer, rbuf))
             unpack.append((rbuf, (0, dy, dx), (Nz, by, bx)))
@@ -278,12 +352,13 @@ class TiledGLR:
                         correl_min=ctx.empty(self.eshape, np.float32),
                         profile=ctx.empty(self.eshape, np.uint8))
         self._mask_set = False
+        self._strips = {}
 
     def run(self, cube_faint, mask, correl, profile, correl_min):
         ctx = self.ctx
         top, bot, left, right = self.halos
         Nz, ny, nx = self.shape
-        exchange_halo(ctx, self.comm, self.tiling, self.rank, cube_faint, self.ext)
+        exchange_halo(ctx, self.comm, self.tiling, self.rank, cube_faint, self.ext, self._strips)
         if mask is not None and not self._mask_set:  # halo spaxels are discarded: mask 0 there
             _copy_box(ctx, self.emask, self.eshape, (0, top, left), mask, mask.shape, (0, 0, 0),
                       (Nz, ny, nx))

@@ -15,13 +15,17 @@ from .thresholds import clipped_histograms, compute_thresh_gaussfit
 
 
 def preprocess(ctx, raw, var, mask, dct_order=10, dct_approx=False, allreduce=None,
-               want_cont=True):
+               want_cont=True, allreduce_dev=None):
     """DCT continuum + standardisation.  raw/var: float32 (Nz,Ny,Nx) DeviceArrays, mask
     uint8.  ``allreduce``: callable summing a float64 host vector over all ranks (the
-    per-channel mean of steps.py:442 is over the *whole* field when the cube is tiled)."""
+    per-channel mean of steps.py:442 is over the *whole* field when the cube is tiled);
+    ``allreduce_dev``: the same on the device, ``f(ctx, [DeviceArray, ...])`` in place
+    (``TileComm.allreduce_sum_device``: RCCL on the context's stream, no host round trip)."""
     coef = kernels.dct_fit(ctx, raw, var, mask, dct_order, dct_approx)
     zsum, zcnt = kernels.dct_resid_sums(ctx, raw, mask, coef)
-    if allreduce is not None:
+    if allreduce_dev is not None:
+        allreduce_dev(ctx, [zsum, zcnt])
+    elif allreduce is not None:
         both = np.concatenate([zsum.to_host(), zcnt.to_host()])
         both = allreduce(both)
         n = zsum.size

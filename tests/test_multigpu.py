@@ -108,3 +108,21 @@ def test_tiled_hip_equals_single_hip(tmp_path, world):
                             f.profiles, f.areamap, f.nbAreas)
     assert np.max(np.abs(stitch(tiles, "correl", shape) - ref["cube_correl"])) <= 2e-4
     assert np.max(np.abs(stitch(tiles, "maxmap", shape[1:]) - ref["maxmap"])) <= 2e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", ["torch-first", "lib-first"])
+def test_native_rccl_communicator_world1(order):
+    """The RCCL path of TileComm at world size 1 (all a one-GPU box allows): communicator from
+    a broadcast unique id, device all-reduce, grouped send/recv to self, on the library's own
+    stream and buffers -- with torch loaded before and after liborigin_hip.so (the two load
+    orders bind different HIP runtimes, see csrc/comm.hip)."""
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(free_port()))
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "rccl_self_check.py")]
+    if order == "lib-first":
+        cmd.append("--lib-first")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out[-3000:]
+    assert "backend rccl device_p2p True" in out, out[-3000:]
