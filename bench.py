@@ -26,6 +26,7 @@ from origin_amd import synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
+F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA (no sparsity)
 
 
 def _gen_chunk(args):
@@ -212,6 +213,7 @@ def main():
         "glr_spatial": ("mfma", 2.0 * 25 * 25 * local_vox),
         "glr_spectral": ("mfma", 2.0 * ntaps * local_vox),
     }
+    glr_precision = (glr.plan if world > 1 else plan).precision
     if world > 1:  # the GLR runs on the halo-extended tile
         ext_vox = float(Nz) * glr.eshape[1] * glr.eshape[2]
         algo["glr_spatial"] = ("mfma", 2.0 * 25 * 25 * ext_vox)
@@ -230,7 +232,12 @@ def main():
         if bound == "hbm":
             ach, peak, unit = per_launch / avg_s / 1e9, HBM_PEAK_GBS, "GB/s"
         else:
-            ach, peak, unit = per_launch / avg_s / 1e12, FP32_PEAK_TFLOPS, "TFLOP/s"
+            # the spectral stage runs on f16 matrix cores (3 MFMA terms per product, banded
+            # Toeplitz operand) unless the plan was told to stay in fp32; the spatial stage is
+            # fp32 packed FMA (vector = matrix rate for fp32 on gfx950)
+            f16 = dominant == "glr_spectral" and glr_precision == "f16x2"
+            ach, unit = per_launch / avg_s / 1e12, "TFLOP/s"
+            peak = F16_MFMA_PEAK_TFLOPS if f16 else FP32_PEAK_TFLOPS
         roofline = dict(bound=bound, kernel=dominant, achieved=round(ach, 3), peak=peak,
                         unit=unit, frac=round(ach / peak, 4), traffic=None,
                         avg_launch_ms=round(tot_ms / launches, 4), launches=launches)
@@ -273,7 +280,7 @@ def main():
             "config": {"workload": f"synthetic {Nz}x{N}x{N} cube, Dico_FWHM_2_12 "
                                    f"({args.nprof} profiles), PSF 25x25, 100x100 areas, "
                                    "dct_order 10, pfa 0.01, Noise_population 50, itermax 100",
-                       "tiles": world, "comm": (comm.backend + (" " + comm.note if comm.note else ""))
+                       "glr_spectral_arithmetic": glr_precision, "tiles": world, "comm": (comm.backend + (" " + comm.note if comm.note else ""))
                        if comm is not None else None, "pca": info,
                        "gen_seconds": round(t_gen, 1)},
             "roofline": roofline,

@@ -61,6 +61,8 @@ SIGNATURES = {
     "origin_o2_histogram_batch": [vp, vp, i32, C.c_double, i32, vp, vp, i64, vp],
     "origin_glr_plan_create": [vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, PP(vp)],
     "origin_glr_plan_destroy": [vp],
+    "origin_glr_plan_set_precision": [vp, i32],
+    "origin_glr_plan_get_precision": [vp, PP(i32)],
     "origin_glr_plan_bytes": [vp, PP(sz)],
     "origin_glr_work_elems": [vp, PP(sz)],
     "origin_glr_run": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],

@@ -22,6 +22,8 @@
 // cube, produced by the same stencil kernel, and den_k is convolved next to num_k.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -48,6 +50,9 @@ struct origin_glr_plan {
   int nborder;
   int lwt;         // template half width chosen for d_rows (8, 16, 24, 29 or 32; 0 = none)
   int NzP;
+  uint4 *d_atab;   // spectral_mfma_kernel: shifted hi/lo f16 tap copies [K][2][8][MF_GROUPS][8]
+  int *d_pwide;    // [K] 1 = half width > 16 (all 6 window blocks), 0 = blocks 1..4
+  int precision;   // 0 = fp32 FMA kernels, 1 = split-f16 MFMA spectral stage (when eligible)
   size_t bytes;
 };
 
@@ -657,6 +662,381 @@ __global__ __launch_bounds__(256) void spectral3_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------
+// spectral stage on the matrix cores.
+//
+// num_k[z] = sum_j p_k[j] x[z + lw_k - j] is a banded Toeplitz product: for a tile of 32 output
+// channels z0..z0+31 and the 96-channel window x[z0-32 .. z0+63],
+//     num_k[z0+m, s] = sum_{i=0}^{95} A_k[m][i] X[i][s],   A_k[m][i] = p_k[m + lw_k + 32 - i]
+// (zero outside the band), i.e. a [32 x 96] x [96 x N] GEMM per profile whose B operand -- the
+// data -- is shared by all K profiles.  fp32 MFMA runs at the vector rate, so the product is
+// evaluated with v_mfma_f32_32x32x16_f16 (16x that rate) on a two-term split of both
+// operands: y = x * 2^e (e per tile, from the tile's max |x|, so any input range is safe and
+// scaling the cube by a power of two scales the result exactly), y = yh + yl with yh = f16(y),
+// yl = f16(y - yh) -- 22 significant bits -- likewise the taps, and
+//     num = Ah Bh + Ah Bl + Al Bh      (the dropped Al Bl term is 2^-22 relative)
+// accumulated in fp32 by the matrix core.  Error vs float64: ~3e-7 of sum |p x|, the same
+// order as the fp32 FMA chain of spectral3_kernel (~1e-7); origin_glr_plan_set_precision
+// selects that kernel instead.
+//
+// A wave owns 64 consecutive spaxels (two 32-column B tiles, fragments loaded straight from
+// global memory: lane (r, h) holds X[16 ks + 8 h + j][r], 128-byte segments per half wave) and
+// marches z in tiles of 32.  The A fragments of a Toeplitz matrix are 8 consecutive entries of
+// one padded tap array G_k[e] = p_k[lw_k + 63 - e] starting at e = 16 ks + 8 h - m + 31; LDS
+// holds, per profile, 8 copies of G_k shifted by 0..7 elements (hi and lo halves) so that
+// every fragment is ONE aligned ds_read_b128 at a per-lane base plus an immediate offset.
+// Profiles whose half width is <= 16 only touch window blocks 1..4 (4 of the 6 k-steps).
+// Normalisation and border handling as in spectral3_kernel (interior class here, border
+// spaxels recomputed exactly by the list pass).
+// ------------------------------------------------------------------------------------
+#ifndef MF_EXPERIMENT
+#define MF_EXPERIMENT 0
+#endif
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+
+constexpr int MF_TAP_SCALE_LOG2 = 12;                 // taps are stored times 2^12
+constexpr int MF_GROUPS = 18;                         // 16-byte groups per shifted copy (15 used)
+constexpr int MF_COPY_BYTES = MF_GROUPS * 16;         // 288 = 256 + 32: bank-staggered copies
+constexpr int MF_PROF_BYTES = 2 * 8 * MF_COPY_BYTES;  // hi copies, then lo copies
+constexpr int MF_RD_BYTES = 32 * 4;                   // per wave and profile: 32 channels of 1/sqrt(den)
+constexpr int MF_MAX_K = 30;                          // 30 * (4608 + 4 * 128) B = 150 KiB of LDS
+constexpr int MF_BREG = 160;                          // B fragments live in a[160:255]
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void mf_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    mf_for<I + 1, N>(f);
+  }
+}
+
+// Register plan.  The data window (B fragments: 6 blocks x 2 column tiles x hi/lo x 4 dwords =
+// 96 registers, constant over all K profiles) is parked in the accumulator file a[160:255] by
+// hand and named literally in the MFMA instructions; results accumulate in VGPRs where the
+// VALU epilogue reads them directly.  (hipcc's own allocation kept the results in AGPRs and
+// moved everything through v_accvgpr_read/mov, which issue in order with the MFMAs: measured
+// wall time = VALU time + MFMA time.)  The compiler must not touch a[160:255]: the kernel is
+// written to stay below 256 VGPRs so that it allocates no AGPR at all (audit the .s for
+// v_accvgpr outside ASMSTART/ASMEND after every change; tests compare with the fp32 kernel).
+// Wait states the compiler cannot see (cdna_hip_programming.md 5.7): v_accvgpr_write -> MFMA
+// operand (s_nop 1 in the first MFMA of every profile) and MFMA result -> VALU reader (the
+// epilogue of a profile starts three MFMAs into the next one; a nop statement guards the last).
+template <int R>
+__device__ __forceinline__ void mf_put(const f16x8 &v) {
+  const u32x4v u = __builtin_bit_cast(u32x4v, v);
+  asm volatile("v_accvgpr_write_b32 a[%c4], %0\n\tv_accvgpr_write_b32 a[%c5], %1\n\t"
+               "v_accvgpr_write_b32 a[%c6], %2\n\tv_accvgpr_write_b32 a[%c7], %3"
+               :
+               : "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]), "n"(R), "n"(R + 1), "n"(R + 2),
+                 "n"(R + 3));
+}
+// fragment (block ks, column tile t, hi/lo) -> first register
+__host__ __device__ constexpr int mf_breg(int ks, int t, int lo) {
+  return MF_BREG + 4 * ((ks * 2 + t) * 2 + lo);
+}
+template <int R, bool FIRST>
+__device__ __forceinline__ void mf_mma(f32x16 &acc, const f16x8 &a) {
+  if constexpr (FIRST)
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, a[%c2:%c3], 0"
+                 : "=&v"(acc)
+                 : "v"(a), "n"(R), "n"(R + 3));
+  else
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[%c2:%c3], %0"
+                 : "+v"(acc)
+                 : "v"(a), "n"(R), "n"(R + 3));
+}
+
+__device__ __forceinline__ float mf_min(float a, float b) {
+  float r;  // plain v_min_f32: fminf() adds a canonicalising v_max per operand
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// running first-maximum / argmax / minimum over the profiles for accumulator element E
+// (E = 2 i + t: register i of column tile t; register i of lane (r, h) is channel
+// z0 + (i&3) + 8 (i>>2) + 4 h)
+template <int E>
+__device__ __forceinline__ void mf_epi1(const f32x16 (&acc)[2], const f32x4v (&f)[4], int k,
+                                        f32x16 (&best)[2], int (&bk)[2][16],
+                                        f32x16 (&worst)[2]) {
+  constexpr int t = E & 1, i = E >> 1;
+  const float T = acc[t][i] * f[i >> 2][i & 3];
+  const bool gt = T > best[t][i];  // strict '>' : the first maximum wins   (lib :1210)
+  best[t][i] = gt ? T : best[t][i];
+  bk[t][i] = gt ? k : bk[t][i];
+  worst[t][i] = mf_min(worst[t][i], T);
+}
+
+// One profile: its 24 (narrow: window blocks 1..4) or 36 (wide: 0..5) MFMAs into `acc`, with the
+// epilogue of the PREVIOUS profile (results in `prev`) dealt out between them -- one MFMA
+// holds the matrix pipe for 32 cycles, an epilogue element is five 4-cycle VALU issues.
+// (ah, al) arrive holding the A fragments of the first window block and leave holding those
+// of the next profile's first block (`a_next`), so no LDS latency is exposed between profiles.
+template <bool WIDE, bool EPI>
+__device__ __forceinline__ void mf_step(const char *__restrict__ ak,
+                                        const char *__restrict__ a_next, f16x8 &ah, f16x8 &al,
+                                        f32x16 (&acc)[2], const f32x16 (&prev)[2],
+                                        const char *__restrict__ rd_prev, float inv, int kprev,
+                                        f32x16 (&best)[2], int (&bk)[2][16],
+                                        f32x16 (&worst)[2]) {
+  constexpr int KS0 = WIDE ? 0 : 1, NKS = WIDE ? 6 : 4, NM = 6 * NKS;
+  // 1/sqrt(den) of the previous profile for this lane's 16 channels, times the unscaling factor
+  f32x4v f[4];
+  if constexpr (EPI) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      f[g] = *reinterpret_cast<const f32x4v *>(rd_prev + 32 * g) * inv;
+  }
+  f16x8 nh, nl;
+  mf_for<0, NM>([&](auto ic) {
+    constexpr int idx = decltype(ic)::value;
+    constexpr int g = idx / 6, sub = idx % 6, ks = KS0 + g, t = sub & 1;
+    if constexpr (sub == 0) {
+      // fragments of the next window block (or of the next profile) are requested a block ahead
+      const char *src = g + 1 < NKS ? ak + (ks + 1) * 32 : a_next;
+      nh = *reinterpret_cast<const f16x8 *>(src);
+      nl = *reinterpret_cast<const f16x8 *>(src + 8 * MF_COPY_BYTES);
+    }
+    // ah Bh, ah Bl, al Bh
+#if MF_EXPERIMENT != 2
+    mf_mma<mf_breg(ks, t, (sub >> 1) == 1), (idx < 2)>(acc[t], sub < 4 ? ah : al);
+#else
+    if (idx < 2) acc[t] = (f32x16)(0.0f) + (float)(sub < 4 ? ah : al)[0];
+#endif
+    if constexpr (EPI && MF_EXPERIMENT != 1) {
+      if constexpr (WIDE) {  // MFMAs 3..34: one element each
+        if constexpr (idx >= 3 && idx < 35) mf_epi1<idx - 3>(prev, f, kprev, best, bk, worst);
+      } else if constexpr (idx >= 3) {  // MFMAs 3..23: two elements after the first 11, then one
+        constexpr int sl = idx - 3;
+        if constexpr (sl < 11) {
+          mf_epi1<2 * sl>(prev, f, kprev, best, bk, worst);
+          mf_epi1<2 * sl + 1>(prev, f, kprev, best, bk, worst);
+        } else {
+          mf_epi1<sl + 11>(prev, f, kprev, best, bk, worst);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the hand-made interleave
+    if constexpr (sub == 5) {
+      ah = nh;
+      al = nl;
+    }
+  });
+}
+
+__global__ __launch_bounds__(256, 1) void spectral_mfma_kernel(
+    const float *__restrict__ fsf, const float *__restrict__ rdi, int NzP,
+    const uint4 *__restrict__ atab, const int *__restrict__ pwide, int K, int Nz, long S,
+    int zchunk, const uint8_t *__restrict__ mask, float *__restrict__ correl,
+    uint8_t *__restrict__ profile, float *__restrict__ correl_min, float *__restrict__ part_max,
+    float *__restrict__ part_min) {
+  extern __shared__ __align__(16) char mf_lds[];
+  // reserve a[160:255] in the kernel descriptor (nothing is emitted)
+  asm volatile("" ::: "a160", "a255");
+  {
+    const int nvec = K * (MF_PROF_BYTES / 16);
+    for (int i = threadIdx.x; i < nvec; i += 256) reinterpret_cast<uint4 *>(mf_lds)[i] = atab[i];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const long s_base = ((long)blockIdx.x * 4 + wv) * 64;
+  if (s_base >= S) return;  // whole wave; no barrier follows
+  const int zc0 = blockIdx.y * zchunk, zc1 = min(Nz, zc0 + zchunk);
+  const int E0 = 8 * h - r + 31;
+  const char *a_lane = mf_lds + (E0 & 7) * MF_COPY_BYTES + (E0 >> 3) * 16;
+  // this wave's [K][32] table of 1/sqrt(den) for the current tile (behind the tap copies)
+  char *rd_wave = mf_lds + K * MF_PROF_BYTES + wv * K * MF_RD_BYTES;
+  const char *rd_lane = rd_wave + 16 * h;  // channels 4h..4h+3 of each group of 8
+  long sc[2];
+  bool sv[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const long s = s_base + 32 * t + r;
+    sv[t] = s < S;
+    sc[t] = sv[t] ? s : S - 1;
+  }
+  float vmax[2] = {-INFINITY, -INFINITY}, vmin[2] = {INFINITY, INFINITY};
+
+  for (int z0 = zc0; z0 < zc1; z0 += 32) {
+    // ---- 1/sqrt(den)[k][z0 .. z0+31] -> LDS (the previous tile's readers are done: same wave)
+    {
+      float rv[MF_MAX_K / 2];  // all requests in flight together
+#pragma unroll
+      for (int q = 0; q < MF_MAX_K / 2; ++q) {
+        const int i = lane + 64 * q;
+        rv[q] = i < K * 32 ? rdi[(long)(i >> 5) * NzP + z0 + (i & 31)] : 0.0f;
+      }
+#pragma unroll
+      for (int q = 0; q < MF_MAX_K / 2; ++q) {
+        const int i = lane + 64 * q;
+        if (i < K * 32) reinterpret_cast<float *>(rd_wave)[i] = rv[q];
+      }
+    }
+    // ---- window X[z0-32 .. z0+63] of both column tiles, in B-fragment order
+    float x[6][2][8];
+    const int zb = z0 - 32 + 8 * h;
+    if (z0 - 32 >= 0 && z0 + 64 <= Nz) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const float *p = fsf + (long)zb * S + sc[t];
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) x[ks][t][j] = p[(long)(16 * ks + j) * S];
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int zz = zb + 16 * ks + j;
+            const bool in = zz >= 0 && zz < Nz;
+            const float v = fsf[(long)(in ? zz : 0) * S + sc[t]];
+            x[ks][t][j] = in ? v : 0.0f;
+          }
+    }
+    // ---- power-of-two scale of this tile: max |y| in [2^14, 2^15)
+    float m = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(sv[t] ? x[ks][t][j] : 0.0f));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    const int ex = (int)((__float_as_uint(m) >> 23) & 0xffu);
+    const bool tiny = ex < 40 || ex == 255;  // zero / denormal-small / non-finite: no scaling
+    const float scale = __uint_as_float((unsigned)(tiny ? 127 : 268 - ex) << 23);
+    // 2^-(e + MF_TAP_SCALE_LOG2): undoes both scalings, exactly
+    const float inv = __uint_as_float((unsigned)(tiny ? 127 - MF_TAP_SCALE_LOG2
+                                                      : ex - 14 - MF_TAP_SCALE_LOG2) << 23);
+    // ---- split into f16 hi + lo and park the fragments in a[160:255]
+    mf_for<0, 12>([&](auto ic) {
+      constexpr int ks = decltype(ic)::value >> 1, t = decltype(ic)::value & 1;
+      f16x8 yh8, yl8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float y = x[ks][t][j] * scale;
+        const _Float16 yh = (_Float16)y;
+        yh8[j] = yh;
+        yl8[j] = (_Float16)(y - (float)yh);
+      }
+      mf_put<mf_breg(ks, t, 0)>(yh8);
+      mf_put<mf_breg(ks, t, 1)>(yl8);
+    });
+
+    f32x16 best[2], worst[2];
+    int bk[2][16];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) best[t][i] = -INFINITY, worst[t][i] = INFINITY, bk[t][i] = 0;
+
+    // software pipeline over profiles: the MFMAs of profile k run while the VALU works off
+    // the epilogue of profile k-1 from the other accumulator set
+    f32x16 accA[2], accB[2];
+    f16x8 ah, al;
+    auto first_block = [&](int k) -> const char * {  // A fragments of profile k's first block
+      const int kk = k < K ? k : 0;
+      return a_lane + kk * MF_PROF_BYTES + (pwide[kk] ? 0 : 32);
+    };
+    {
+      const char *p0 = first_block(0);
+      ah = *reinterpret_cast<const f16x8 *>(p0);
+      al = *reinterpret_cast<const f16x8 *>(p0 + 8 * MF_COPY_BYTES);
+    }
+#define MF_STEP(EPI, K_, ACC, PREV)                                                            \
+  do {                                                                                         \
+    const char *ak_ = a_lane + (K_) * MF_PROF_BYTES;                                           \
+    const char *an_ = first_block((K_) + 1);                                                   \
+    const char *rp_ = rd_lane + ((K_) - 1) * MF_RD_BYTES;                                      \
+    if (pwide[K_])                                                                             \
+      mf_step<true, EPI>(ak_, an_, ah, al, ACC, PREV, rp_, inv, (K_) - 1, best, bk, worst);    \
+    else                                                                                       \
+      mf_step<false, EPI>(ak_, an_, ah, al, ACC, PREV, rp_, inv, (K_) - 1, best, bk, worst);   \
+  } while (0)
+    MF_STEP(false, 0, accA, accB);
+    int k = 1;
+    for (; k + 1 < K; k += 2) {
+      MF_STEP(true, k, accB, accA);
+      MF_STEP(true, k + 1, accA, accB);
+    }
+    // mask bytes of the 32 outputs: requested before the last epilogue so that they land
+    // behind it
+    unsigned char mk[2][16];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mk[t][i] = 0;
+    if (mask) {  // branch-free inside: every load is issued before the first is awaited
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int zz = min(z0 + (i & 3) + 8 * (i >> 2) + 4 * h, Nz - 1);
+          mk[t][i] = mask[(long)zz * S + sc[t]];
+        }
+    }
+    {
+      f32x4v f[4];
+      if (k < K) {  // K even: one more profile, into B
+        MF_STEP(true, k, accB, accA);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          f[g] = *reinterpret_cast<const f32x4v *>(rd_lane + k * MF_RD_BYTES + 32 * g) * inv;
+        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(accB[0]), "+v"(accB[1]));  // MFMA D -> VALU
+        mf_for<0, 32>([&](auto ic) { mf_epi1<decltype(ic)::value>(accB, f, k, best, bk, worst); });
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          f[g] = *reinterpret_cast<const f32x4v *>(rd_lane + (K - 1) * MF_RD_BYTES + 32 * g) * inv;
+        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(accA[0]), "+v"(accA[1]));
+        mf_for<0, 32>([&](auto ic) { mf_epi1<decltype(ic)::value>(accA, f, K - 1, best, bk, worst); });
+      }
+    }
+#undef MF_STEP
+
+    // ---- store, mask glue (steps.py:781,788)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int zz = z0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (zz < zc1) {
+          const long idx = (long)zz * S + sc[t];
+          float b = best[t][i];
+          int kk = bk[t][i];
+          if (mk[t][i]) b = 0.0f, kk = 0;
+          if (sv[t]) {
+            correl[idx] = b;
+            correl_min[idx] = worst[t][i];
+            profile[idx] = (uint8_t)kk;
+          }
+          vmax[t] = fmaxf(vmax[t], b);
+          vmin[t] = fminf(vmin[t], worst[t][i]);
+        }
+      }
+  }
+  if (part_max) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float a = fmaxf(vmax[t], __shfl_xor(vmax[t], 32));
+      const float b = fminf(vmin[t], __shfl_xor(vmin[t], 32));
+      if (h == 0 && sv[t]) {
+        part_max[(long)blockIdx.y * S + sc[t]] = a;
+        part_min[(long)blockIdx.y * S + sc[t]] = b;
+      }
+    }
+  }
+}
+
 // fallback for profiles wider than the register window: plain loops over global memory
 template <bool GENERAL>
 __global__ __launch_bounds__(256) void spectral_generic_kernel(
@@ -819,7 +1199,8 @@ int origin_glr_plan_destroy(origin_glr_plan *plan) {
   for (void *p : {(void *)plan->d_k, (void *)plan->d_k2, (void *)plan->d_w, (void *)plan->d_taps,
                   (void *)plan->d_taps2, (void *)plan->d_tap_off, (void *)plan->d_rden,
                   (void *)plan->d_htaps, (void *)plan->d_htap_off, (void *)plan->d_rows,
-                  (void *)plan->d_rdi, (void *)plan->d_border})
+                  (void *)plan->d_rdi, (void *)plan->d_border, (void *)plan->d_atab,
+                  (void *)plan->d_pwide})
     if (p) (void)hipFree(p);
   delete plan;
   return ORIGIN_OK;
@@ -914,7 +1295,7 @@ int origin_glr_plan_create(origin_ctx *ctx, int Nz, int Ny, int Nx, int nfields,
   TRY(upload(ctx, htaps, &pl->d_htaps, &pl->bytes));
   TRY(upload(ctx, hoff, &pl->d_htap_off, &pl->bytes));
   pl->lwt = 0;
-  pl->NzP = (Nz + 3) / 4 * 4 + 8;
+  pl->NzP = (Nz + 31) / 32 * 32 + 32;  // spectral_mfma_kernel reads whole 32-channel tiles
   if (lwmax <= 32) {
     const int lwt = lwmax <= 8 ? 8 : lwmax <= 16 ? 16 : lwmax <= 24 ? 24 : lwmax <= 29 ? 29 : 32;
     const int RL = (2 * lwt + 1 + 15) / 16 * 16 + 16;  // [lw | taps padded to 16s]
@@ -926,6 +1307,32 @@ int origin_glr_plan_create(origin_ctx *ctx, int Nz, int Ny, int Nx, int nfields,
     }
     TRY(upload(ctx, rows, &pl->d_rows, &pl->bytes));
     pl->lwt = lwt;
+  }
+  // spectral_mfma_kernel: padded tap arrays G_k[e] = p_k[lw_k + 63 - e], e = 0..(8 MF_GROUPS + 6),
+  // split into f16 hi + lo (times 2^MF_TAP_SCALE_LOG2), 8 copies shifted by 0..7 elements
+  if (lwmax <= 32 && K <= MF_MAX_K && pl->mode == 0) {
+    std::vector<_Float16> at((size_t)K * MF_PROF_BYTES / 2, (_Float16)0.0f);
+    std::vector<int> pwide(K, 0);
+    const float tscale = (float)(1 << MF_TAP_SCALE_LOG2);
+    for (int kk = 0; kk < K; ++kk) {
+      const int L = off[kk + 1] - off[kk], lw = (L - 1) / 2;
+      pwide[kk] = lw > 16;
+      for (int c = 0; c < 8; ++c)
+        for (int q = 0; q < MF_GROUPS; ++q)
+          for (int j = 0; j < 8; ++j) {
+            const int e = 8 * q + c + j, ti = lw + 63 - e;
+            const float g = (ti >= 0 && ti < L) ? taps[off[kk] + ti] * tscale : 0.0f;
+            const _Float16 gh = (_Float16)g;
+            const _Float16 gl = (_Float16)(g - (float)gh);
+            const size_t base = (size_t)kk * (MF_PROF_BYTES / 2) + (size_t)c * (MF_COPY_BYTES / 2) +
+                                (size_t)q * 8 + j;
+            at[base] = gh;
+            at[base + 8 * (MF_COPY_BYTES / 2)] = gl;
+          }
+    }
+    TRY(upload(ctx, at, (_Float16 **)&pl->d_atab, &pl->bytes));
+    TRY(upload(ctx, pwide, &pl->d_pwide, &pl->bytes));
+    pl->precision = getenv("ORIGIN_GLR_FP32") ? 0 : 1;
   }
   // scalar loads may read a few taps past the end of a profile row: pad
   for (int i = 0; i < 64; ++i) {
@@ -984,6 +1391,18 @@ int origin_glr_plan_create(origin_ctx *ctx, int Nz, int Ny, int Nx, int nfields,
   }
 #undef TRY
   *out = pl;
+  return ORIGIN_OK;
+}
+
+int origin_glr_plan_set_precision(origin_glr_plan *plan, int precision) {
+  ORIGIN_CHECK_ARG(plan && (precision == 0 || precision == 1), "precision must be 0 or 1");
+  plan->precision = (precision == 1 && plan->d_atab) ? 1 : 0;
+  return ORIGIN_OK;
+}
+
+int origin_glr_plan_get_precision(origin_glr_plan *plan, int *precision) {
+  ORIGIN_CHECK_ARG(plan && precision, "null argument");
+  *precision = plan->precision;
   return ORIGIN_OK;
 }
 
@@ -1084,7 +1503,31 @@ int origin_glr_run(origin_ctx *ctx, origin_glr_plan *pl, const float *d_cube,
   bool border_fix = false;
   {
   ProfScope ps(ctx, K_GLR_SPECTRAL);
-  if (!gen && (S & 1) == 0 && pl->lwt) {
+  const bool mfma = !gen && pl->precision == 1 && pl->d_atab && pl->d_rdi;
+  const bool packed = !mfma && !gen && (S & 1) == 0 && pl->lwt;
+  if (mfma) {
+    // matrix-core path: a wave = 64 spaxels x 32-channel tiles; z chunks sized to give every CU
+    // several blocks (one 4-wave block per CU at a time: K * 4.5 KiB of LDS)
+    const long bx = cdiv(S, 256);
+    int nzm = (int)(((long)ctx->num_cu * 8 + bx - 1) / bx);
+    nzm = std::max(1, std::min(nzm, std::min(64, cdiv(Nz, 64))));
+    int zcm = (cdiv(Nz, nzm) + 31) / 32 * 32;
+    nzm = cdiv(Nz, zcm);
+    nzc = nzm;
+    pmax = want_maps ? part : nullptr;
+    pmin = want_maps ? part + (size_t)nzc * S : nullptr;
+    const size_t lds = (size_t)K * (MF_PROF_BYTES + 4 * MF_RD_BYTES);
+    static bool attr_done = false;
+    if (!attr_done) {
+      ORIGIN_HIP(hipFuncSetAttribute((const void *)spectral_mfma_kernel,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     MF_MAX_K * (MF_PROF_BYTES + 4 * MF_RD_BYTES)));
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(spectral_mfma_kernel, dim3((unsigned)bx, nzm), dim3(256), lds, ctx->stream,
+                       fsf, pl->d_rdi, pl->NzP, pl->d_atab, pl->d_pwide, K, Nz, S, zcm, d_mask,
+                       d_correl, d_profile, d_correl_min, pmax, pmin);
+  } else if (packed) {
     // packed path: one lane = two adjacent spaxels, SPEC_ZC channels per step
     dim3 g2(cdiv(S / 2, 256), nzc);
 #define LAUNCH3(LW)                                                                            \
@@ -1098,25 +1541,6 @@ int origin_glr_run(origin_ctx *ctx, origin_glr_plan *pl, const float *d_cube,
       case 29: LAUNCH3(29); break;
       default: LAUNCH3(32); break;
     }
-    if (pl->nborder > 0) {  // border spaxels: exact per-class normalisation
-      origin_prof_end_begin(ctx, K_GLR_BORDER);
-      // few spaxels: cut z finer so that the pass still fills the chip (its maps are redone
-      // from the final cubes below, so it writes no partials)
-      const long bb = cdiv(pl->nborder, 256);
-      int nzb = (int)(((long)ctx->num_cu * 12 + bb - 1) / bb);
-      nzb = std::max(1, std::min(nzb, Nz / (4 * std::max(pl->lwmax, 1) + 4)));
-      nzb = std::max(nzb, 1);
-      const int zcb = cdiv(Nz, nzb);
-      dim3 gb((unsigned)bb, cdiv(Nz, zcb));
-      border_fix = true;
-#define LAUNCHB(LW)                                                                            \
-  hipLaunchKernelGGL((spectral_kernel<LW, false>), gb, block, 0, ctx->stream, fsf, norm,       \
-                     pl->d_rden, pl->d_taps, pl->d_taps2, pl->d_tap_off, K, pl->Kp, Nz, Ny, Nx, \
-                     P, zcb, d_mask, d_correl, d_profile, d_correl_min, (float *)nullptr,      \
-                     (float *)nullptr, pl->d_border, pl->nborder)
-      if (pl->lwmax <= 8) LAUNCHB(8); else if (pl->lwmax <= 16) LAUNCHB(16); else LAUNCHB(32);
-#undef LAUNCHB
-    }
 #undef LAUNCH3
   } else if (pl->lwmax <= 8) {
     if (gen) LAUNCH((spectral_kernel<8, true>)); else LAUNCH((spectral_kernel<8, false>));
@@ -1126,6 +1550,25 @@ int origin_glr_run(origin_ctx *ctx, origin_glr_plan *pl, const float *d_cube,
     if (gen) LAUNCH((spectral_kernel<32, true>)); else LAUNCH((spectral_kernel<32, false>));
   } else {
     if (gen) LAUNCH((spectral_generic_kernel<true>)); else LAUNCH((spectral_generic_kernel<false>));
+  }
+  if ((mfma || packed) && pl->nborder > 0) {  // border spaxels: exact per-class normalisation
+    origin_prof_end_begin(ctx, K_GLR_BORDER);
+    // few spaxels: cut z finer so that the pass still fills the chip (its maps are redone
+    // from the final cubes below, so it writes no partials)
+    const long bb = cdiv(pl->nborder, 256);
+    int nzb = (int)(((long)ctx->num_cu * 12 + bb - 1) / bb);
+    nzb = std::max(1, std::min(nzb, Nz / (4 * std::max(pl->lwmax, 1) + 4)));
+    nzb = std::max(nzb, 1);
+    const int zcb = cdiv(Nz, nzb);
+    dim3 gb((unsigned)bb, cdiv(Nz, zcb));
+    border_fix = true;
+#define LAUNCHB(LW)                                                                            \
+hipLaunchKernelGGL((spectral_kernel<LW, false>), gb, block, 0, ctx->stream, fsf, norm,       \
+                   pl->d_rden, pl->d_taps, pl->d_taps2, pl->d_tap_off, K, pl->Kp, Nz, Ny, Nx, \
+                   P, zcb, d_mask, d_correl, d_profile, d_correl_min, (float *)nullptr,      \
+                   (float *)nullptr, pl->d_border, pl->nborder)
+    if (pl->lwmax <= 8) LAUNCHB(8); else if (pl->lwmax <= 16) LAUNCHB(16); else LAUNCHB(32);
+#undef LAUNCHB
   }
   }
 #undef LAUNCH

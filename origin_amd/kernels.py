@@ -87,7 +87,12 @@ class GLRPlan:
     """Device-side constants of a GLR run: zero-mean PSFs, weights, prepared profiles and
     normalisation tables (include/origin_hip.h: origin_glr_plan)."""
 
-    def __init__(self, ctx, shape, fsf, weights, profiles, pcut=None, pmeansub=True):
+    def __init__(self, ctx, shape, fsf, weights, profiles, pcut=None, pmeansub=True,
+                 precision=None):
+        """``precision``: None = library default, "f16x2" = spectral stage on the matrix cores
+        (two-term f16 split, fp32 accumulation), "f32" = fp32 FMA kernels.  ``self.precision``
+        tells what the plan will run (plans with weight maps or very wide profiles only have
+        "f32")."""
         Nz, Ny, Nx = (int(s) for s in shape)
         self.ctx, self.shape = ctx, (Nz, Ny, Nx)
         if weights is None:  # one FSF                         (lib_origin.py:1112-1114)
@@ -123,6 +128,13 @@ class GLRPlan:
         _capi.call("origin_glr_plan_bytes", self._h, C.byref(n))
         self.nbytes = n.value
         self._work = None
+        if precision is not None:
+            if precision not in ("f32", "f16x2"):
+                raise ValueError("precision must be None, 'f32' or 'f16x2'")
+            _capi.call("origin_glr_plan_set_precision", self._h, int(precision == "f16x2"))
+        got = C.c_int()
+        _capi.call("origin_glr_plan_get_precision", self._h, C.byref(got))
+        self.precision = "f16x2" if got.value == 1 else "f32"
 
     def close(self):
         if self._h is not None and self._h.value:

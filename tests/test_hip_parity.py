@@ -13,6 +13,7 @@ import numpy as np
 import pytest
 
 from oracle import cpu_ref
+from origin_amd import synth
 from oracle import golden_cases as gc
 
 pytestmark = pytest.mark.gpu
@@ -207,6 +208,53 @@ def test_glr_golden(hip, name):
     assert np.max(np.abs(correl - g[name + "_correl"])) <= 1e-4
     assert np.max(np.abs(correl_min - g[name + "_correl_min"])) <= 1e-4
     assert np.mean(profile != g[name + "_profile"]) <= 1e-4
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x2"])
+@pytest.mark.parametrize("name", list("ade"))
+def test_glr_golden_both_arithmetics(ctx, name, precision):
+    """The spectral stage exists twice for plans without weight maps: matrix cores on a
+    two-term f16 split (default) and the fp32 FMA kernel.  Both against the reference's output
+    (case d has asymmetric profiles: the Toeplitz operand orientation shows there)."""
+    from origin_amd import kernels
+    g = load("g5_glr")
+    c = gc.g5_inputs()[name]
+    plan = kernels.GLRPlan(ctx, c["cube"].shape, c["fsf"], None, c["profiles"], c["pcut"],
+                           c["pmeansub"], precision=precision)
+    assert plan.precision == precision
+    out = plan.run(ctx.to_device(c["cube"], np.float32), mask=None, want_maps=True)
+    correl, cmin = out["correl"].to_host(), out["correl_min"].to_host()
+    assert np.max(np.abs(correl - g[name + "_correl"])) <= 1e-4
+    assert np.max(np.abs(cmin - g[name + "_correl_min"])) <= 1e-4
+    assert np.mean(out["profile"].to_host() != g[name + "_profile"]) <= 1e-4
+    assert np.max(np.abs(out["maxmap"].to_host() - g[name + "_correl"].max(axis=0))) <= 1e-4
+    plan.close()
+
+
+def test_glr_f16_split_survives_huge_dynamic_range(ctx):
+    """Per-tile power-of-two scaling: slabs of channels at 1e-6, 1 and 1e+7 times unit noise must
+    neither overflow the f16 halves nor lose the faint slabs.  Error bound relative to the
+    largest |T| within the 96-channel window a tile shares (float64 oracle)."""
+    from scipy.ndimage import maximum_filter1d
+    from origin_amd import kernels
+    rng = np.random.default_rng(77)
+    Nz, Ny, Nx = 448, 26, 30
+    amp = np.repeat([1e-6, 1.0, 1e7, 1e-3, 1e3, 1.0, 1e-6], 64)[:, None, None]
+    cube = (rng.standard_normal((Nz, Ny, Nx)) * amp).astype(np.float32)
+    psf = synth.moffat_psf(Nz, 25).astype(np.float64)
+    prof = synth.dico_fwhm(20)
+    ref = cpu_ref.Correlation_GLR_test(cube.astype(np.float64), psf, None, prof, nthreads=1,
+                                       pcut=1e-8, pmeansub=True)
+    plan = kernels.GLRPlan(ctx, cube.shape, psf, None, prof, 1e-8, True, precision="f16x2")
+    assert plan.precision == "f16x2"
+    out = plan.run(ctx.to_device(cube), mask=None, want_maps=False)
+    got, gmin = out["correl"].to_host(), out["correl_min"].to_host()
+    assert np.all(np.isfinite(got)) and np.all(np.isfinite(gmin))
+    local = maximum_filter1d(np.abs(ref[0]).max(axis=(1, 2)), size=193, mode="nearest")
+    tol = 3e-6 * local[:, None, None]
+    assert np.all(np.abs(got - ref[0]) <= tol)
+    assert np.all(np.abs(gmin - ref[2]) <= tol)
+    plan.close()
 
 
 def test_glr_wide_profiles_fallback(hip):
