@@ -39,13 +39,13 @@ struct origin_glr_plan {
   float *d_taps;  // concatenated profiles (odd lengths; even ones padded with a 0 tap)
   float *d_taps2; // squares
   int *d_tap_off; // [K+1]
-  float *d_rden;  // mode 0: [P*P][Nz][Kp], Kp = K rounded up to 4
-  int Kp;
+  float *d_rden;  // mode 0: [P*P][K][NzP]  1/sqrt(den) per border class (0 for z >= Nz)
+  int Kp;         // z stride of d_rden (= NzP)
   int symmetric;   // every prepared profile is exactly symmetric about its centre
   float *d_htaps;  // symmetric case: half profiles h_k[d] = p_k[lw_k + d], d = 0..lw_k
   int *d_htap_off; // [K+1]
   float *d_rows;   // [K+1][RL] rows (lw, p[0..2 lw]) for spectral3_kernel<LWT>
-  float *d_rdi;    // mode 0: interior-class 1/sqrt(den), transposed [K][NzP]
+  float *d_rdi;    // mode 0: interior-class slice of d_rden, [K][NzP] (not owned)
   int *d_border;   // mode 0: flat indices of the spaxels whose border class is not interior
   int nborder;
   int lwt;         // template half width chosen for d_rows (8, 16, 24, 29 or 32; 0 = none)
@@ -313,18 +313,20 @@ __global__ __launch_bounds__(256) void norm_classes_kernel(const float *__restri
   ncls[i] = acc;
 }
 
-// rden[cls][z][k] = 1/sqrt(sum_j p_k[j]^2 normcls[z + lw - j][cls])   (0 if den <= 0)
+// rden[cls][k][z] = 1/sqrt(sum_j p_k[j]^2 normcls[z + lw - j][cls])   (0 if den <= 0 or z >= Nz)
+// z is the fastest axis (stride NzP, a multiple of 32): a lane of the matrix-core kernel
+// fetches the four consecutive channels of an accumulator group with one 16-byte load.
 __global__ __launch_bounds__(256) void rden_kernel(const double *__restrict__ ncls,
                                                    const float *__restrict__ taps2,
                                                    const int *__restrict__ tap_off, int K, int Nz,
-                                                   int PP, int Kp, float *__restrict__ rden) {
+                                                   int PP, int NzP, float *__restrict__ rden) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  const long n = (long)PP * Kp * Nz;
+  const long n = (long)PP * K * NzP;
   if (i >= n) return;
-  const int k = (int)(i % Kp);
-  const int z = (int)((i / Kp) % Nz);
-  const int cls = (int)(i / ((long)Nz * Kp));
-  if (k >= K) {
+  const int z = (int)(i % NzP);
+  const int k = (int)((i / NzP) % K);
+  const int cls = (int)(i / ((long)NzP * K));
+  if (z >= Nz) {
     rden[i] = 0.0f;
     return;
   }
@@ -401,7 +403,7 @@ __global__ __launch_bounds__(256) void spectral_kernel(
   if constexpr (!GENERAL) {
     const int y = (int)(sc / Nx), x = (int)(sc - (long)y * Nx);
     const int cls = border_class(y, Ny, P) * P + border_class(x, Nx, P);
-    rd = rden + (long)cls * Kp * Nz;
+    rd = rden + (long)cls * K * Kp;  // Kp: z stride of the table
   }
 
   float w[W];
@@ -427,7 +429,7 @@ __global__ __launch_bounds__(256) void spectral_kernel(
         const float den = conv_sel<LWMAX>(wn, taps2 + off, lw);
         T = den > 0.0f ? num / sqrtf(den) : 0.0f;  // den <= 0 -> inf -> T = 0  (lib :1057)
       } else {
-        T = num * rd[(long)z * Kp + k];
+        T = num * rd[(long)k * Kp + z];
       }
       if (T > best) {  // strict '>' : first maximum wins                      (lib :1210)
         best = T;
@@ -552,15 +554,6 @@ __device__ __forceinline__ void conv3_sel(const f32x2 (&w)[2 * LWMAX + SPEC_ZC],
 }
 #undef CASE3
 
-// interior-class table transposed: rdi[k][z] = rden_interior[z][k]
-__global__ __launch_bounds__(256) void rdi_kernel(const float *__restrict__ rd_int, int K, int Kp,
-                                                  int Nz, int NzP, float *__restrict__ rdi) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (long)K * NzP) return;
-  const int k = (int)(i / NzP), z = (int)(i - (long)k * NzP);
-  rdi[i] = z < Nz ? rd_int[(long)z * Kp + k] : 0.0f;
-}
-
 template <int LWMAX>
 __global__ __launch_bounds__(256) void spectral3_kernel(
     const float *__restrict__ fsf, const float *__restrict__ rdi, int NzP,
@@ -679,31 +672,34 @@ __global__ __launch_bounds__(256) void spectral3_kernel(
 // order as the fp32 FMA chain of spectral3_kernel (~1e-7); origin_glr_plan_set_precision
 // selects that kernel instead.
 //
-// A wave owns 64 consecutive spaxels (two 32-column B tiles, fragments loaded straight from
+// A wave owns 32 consecutive spaxels (one 32-column B tile, fragments loaded straight from
 // global memory: lane (r, h) holds X[16 ks + 8 h + j][r], 128-byte segments per half wave) and
 // marches z in tiles of 32.  The A fragments of a Toeplitz matrix are 8 consecutive entries of
 // one padded tap array G_k[e] = p_k[lw_k + 63 - e] starting at e = 16 ks + 8 h - m + 31; LDS
-// holds, per profile, 8 copies of G_k shifted by 0..7 elements (hi and lo halves) so that
-// every fragment is ONE aligned ds_read_b128 at a per-lane base plus an immediate offset.
-// Profiles whose half width is <= 16 only touch window blocks 1..4 (4 of the 6 k-steps).
-// Normalisation and border handling as in spectral3_kernel (interior class here, border
-// spaxels recomputed exactly by the list pass).
+// holds, per profile, 8 copies of G_k shifted by 0..7 elements (hi and lo halves, 320-byte
+// copies: conflict-free for the lane groups of ds_read_b128) so that every fragment is ONE
+// aligned ds_read_b128 at a per-lane base plus an immediate offset.  Profiles whose half width
+// is <= 16 only touch window blocks 1..4 (4 of the 6 k-steps).
+// Measured (tools/mfma_rate.hip): the MFMA issues every 32 cycles from 1, 2 or 4 accumulator
+// chains alike, but VALU work does not hide behind it -- neither from the same wave nor from a
+// second wave on the SIMD: each VALU instruction adds ~2 cycles.  The epilogue (scale, first
+// arg-max, min: 4.5 VALU per output and profile) is therefore the second cost centre.
+// Normalisation: 1/sqrt(den) of the lane's border class, exact for every spaxel (no fix-up
+// pass behind this kernel).
 // ------------------------------------------------------------------------------------
-#ifndef MF_EXPERIMENT
-#define MF_EXPERIMENT 0
-#endif
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 
 constexpr int MF_TAP_SCALE_LOG2 = 12;                 // taps are stored times 2^12
-constexpr int MF_GROUPS = 18;                         // 16-byte groups per shifted copy (15 used)
-constexpr int MF_COPY_BYTES = MF_GROUPS * 16;         // 288 = 256 + 32: bank-staggered copies
+constexpr int MF_GROUPS = 20;                         // 16-byte groups per shifted copy (15 used)
+constexpr int MF_COPY_BYTES = MF_GROUPS * 16;         // 320 = 256 + 64: conflict-free ds_read_b128
 constexpr int MF_PROF_BYTES = 2 * 8 * MF_COPY_BYTES;  // hi copies, then lo copies
 constexpr int MF_RD_BYTES = 32 * 4;                   // per wave and profile: 32 channels of 1/sqrt(den)
-constexpr int MF_MAX_K = 30;                          // 30 * (4608 + 4 * 128) B = 150 KiB of LDS
-constexpr int MF_BREG = 160;                          // B fragments live in a[160:255]
+constexpr int MF_WAVES = 8;                           // waves per block (two per SIMD)
+constexpr int MF_MAX_K = 26;                          // 26 * (5120 + 8 * 128) B = 156 KiB of LDS
+constexpr int MF_BREG = 80;                           // B fragments live in a[80:127]
 
 template <int I, int N, typename F>
 __device__ __forceinline__ void mf_for(F &&f) {
@@ -713,17 +709,19 @@ __device__ __forceinline__ void mf_for(F &&f) {
   }
 }
 
-// Register plan.  The data window (B fragments: 6 blocks x 2 column tiles x hi/lo x 4 dwords =
-// 96 registers, constant over all K profiles) is parked in the accumulator file a[160:255] by
-// hand and named literally in the MFMA instructions; results accumulate in VGPRs where the
-// VALU epilogue reads them directly.  (hipcc's own allocation kept the results in AGPRs and
-// moved everything through v_accvgpr_read/mov, which issue in order with the MFMAs: measured
-// wall time = VALU time + MFMA time.)  The compiler must not touch a[160:255]: the kernel is
-// written to stay below 256 VGPRs so that it allocates no AGPR at all (audit the .s for
-// v_accvgpr outside ASMSTART/ASMEND after every change; tests compare with the fp32 kernel).
+// Register plan.  A wave owns 32 consecutive spaxels (one 32-column B tile) and marches z in
+// tiles of 32 channels.  The data window (B fragments: 6 blocks x hi/lo x 4 dwords = 48
+// registers, constant over all K profiles) is parked in the accumulator file a[80:127] by hand
+// and named literally in the MFMA instructions; results accumulate in VGPRs where the VALU
+// epilogue reads them directly.  (Left to itself hipcc keeps the results in AGPRs and moves
+// everything through v_accvgpr_read/mov, which issue in order with the MFMAs.)  The kernel
+// stays far below its VGPR budget, so the compiler allocates no AGPR of its own (audit the .s
+// for v_accvgpr outside ASMSTART/ASMEND after every change; tests compare with the fp32
+// kernel).  With 128 + 128 registers per wave two waves share a SIMD: while one wave is in
+// its VALU epilogue, loads or stores, another one feeds the matrix pipe.
 // Wait states the compiler cannot see (cdna_hip_programming.md 5.7): v_accvgpr_write -> MFMA
-// operand (s_nop 1 in the first MFMA of every profile) and MFMA result -> VALU reader (the
-// epilogue of a profile starts three MFMAs into the next one; a nop statement guards the last).
+// operand (s_nop 1 in the first MFMA of every profile) and MFMA result -> VALU reader
+// (s_nop after the last MFMA of a profile).
 template <int R>
 __device__ __forceinline__ void mf_put(const f16x8 &v) {
   const u32x4v u = __builtin_bit_cast(u32x4v, v);
@@ -733,10 +731,9 @@ __device__ __forceinline__ void mf_put(const f16x8 &v) {
                : "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]), "n"(R), "n"(R + 1), "n"(R + 2),
                  "n"(R + 3));
 }
-// fragment (block ks, column tile t, hi/lo) -> first register
-__host__ __device__ constexpr int mf_breg(int ks, int t, int lo) {
-  return MF_BREG + 4 * ((ks * 2 + t) * 2 + lo);
-}
+// fragment (block ks, hi/lo) -> first register
+__host__ __device__ constexpr int mf_breg(int ks, int lo) { return MF_BREG + 4 * (ks * 2 + lo); }
+
 template <int R, bool FIRST>
 __device__ __forceinline__ void mf_mma(f32x16 &acc, const f16x8 &a) {
   if constexpr (FIRST)
@@ -755,95 +752,75 @@ __device__ __forceinline__ float mf_min(float a, float b) {
   return r;
 }
 
-// running first-maximum / argmax / minimum over the profiles for accumulator element E
-// (E = 2 i + t: register i of column tile t; register i of lane (r, h) is channel
-// z0 + (i&3) + 8 (i>>2) + 4 h)
-template <int E>
-__device__ __forceinline__ void mf_epi1(const f32x16 (&acc)[2], const f32x4v (&f)[4], int k,
-                                        f32x16 (&best)[2], int (&bk)[2][16],
-                                        f32x16 (&worst)[2]) {
-  constexpr int t = E & 1, i = E >> 1;
-  const float T = acc[t][i] * f[i >> 2][i & 3];
-  const bool gt = T > best[t][i];  // strict '>' : the first maximum wins   (lib :1210)
-  best[t][i] = gt ? T : best[t][i];
-  bk[t][i] = gt ? k : bk[t][i];
-  worst[t][i] = mf_min(worst[t][i], T);
+// the 12 (narrow: window blocks 1..4) or 18 (wide: 0..5) MFMAs of one profile:
+// acc = Ah Bh + Ah Bl + Al Bh over the blocks; A fragments are requested a block ahead.  One
+// accumulator chain is enough: tools/mfma_rate.hip measures the same 32-cycle issue for 1, 2
+// and 4 chains.
+template <bool WIDE>
+__device__ __forceinline__ void mf_profile(const char *__restrict__ ak, f32x16 &acc) {
+  constexpr int KS0 = WIDE ? 0 : 1, NKS = WIDE ? 6 : 4;
+  constexpr int LO = 8 * MF_COPY_BYTES;
+  f16x8 ah = *reinterpret_cast<const f16x8 *>(ak + KS0 * 32);
+  f16x8 al = *reinterpret_cast<const f16x8 *>(ak + KS0 * 32 + LO);
+  mf_for<0, NKS>([&](auto ic) {
+    constexpr int g = decltype(ic)::value, ks = KS0 + g;
+    f16x8 nh, nl;
+    if constexpr (g + 1 < NKS) {
+      nh = *reinterpret_cast<const f16x8 *>(ak + (ks + 1) * 32);
+      nl = *reinterpret_cast<const f16x8 *>(ak + (ks + 1) * 32 + LO);
+    }
+    mf_mma<mf_breg(ks, 0), g == 0>(acc, ah);
+    mf_mma<mf_breg(ks, 1), false>(acc, ah);
+    mf_mma<mf_breg(ks, 0), false>(acc, al);
+    if constexpr (g + 1 < NKS) ah = nh, al = nl;
+  });
+  asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc));  // MFMA result -> VALU reader
 }
 
-// One profile: its 24 (narrow: window blocks 1..4) or 36 (wide: 0..5) MFMAs into `acc`, with the
-// epilogue of the PREVIOUS profile (results in `prev`) dealt out between them -- one MFMA
-// holds the matrix pipe for 32 cycles, an epilogue element is five 4-cycle VALU issues.
-// (ah, al) arrive holding the A fragments of the first window block and leave holding those
-// of the next profile's first block (`a_next`), so no LDS latency is exposed between profiles.
-template <bool WIDE, bool EPI>
-__device__ __forceinline__ void mf_step(const char *__restrict__ ak,
-                                        const char *__restrict__ a_next, f16x8 &ah, f16x8 &al,
-                                        f32x16 (&acc)[2], const f32x16 (&prev)[2],
-                                        const char *__restrict__ rd_prev, float inv, int kprev,
-                                        f32x16 (&best)[2], int (&bk)[2][16],
-                                        f32x16 (&worst)[2]) {
-  constexpr int KS0 = WIDE ? 0 : 1, NKS = WIDE ? 6 : 4, NM = 6 * NKS;
-  // 1/sqrt(den) of the previous profile for this lane's 16 channels, times the unscaling factor
-  f32x4v f[4];
-  if constexpr (EPI) {
+// running first-maximum / argmax / minimum over the profiles.  Accumulator register i of lane
+// (r, h) is channel z0 + (i&3) + 8 (i>>2) + 4 h; f[g] holds 1/sqrt(den) (times the unscaling
+// factor) of profile k for the lane's channels of group g.
+__device__ __forceinline__ void mf_epilogue(const f32x16 &acc, const f32x4v (&f)[4], int k,
+                                            f32x16 &best, int (&bk)[16], f32x16 &worst) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-      f[g] = *reinterpret_cast<const f32x4v *>(rd_prev + 32 * g) * inv;
-  }
-  f16x8 nh, nl;
-  mf_for<0, NM>([&](auto ic) {
-    constexpr int idx = decltype(ic)::value;
-    constexpr int g = idx / 6, sub = idx % 6, ks = KS0 + g, t = sub & 1;
-    if constexpr (sub == 0) {
-      // fragments of the next window block (or of the next profile) are requested a block ahead
-      const char *src = g + 1 < NKS ? ak + (ks + 1) * 32 : a_next;
-      nh = *reinterpret_cast<const f16x8 *>(src);
-      nl = *reinterpret_cast<const f16x8 *>(src + 8 * MF_COPY_BYTES);
-    }
-    // ah Bh, ah Bl, al Bh
-#if MF_EXPERIMENT != 2
-    mf_mma<mf_breg(ks, t, (sub >> 1) == 1), (idx < 2)>(acc[t], sub < 4 ? ah : al);
-#else
-    if (idx < 2) acc[t] = (f32x16)(0.0f) + (float)(sub < 4 ? ah : al)[0];
-#endif
-    if constexpr (EPI && MF_EXPERIMENT != 1) {
-      if constexpr (WIDE) {  // MFMAs 3..34: one element each
-        if constexpr (idx >= 3 && idx < 35) mf_epi1<idx - 3>(prev, f, kprev, best, bk, worst);
-      } else if constexpr (idx >= 3) {  // MFMAs 3..23: two elements after the first 11, then one
-        constexpr int sl = idx - 3;
-        if constexpr (sl < 11) {
-          mf_epi1<2 * sl>(prev, f, kprev, best, bk, worst);
-          mf_epi1<2 * sl + 1>(prev, f, kprev, best, bk, worst);
-        } else {
-          mf_epi1<sl + 11>(prev, f, kprev, best, bk, worst);
-        }
+  for (int g = 0; g < 4; ++g) {
+#pragma unroll
+    for (int q = 0; q < 4; q += 2) {
+      const int i = 4 * g + q;
+      const f32x2 T2 = (f32x2){acc[i], acc[i + 1]} * (f32x2){f[g][q], f[g][q + 1]};  // v_pk_mul_f32
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float T = e ? T2.y : T2.x;
+        const bool gt = T > best[i + e];  // strict '>' : the first maximum wins   (lib :1210)
+        best[i + e] = gt ? T : best[i + e];
+        bk[i + e] = gt ? k : bk[i + e];
+        worst[i + e] = mf_min(worst[i + e], T);
       }
     }
-    __builtin_amdgcn_sched_barrier(0);  // keep the hand-made interleave
-    if constexpr (sub == 5) {
-      ah = nh;
-      al = nl;
-    }
-  });
+  }
 }
 
-__global__ __launch_bounds__(256, 1) void spectral_mfma_kernel(
-    const float *__restrict__ fsf, const float *__restrict__ rdi, int NzP,
-    const uint4 *__restrict__ atab, const int *__restrict__ pwide, int K, int Nz, long S,
-    int zchunk, const uint8_t *__restrict__ mask, float *__restrict__ correl,
+__global__ __launch_bounds__(64 * MF_WAVES, 1) void spectral_mfma_kernel(
+    const float *__restrict__ fsf, const float *__restrict__ rden, int NzP,
+    const uint4 *__restrict__ atab, const int *__restrict__ pwide, int K, int Nz, int Ny, int Nx,
+    int P, int zchunk, const uint8_t *__restrict__ mask, float *__restrict__ correl,
     uint8_t *__restrict__ profile, float *__restrict__ correl_min, float *__restrict__ part_max,
     float *__restrict__ part_min) {
   extern __shared__ __align__(16) char mf_lds[];
-  // reserve a[160:255] in the kernel descriptor (nothing is emitted)
-  asm volatile("" ::: "a160", "a255");
+  // a[80:127] belong to the B fragments (the clobber makes the descriptor allocate 128 AGPRs;
+  // with inline-asm AGPR use hipcc splits the 256 registers of a wave 128 / 128 and parks its
+  // own long-lived scalars in the lowest AGPRs -- a[0:15] here, audited, far below)
+  asm volatile("" ::: "a80", "a127");
   {
     const int nvec = K * (MF_PROF_BYTES / 16);
-    for (int i = threadIdx.x; i < nvec; i += 256) reinterpret_cast<uint4 *>(mf_lds)[i] = atab[i];
+    for (int i = threadIdx.x; i < nvec; i += 64 * MF_WAVES)
+      reinterpret_cast<uint4 *>(mf_lds)[i] = atab[i];
   }
   __syncthreads();
+  const long S = (long)Ny * Nx;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const long s_base = ((long)blockIdx.x * 4 + wv) * 64;
+  const long s_base = ((long)blockIdx.x * MF_WAVES + wv) * 32;
   if (s_base >= S) return;  // whole wave; no barrier follows
   const int zc0 = blockIdx.y * zchunk, zc1 = min(Nz, zc0 + zchunk);
   const int E0 = 8 * h - r + 31;
@@ -851,64 +828,58 @@ __global__ __launch_bounds__(256, 1) void spectral_mfma_kernel(
   // this wave's [K][32] table of 1/sqrt(den) for the current tile (behind the tap copies)
   char *rd_wave = mf_lds + K * MF_PROF_BYTES + wv * K * MF_RD_BYTES;
   const char *rd_lane = rd_wave + 16 * h;  // channels 4h..4h+3 of each group of 8
-  long sc[2];
-  bool sv[2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const long s = s_base + 32 * t + r;
-    sv[t] = s < S;
-    sc[t] = sv[t] ? s : S - 1;
+  const bool sv = s_base + r < S;
+  const long sc = sv ? s_base + r : S - 1;
+  float vmax = -INFINITY, vmin = INFINITY;
+  // Normalisation class of this lane's spaxel (how the field border clips the PSF window).
+  // Waves whose 32 spaxels are all interior read the interior table through LDS; a wave
+  // that touches the border fetches each lane's own class from the [cls][k][z] table (one
+  // 16-byte load per accumulator group, requested before the profile's MFMAs).
+  const int ccls = (P / 2) * P + P / 2;
+  int cls;
+  {
+    const int y = (int)(sc / Nx), xx = (int)(sc - (long)y * Nx);
+    cls = border_class(y, Ny, P) * P + border_class(xx, Nx, P);
   }
-  float vmax[2] = {-INFINITY, -INFINITY}, vmin[2] = {INFINITY, INFINITY};
+  const bool bwave = __any(cls != ccls);
+  const float *rdi = rden + (long)ccls * K * NzP;
+  const float *rdb = rden + (long)cls * K * NzP + 4 * h;
 
   for (int z0 = zc0; z0 < zc1; z0 += 32) {
-    // ---- 1/sqrt(den)[k][z0 .. z0+31] -> LDS (the previous tile's readers are done: same wave)
-    {
-      float rv[MF_MAX_K / 2];  // all requests in flight together
+    // ---- 1/sqrt(den)[k][z0 .. z0+31]: requested now, written to LDS (times the unscaling
+    // factor) once the tile's scale is known
+    float rv[MF_MAX_K / 2];
 #pragma unroll
-      for (int q = 0; q < MF_MAX_K / 2; ++q) {
-        const int i = lane + 64 * q;
-        rv[q] = i < K * 32 ? rdi[(long)(i >> 5) * NzP + z0 + (i & 31)] : 0.0f;
-      }
-#pragma unroll
-      for (int q = 0; q < MF_MAX_K / 2; ++q) {
-        const int i = lane + 64 * q;
-        if (i < K * 32) reinterpret_cast<float *>(rd_wave)[i] = rv[q];
-      }
+    for (int q = 0; q < MF_MAX_K / 2; ++q) {
+      const int i = lane + 64 * q;
+      rv[q] = i < K * 32 ? rdi[(long)(i >> 5) * NzP + z0 + (i & 31)] : 0.0f;
     }
-    // ---- window X[z0-32 .. z0+63] of both column tiles, in B-fragment order
-    float x[6][2][8];
+    // ---- window X[z0-32 .. z0+63] in B-fragment order: lane (r, h) holds rows 16 ks + 8 h + j
+    float x[6][8];
     const int zb = z0 - 32 + 8 * h;
     if (z0 - 32 >= 0 && z0 + 64 <= Nz) {
+      const float *p = fsf + (long)zb * S + sc;
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const float *p = fsf + (long)zb * S + sc[t];
+      for (int ks = 0; ks < 6; ++ks)
 #pragma unroll
-        for (int ks = 0; ks < 6; ++ks)
-#pragma unroll
-          for (int j = 0; j < 8; ++j) x[ks][t][j] = p[(long)(16 * ks + j) * S];
-      }
+        for (int j = 0; j < 8; ++j) x[ks][j] = p[(long)(16 * ks + j) * S];
     } else {
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int ks = 0; ks < 6; ++ks)
 #pragma unroll
-        for (int ks = 0; ks < 6; ++ks)
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int zz = zb + 16 * ks + j;
-            const bool in = zz >= 0 && zz < Nz;
-            const float v = fsf[(long)(in ? zz : 0) * S + sc[t]];
-            x[ks][t][j] = in ? v : 0.0f;
-          }
+        for (int j = 0; j < 8; ++j) {
+          const int zz = zb + 16 * ks + j;
+          const bool in = zz >= 0 && zz < Nz;
+          const float v = fsf[(long)(in ? zz : 0) * S + sc];
+          x[ks][j] = in ? v : 0.0f;
+        }
     }
     // ---- power-of-two scale of this tile: max |y| in [2^14, 2^15)
     float m = 0.0f;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int ks = 0; ks < 6; ++ks)
 #pragma unroll
-      for (int ks = 0; ks < 6; ++ks)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(sv[t] ? x[ks][t][j] : 0.0f));
+      for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(sv ? x[ks][j] : 0.0f));
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     const int ex = (int)((__float_as_uint(m) >> 23) & 0xffu);
@@ -917,122 +888,88 @@ __global__ __launch_bounds__(256, 1) void spectral_mfma_kernel(
     // 2^-(e + MF_TAP_SCALE_LOG2): undoes both scalings, exactly
     const float inv = __uint_as_float((unsigned)(tiny ? 127 - MF_TAP_SCALE_LOG2
                                                       : ex - 14 - MF_TAP_SCALE_LOG2) << 23);
-    // ---- split into f16 hi + lo and park the fragments in a[160:255]
-    mf_for<0, 12>([&](auto ic) {
-      constexpr int ks = decltype(ic)::value >> 1, t = decltype(ic)::value & 1;
+    // (this wave's readers of the previous tile's table are done: same wave, in order)
+#pragma unroll
+    for (int q = 0; q < MF_MAX_K / 2; ++q) {
+      const int i = lane + 64 * q;
+      if (i < K * 32) reinterpret_cast<float *>(rd_wave)[i] = rv[q] * inv;
+    }
+    // ---- split into f16 hi + lo and park the fragments in a[80:127]
+    mf_for<0, 6>([&](auto ic) {
+      constexpr int ks = decltype(ic)::value;
       f16x8 yh8, yl8;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float y = x[ks][t][j] * scale;
+        const float y = x[ks][j] * scale;
         const _Float16 yh = (_Float16)y;
         yh8[j] = yh;
         yl8[j] = (_Float16)(y - (float)yh);
       }
-      mf_put<mf_breg(ks, t, 0)>(yh8);
-      mf_put<mf_breg(ks, t, 1)>(yl8);
+      mf_put<mf_breg(ks, 0)>(yh8);
+      mf_put<mf_breg(ks, 1)>(yl8);
     });
 
-    f32x16 best[2], worst[2];
-    int bk[2][16];
+    // accumulator register i of lane (r, h) is channel z0 + (i&3) + 8 (i>>2) + 4 h
+    f32x16 best, worst;
+    int bk[16];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) best[t][i] = -INFINITY, worst[t][i] = INFINITY, bk[t][i] = 0;
-
-    // software pipeline over profiles: the MFMAs of profile k run while the VALU works off
-    // the epilogue of profile k-1 from the other accumulator set
-    f32x16 accA[2], accB[2];
-    f16x8 ah, al;
-    auto first_block = [&](int k) -> const char * {  // A fragments of profile k's first block
-      const int kk = k < K ? k : 0;
-      return a_lane + kk * MF_PROF_BYTES + (pwide[kk] ? 0 : 32);
-    };
-    {
-      const char *p0 = first_block(0);
-      ah = *reinterpret_cast<const f16x8 *>(p0);
-      al = *reinterpret_cast<const f16x8 *>(p0 + 8 * MF_COPY_BYTES);
-    }
-#define MF_STEP(EPI, K_, ACC, PREV)                                                            \
-  do {                                                                                         \
-    const char *ak_ = a_lane + (K_) * MF_PROF_BYTES;                                           \
-    const char *an_ = first_block((K_) + 1);                                                   \
-    const char *rp_ = rd_lane + ((K_) - 1) * MF_RD_BYTES;                                      \
-    if (pwide[K_])                                                                             \
-      mf_step<true, EPI>(ak_, an_, ah, al, ACC, PREV, rp_, inv, (K_) - 1, best, bk, worst);    \
-    else                                                                                       \
-      mf_step<false, EPI>(ak_, an_, ah, al, ACC, PREV, rp_, inv, (K_) - 1, best, bk, worst);   \
-  } while (0)
-    MF_STEP(false, 0, accA, accB);
-    int k = 1;
-    for (; k + 1 < K; k += 2) {
-      MF_STEP(true, k, accB, accA);
-      MF_STEP(true, k + 1, accA, accB);
-    }
-    // mask bytes of the 32 outputs: requested before the last epilogue so that they land
-    // behind it
-    unsigned char mk[2][16];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) mk[t][i] = 0;
-    if (mask) {  // branch-free inside: every load is issued before the first is awaited
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int zz = min(z0 + (i & 3) + 8 * (i >> 2) + 4 * h, Nz - 1);
-          mk[t][i] = mask[(long)zz * S + sc[t]];
-        }
-    }
-    {
+    for (int i = 0; i < 16; ++i) best[i] = -INFINITY, worst[i] = INFINITY, bk[i] = 0;
+    for (int k = 0; k < K; ++k) {
+      f32x16 acc;
       f32x4v f[4];
-      if (k < K) {  // K even: one more profile, into B
-        MF_STEP(true, k, accB, accA);
+      if (bwave) {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-          f[g] = *reinterpret_cast<const f32x4v *>(rd_lane + k * MF_RD_BYTES + 32 * g) * inv;
-        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(accB[0]), "+v"(accB[1]));  // MFMA D -> VALU
-        mf_for<0, 32>([&](auto ic) { mf_epi1<decltype(ic)::value>(accB, f, k, best, bk, worst); });
+          f[g] = *reinterpret_cast<const f32x4v *>(rdb + (long)k * NzP + z0 + 8 * g);
+      }
+      const char *ak = a_lane + k * MF_PROF_BYTES;
+      if (pwide[k]) mf_profile<true>(ak, acc);
+      else mf_profile<false>(ak, acc);
+      if (bwave) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) f[g] *= inv;
       } else {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-          f[g] = *reinterpret_cast<const f32x4v *>(rd_lane + (K - 1) * MF_RD_BYTES + 32 * g) * inv;
-        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(accA[0]), "+v"(accA[1]));
-        mf_for<0, 32>([&](auto ic) { mf_epi1<decltype(ic)::value>(accA, f, K - 1, best, bk, worst); });
+          f[g] = *reinterpret_cast<const f32x4v *>(rd_lane + k * MF_RD_BYTES + 32 * g);
       }
+      mf_epilogue(acc, f, k, best, bk, worst);
     }
-#undef MF_STEP
-
     // ---- store, mask glue (steps.py:781,788)
+    unsigned char mk[16];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int i = 0; i < 16; ++i) mk[i] = 0;
+    if (mask) {  // branch-free inside: every load is issued before the first is awaited
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int zz = z0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        if (zz < zc1) {
-          const long idx = (long)zz * S + sc[t];
-          float b = best[t][i];
-          int kk = bk[t][i];
-          if (mk[t][i]) b = 0.0f, kk = 0;
-          if (sv[t]) {
-            correl[idx] = b;
-            correl_min[idx] = worst[t][i];
-            profile[idx] = (uint8_t)kk;
-          }
-          vmax[t] = fmaxf(vmax[t], b);
-          vmin[t] = fminf(vmin[t], worst[t][i]);
-        }
+        const int zz = min(z0 + (i & 3) + 8 * (i >> 2) + 4 * h, Nz - 1);
+        mk[i] = mask[(long)zz * S + sc];
       }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int zz = z0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+      if (zz < zc1) {
+        const long idx = (long)zz * S + sc;
+        float b = best[i];
+        int kk = bk[i];
+        if (mk[i]) b = 0.0f, kk = 0;
+        if (sv) {
+          correl[idx] = b;
+          correl_min[idx] = worst[i];
+          profile[idx] = (uint8_t)kk;
+        }
+        vmax = fmaxf(vmax, b);
+        vmin = fminf(vmin, worst[i]);
+      }
+    }
   }
   if (part_max) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const float a = fmaxf(vmax[t], __shfl_xor(vmax[t], 32));
-      const float b = fminf(vmin[t], __shfl_xor(vmin[t], 32));
-      if (h == 0 && sv[t]) {
-        part_max[(long)blockIdx.y * S + sc[t]] = a;
-        part_min[(long)blockIdx.y * S + sc[t]] = b;
-      }
+    const float a = fmaxf(vmax, __shfl_xor(vmax, 32));
+    const float b = fminf(vmin, __shfl_xor(vmin, 32));
+    if (h == 0 && sv) {
+      part_max[(long)blockIdx.y * S + sc] = a;
+      part_min[(long)blockIdx.y * S + sc] = b;
     }
   }
 }
@@ -1058,7 +995,7 @@ __global__ __launch_bounds__(256) void spectral_generic_kernel(
   const float *rd = nullptr;
   if constexpr (!GENERAL) {
     const int y = (int)(s / Nx), x = (int)(s - (long)y * Nx);
-    rd = rden + (long)(border_class(y, Ny, P) * P + border_class(x, Nx, P)) * Kp * Nz;
+    rd = rden + (long)(border_class(y, Ny, P) * P + border_class(x, Nx, P)) * K * Kp;
   }
   float vmax = -INFINITY, vmin = INFINITY;
   for (int z = z0; z < z1; ++z) {
@@ -1078,7 +1015,7 @@ __global__ __launch_bounds__(256) void spectral_generic_kernel(
       if constexpr (GENERAL)
         T = den > 0.0f ? num / sqrtf(den) : 0.0f;
       else
-        T = num * rd[(long)z * Kp + k];
+        T = num * rd[(long)k * Kp + z];
       if (T > best) {
         best = T;
         bk = k;
@@ -1199,7 +1136,7 @@ int origin_glr_plan_destroy(origin_glr_plan *plan) {
   for (void *p : {(void *)plan->d_k, (void *)plan->d_k2, (void *)plan->d_w, (void *)plan->d_taps,
                   (void *)plan->d_taps2, (void *)plan->d_tap_off, (void *)plan->d_rden,
                   (void *)plan->d_htaps, (void *)plan->d_htap_off, (void *)plan->d_rows,
-                  (void *)plan->d_rdi, (void *)plan->d_border, (void *)plan->d_atab,
+                  (void *)plan->d_border, (void *)plan->d_atab,
                   (void *)plan->d_pwide})
     if (p) (void)hipFree(p);
   delete plan;
@@ -1278,7 +1215,7 @@ int origin_glr_plan_create(origin_ctx *ctx, int Nz, int Ny, int Nx, int nfields,
     lwmax = std::max(lwmax, (off[kk + 1] - off[kk] - 1) / 2);
   }
   pl->lwmax = lwmax;
-  pl->Kp = (K + 3) / 4 * 4;
+  pl->Kp = 0;  // set with NzP below
   // exactly symmetric profiles (the Gaussian dictionaries are) allow p[c+d] (w[c+d] + w[c-d])
   std::vector<float> htaps;
   std::vector<int> hoff(K + 1, 0);
@@ -1296,6 +1233,7 @@ int origin_glr_plan_create(origin_ctx *ctx, int Nz, int Ny, int Nx, int nfields,
   TRY(upload(ctx, hoff, &pl->d_htap_off, &pl->bytes));
   pl->lwt = 0;
   pl->NzP = (Nz + 31) / 32 * 32 + 32;  // spectral_mfma_kernel reads whole 32-channel tiles
+  pl->Kp = pl->NzP;
   if (lwmax <= 32) {
     const int lwt = lwmax <= 8 ? 8 : lwmax <= 16 ? 16 : lwmax <= 24 ? 24 : lwmax <= 29 ? 29 : 32;
     const int RL = (2 * lwt + 1 + 15) / 16 * 16 + 16;  // [lw | taps padded to 16s]
@@ -1359,7 +1297,7 @@ int origin_glr_plan_create(origin_ctx *ctx, int Nz, int Ny, int Nx, int nfields,
       origin_glr_plan_destroy(pl);
       return ORIGIN_E_NOMEM;
     }
-    const size_t rn = PP * (size_t)pl->Kp * Nz;
+    const size_t rn = PP * (size_t)K * pl->NzP;
     e = hipMalloc((void **)&pl->d_rden, rn * sizeof(float));
     if (e != hipSuccess) {
       (void)hipFree(ncls);
@@ -1372,15 +1310,10 @@ int origin_glr_plan_create(origin_ctx *ctx, int Nz, int Ny, int Nx, int nfields,
     hipLaunchKernelGGL(norm_classes_kernel, dim3(cdiv((long)ncls_n, 256)), dim3(256), 0,
                        ctx->stream, pl->d_k2, Nz, P, ncls);
     hipLaunchKernelGGL(rden_kernel, dim3(cdiv((long)rn, 256)), dim3(256), 0, ctx->stream, ncls,
-                       pl->d_taps2, pl->d_tap_off, K, Nz, (int)PP, pl->Kp, pl->d_rden);
-    e = hipMalloc((void **)&pl->d_rdi, (size_t)K * pl->NzP * sizeof(float));
-    if (e == hipSuccess) {
-      pl->bytes += (size_t)K * pl->NzP * sizeof(float);
-      const int ccls = (P / 2) * P + P / 2;
-      hipLaunchKernelGGL(rdi_kernel, dim3(cdiv((long)K * pl->NzP, 256)), dim3(256), 0, ctx->stream,
-                         pl->d_rden + (size_t)ccls * pl->Kp * Nz, K, pl->Kp, Nz, pl->NzP, pl->d_rdi);
-      e = hipGetLastError();
-    }
+                       pl->d_taps2, pl->d_tap_off, K, Nz, (int)PP, pl->NzP, pl->d_rden);
+    e = hipGetLastError();
+    // the interior class is a slice of the table
+    pl->d_rdi = pl->d_rden + (size_t)((P / 2) * P + P / 2) * K * pl->NzP;
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(ncls);
     if (e != hipSuccess) {
@@ -1508,7 +1441,7 @@ int origin_glr_run(origin_ctx *ctx, origin_glr_plan *pl, const float *d_cube,
   if (mfma) {
     // matrix-core path: a wave = 64 spaxels x 32-channel tiles; z chunks sized to give every CU
     // several blocks (one 4-wave block per CU at a time: K * 4.5 KiB of LDS)
-    const long bx = cdiv(S, 256);
+    const long bx = cdiv(S, 32 * MF_WAVES);
     int nzm = (int)(((long)ctx->num_cu * 8 + bx - 1) / bx);
     nzm = std::max(1, std::min(nzm, std::min(64, cdiv(Nz, 64))));
     int zcm = (cdiv(Nz, nzm) + 31) / 32 * 32;
@@ -1516,17 +1449,17 @@ int origin_glr_run(origin_ctx *ctx, origin_glr_plan *pl, const float *d_cube,
     nzc = nzm;
     pmax = want_maps ? part : nullptr;
     pmin = want_maps ? part + (size_t)nzc * S : nullptr;
-    const size_t lds = (size_t)K * (MF_PROF_BYTES + 4 * MF_RD_BYTES);
+    const size_t lds = (size_t)K * (MF_PROF_BYTES + MF_WAVES * MF_RD_BYTES);
     static bool attr_done = false;
     if (!attr_done) {
       ORIGIN_HIP(hipFuncSetAttribute((const void *)spectral_mfma_kernel,
                                      hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     MF_MAX_K * (MF_PROF_BYTES + 4 * MF_RD_BYTES)));
+                                     MF_MAX_K * (MF_PROF_BYTES + MF_WAVES * MF_RD_BYTES)));
       attr_done = true;
     }
-    hipLaunchKernelGGL(spectral_mfma_kernel, dim3((unsigned)bx, nzm), dim3(256), lds, ctx->stream,
-                       fsf, pl->d_rdi, pl->NzP, pl->d_atab, pl->d_pwide, K, Nz, S, zcm, d_mask,
-                       d_correl, d_profile, d_correl_min, pmax, pmin);
+    hipLaunchKernelGGL(spectral_mfma_kernel, dim3((unsigned)bx, nzm), dim3(64 * MF_WAVES), lds, ctx->stream,
+                       fsf, pl->d_rden, pl->NzP, pl->d_atab, pl->d_pwide, K, Nz, Ny, Nx, P, zcm,
+                       d_mask, d_correl, d_profile, d_correl_min, pmax, pmin);
   } else if (packed) {
     // packed path: one lane = two adjacent spaxels, SPEC_ZC channels per step
     dim3 g2(cdiv(S / 2, 256), nzc);
@@ -1551,7 +1484,7 @@ int origin_glr_run(origin_ctx *ctx, origin_glr_plan *pl, const float *d_cube,
   } else {
     if (gen) LAUNCH((spectral_generic_kernel<true>)); else LAUNCH((spectral_generic_kernel<false>));
   }
-  if ((mfma || packed) && pl->nborder > 0) {  // border spaxels: exact per-class normalisation
+  if (packed && pl->nborder > 0) {  // border spaxels: exact per-class normalisation
     origin_prof_end_begin(ctx, K_GLR_BORDER);
     // few spaxels: cut z finer so that the pass still fills the chip (its maps are redone
     // from the final cubes below, so it writes no partials)
