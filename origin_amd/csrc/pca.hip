@@ -795,39 +795,63 @@ __global__ __launch_bounds__(256) void xv_kernel(const double *__restrict__ Xp,
   if (threadIdx.x == 0) u[(long)k * Nz + z] = acc;
 }
 
+// w_k[q] = u_k . U[:, q] (q < T_k) and |u_k|^2 of the not yet normalised u_k, as partial sums over
+// UW_SLICES slices of z: grid (UW_SLICES, nw), block 256; lanes over q, waves over the rows of a
+// slice.  part[(k * UW_SLICES + b) * (PCA_CAP + 1) + q], entry PCA_CAP = the slice's sum of squares.
+constexpr int UW_SLICES = 32;
+__global__ __launch_bounds__(256) void uw_partial_kernel(const double *__restrict__ u, int Nz,
+                                                         const long *__restrict__ D, int nw,
+                                                         const double *__restrict__ U,
+                                                         double *__restrict__ part) {
+  __shared__ double wred[4][PCA_CAP + 1];
+  const int k = blockIdx.y, b = blockIdx.x;
+  const int T = (int)DSC(DF_T, k);
+  const double *uk = u + (long)k * Nz;
+  const double *Ua = U + (long)DSC(DF_AREA, k) * Nz * PCA_CAP;
+  const int zs = (Nz + UW_SLICES - 1) / UW_SLICES;
+  const int z0 = b * zs, z1 = min(Nz, z0 + zs);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double a = 0.0, s2 = 0.0;
+  for (int z = z0 + wave; z < z1; z += 4) {
+    const double uz = uk[z];
+    s2 = fma(uz, uz, s2);
+    if (lane < T) a = fma(uz, Ua[(long)z * PCA_CAP + lane], a);
+  }
+  wred[wave][lane] = a;
+  if (lane == 0) wred[wave][PCA_CAP] = s2;
+  __syncthreads();
+  if (threadIdx.x <= PCA_CAP) {
+    const int q = threadIdx.x;
+    part[((long)k * UW_SLICES + b) * (PCA_CAP + 1) + q] =
+        ((wred[0][q] + wred[1][q]) + wred[2][q]) + wred[3][q];
+  }
+}
+
 // normalise u_k, store it as column T_k of U, and w_k[q] = u_k . U[:, q] for q < T_k
 __global__ __launch_bounds__(1024) void normalize_kernel(double *__restrict__ u, int Nz,
                                                          const long *__restrict__ D, int nw,
                                                          double *__restrict__ U,
+                                                         const double *__restrict__ part,
                                                          double *__restrict__ wq) {
-  __shared__ double red[16];
-  __shared__ double wred[16][PCA_CAP];
+  __shared__ double s_inv;
   const int k = blockIdx.x;
   const int T = (int)DSC(DF_T, k);
   double *uk = u + (long)k * Nz;
   double *Ua = U + (long)DSC(DF_AREA, k) * Nz * PCA_CAP;
+  const double *pk = part + (long)k * UW_SLICES * (PCA_CAP + 1);
   double acc = 0.0;
-  for (int z = threadIdx.x; z < Nz; z += 1024) acc = fma(uk[z], uk[z], acc);
-  const double t = block_sum(acc, red);
-  const double inv = t > 0.0 ? 1.0 / sqrt(t) : 0.0;
+  if (threadIdx.x <= PCA_CAP) {  // fixed-order sums over the slices
+#pragma unroll 8
+    for (int b = 0; b < UW_SLICES; ++b) acc += pk[(long)b * (PCA_CAP + 1) + threadIdx.x];
+    if (threadIdx.x == PCA_CAP) s_inv = acc > 0.0 ? 1.0 / sqrt(acc) : 0.0;
+  }
+  __syncthreads();
+  const double inv = s_inv;
+  if ((int)threadIdx.x < T) wq[(long)k * PCA_CAP + threadIdx.x] = acc * inv;
   for (int z = threadIdx.x; z < Nz; z += 1024) {
     const double x = uk[z] * inv;
     uk[z] = x;
     Ua[(long)z * PCA_CAP + T] = x;
-  }
-  __syncthreads();
-  // w[q] = sum_z u[z] U[z][q]: lanes over q (T <= 64), waves over z
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double a = 0.0;
-  if (lane < T)
-    for (int z = wave; z < Nz; z += 16) a = fma(uk[z], Ua[(long)z * PCA_CAP + lane], a);
-  wred[wave][lane] = a;
-  __syncthreads();
-  if (wave == 0 && lane < T) {
-    double sacc = 0.0;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) sacc += wred[q][lane];
-    wq[(long)k * PCA_CAP + lane] = sacc;
   }
 }
 
@@ -1151,6 +1175,15 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
     ~PinnedL() { (void)hipHostFree(p); }
   } pinned_desc{h_desc};
 
+  int *h_tiles = nullptr;  // pinned staging of the Gram tile lists (grown on demand)
+  size_t tiles_cap = 0;
+  struct PinnedI {
+    int *p;
+    ~PinnedI() {
+      if (p) (void)hipHostFree(p);
+    }
+  } pinned_tiles{nullptr};
+
   std::vector<long> D;
   int iters = 0;
   for (;;) {
@@ -1217,21 +1250,35 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
     if ((rc = b_tiles.reserve(ctx, (size_t)3 * ntiles * sizeof(int)))) return rc;
     long *dD = (long *)b_desc.p;
     int *d_ti = (int *)b_tiles.p, *d_tj = d_ti + ntiles, *d_ta = d_tj + ntiles;
-    memcpy(h_desc, D.data(), D.size() * sizeof(long));  // free again: last sync was after select
+    // descriptors and tile lists go up from pinned staging, asynchronously: the staging is
+    // free again because the last synchronisation (after the selection) is behind every
+    // earlier upload, and nothing below waits for the host
+    memcpy(h_desc, D.data(), D.size() * sizeof(long));
     ORIGIN_HIP(hipMemcpyAsync(dD, h_desc, D.size() * sizeof(long), hipMemcpyHostToDevice, st));
-    ORIGIN_HIP(hipMemcpyAsync(d_ti, ti.data(), (size_t)ntiles * sizeof(int), hipMemcpyHostToDevice, st));
-    ORIGIN_HIP(hipMemcpyAsync(d_tj, tj.data(), (size_t)ntiles * sizeof(int), hipMemcpyHostToDevice, st));
-    ORIGIN_HIP(hipMemcpyAsync(d_ta, ta.data(), (size_t)ntiles * sizeof(int), hipMemcpyHostToDevice, st));
-    ORIGIN_HIP(hipStreamSynchronize(st));  // pageable sources are reused next iteration
+    if ((size_t)3 * ntiles > tiles_cap) {
+      if (h_tiles) (void)hipHostFree(h_tiles);
+      h_tiles = nullptr;
+      tiles_cap = (size_t)3 * ntiles * 2;
+      ORIGIN_HIP(hipHostMalloc((void **)&h_tiles, tiles_cap * sizeof(int), hipHostMallocDefault));
+      pinned_tiles.p = h_tiles;
+    }
+    memcpy(h_tiles, ti.data(), (size_t)ntiles * sizeof(int));
+    memcpy(h_tiles + ntiles, tj.data(), (size_t)ntiles * sizeof(int));
+    memcpy(h_tiles + 2 * (size_t)ntiles, ta.data(), (size_t)ntiles * sizeof(int));
+    ORIGIN_HIP(hipMemcpyAsync(d_ti, h_tiles, (size_t)3 * ntiles * sizeof(int), hipMemcpyHostToDevice,
+                              st));
     if ((rc = b_xp.reserve(ctx, (size_t)xp * sizeof(double)))) return rc;
     if ((rc = b_g.reserve(ctx, (size_t)g * sizeof(double)))) return rc;
     if ((rc = b_cv.reserve(ctx, (size_t)c * sizeof(double)))) return rc;
     if ((rc = b_bu.reserve(ctx, (size_t)2 * nw * Nz * sizeof(double)))) return rc;
-    if ((rc = b_small.reserve(ctx, (size_t)2 * nw * PCA_CAP * sizeof(double)))) return rc;
+    if ((rc = b_small.reserve(ctx, ((size_t)2 * nw * PCA_CAP +
+                                    (size_t)nw * UW_SLICES * (PCA_CAP + 1)) * sizeof(double))))
+      return rc;
     double *d_Xp = (double *)b_xp.p, *d_G = (double *)b_g.p;
     double *d_v = (double *)b_cv.p;
     double *d_b = (double *)b_bu.p, *d_u = d_b + (size_t)nw * Nz;
     double *d_cbar = (double *)b_small.p, *d_wq = d_cbar + (size_t)nw * PCA_CAP;
+    double *d_uwpart = d_wq + (size_t)nw * PCA_CAP;
     const long *dLD = dD + (size_t)DF_LD * nw, *dXP = dD + (size_t)DF_XP * nw;
     const long *dG = dD + (size_t)DF_G * nw, *dQ = dD + (size_t)DF_Q * nw;
     const long *dN = dD + (size_t)DF_N * nw, *dC = dD + (size_t)DF_C * nw;
@@ -1299,7 +1346,10 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
       ProfScope ps(ctx, K_PCA_UVEC);
       hipLaunchKernelGGL(xv_kernel, dim3(cdiv(Nz, 4), nw), dim3(64, 4), 0, st, d_Xp, dD, nw, Nz,
                          d_v, d_u);
-      hipLaunchKernelGGL(normalize_kernel, dim3(nw), dim3(1024), 0, st, d_u, Nz, dD, nw, d_U, d_wq);
+      hipLaunchKernelGGL(uw_partial_kernel, dim3(UW_SLICES, nw), dim3(256), 0, st, d_u, Nz, dD, nw,
+                         d_U, d_uwpart);
+      hipLaunchKernelGGL(normalize_kernel, dim3(nw), dim3(1024), 0, st, d_u, Nz, dD, nw, d_U,
+                         d_uwpart, d_wq);
     }
     ORIGIN_LAUNCH_CHECK();
     // ---- deflation (coefficient form): one read pass over the iterating areas
