@@ -276,7 +276,7 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-template <int ORDER>
+template <int ORDER, bool VEC>
 __global__ __launch_bounds__(256) void dct_plane_sums_kernel(
     const float *__restrict__ raw, const uint8_t *__restrict__ mask,
     const double *__restrict__ coef, const double *__restrict__ ctab, long S, int spb,
@@ -291,9 +291,8 @@ __global__ __launch_bounds__(256) void dct_plane_sums_kernel(
   const uint8_t *m = mask + (long)z * S;
   const double *ct = ctab + (long)z * NK;
   double sum = 0.0, cnt = 0.0;
-  for (long s = s0 + threadIdx.x; s < s1; s += 256) {
-    const float v = r[s];
-    if (m[s]) {
+  auto one = [&](long s, float v, uint8_t mk) {
+    if (mk) {
       // masked voxel: remove its continuum from the "all spaxels" term
       double c = coef[s] * ct[0];
 #pragma unroll
@@ -303,6 +302,18 @@ __global__ __launch_bounds__(256) void dct_plane_sums_kernel(
       sum += (double)v;
       cnt += 1.0;
     }
+  };
+  if constexpr (VEC) {  // S % 4 == 0, spb % 4 == 0: 16-byte loads of raw, 4-byte loads of mask
+    for (long s = s0 + 4 * threadIdx.x; s < s1; s += 1024) {
+      const float4 v = *reinterpret_cast<const float4 *>(r + s);
+      const uchar4 mk = *reinterpret_cast<const uchar4 *>(m + s);
+      one(s, v.x, mk.x);
+      one(s + 1, v.y, mk.y);
+      one(s + 2, v.z, mk.z);
+      one(s + 3, v.w, mk.w);
+    }
+  } else {
+    for (long s = s0 + threadIdx.x; s < s1; s += 256) one(s, r[s], m[s]);
   }
   sum = wave_sum(sum);
   cnt = wave_sum(cnt);
@@ -367,8 +378,7 @@ template <int ORDER>
 __global__ __launch_bounds__(256) void dct_standardize_kernel(
     const float *__restrict__ raw, const float *__restrict__ var,
     const uint8_t *__restrict__ mask, const double *__restrict__ coef,
-    const double *__restrict__ ctab, const double *__restrict__ zsum,
-    const double *__restrict__ zcnt, int Nz, long S, int zchunk,
+    const double *__restrict__ ctab, const double *__restrict__ zmean, int Nz, long S, int zchunk,
     float *__restrict__ cube_std, float *__restrict__ cont_dct,
     double *__restrict__ part /* [nzc][3][S] or null */) {
   constexpr int NA = ORDER + 1;
@@ -388,11 +398,13 @@ __global__ __launch_bounds__(256) void dct_standardize_kernel(
     const float v = var[idx];
     const bool mk = mask[idx] != 0;
     const double cont = eval_cont<ORDER>(c, ctab + (long)z * NK);
-    const double mean = zsum[z] / zcnt[z];  // nanmean over unmasked spaxels (steps.py:442)
-    const float sd = sqrtf(v);              // std = sqrt(var)               (steps.py:439)
+    const double mean = zmean[z];           // nanmean over unmasked spaxels (steps.py:442)
+    // std = sqrt(var) (steps.py:439); both quotients share one reciprocal (float32 results
+    // within 2 ulp of the reference's float64 quotient cast to float32)
+    const float rs = 1.0f / sqrtf(v);
     const float t = (float)(((double)r - cont) - mean);
-    const float o = mk ? 0.0f : t / sd;     // data[mask] = 0                (steps.py:446)
-    const float cd = (float)cont / sd;      // cont_dct /= std ; astype(f32) (:440, :463)
+    const float o = mk ? 0.0f : t * rs;     // data[mask] = 0                (steps.py:446)
+    const float cd = (float)cont * rs;      // cont_dct /= std ; astype(f32) (:440, :463)
     cube_std[idx] = o;
     if (cont_dct) cont_dct[idx] = cd;
     a_std += (double)o;
@@ -405,6 +417,14 @@ __global__ __launch_bounds__(256) void dct_standardize_kernel(
     p[S] = a_dct;
     p[2 * S] = a_o2;
   }
+}
+
+// the per-channel mean is wave-uniform: divide once per channel, not once per voxel
+__global__ __launch_bounds__(256) void zmean_kernel(const double *__restrict__ zsum,
+                                                    const double *__restrict__ zcnt, int Nz,
+                                                    double *__restrict__ zmean) {
+  const int z = blockIdx.x * 256 + threadIdx.x;
+  if (z < Nz) zmean[z] = zsum[z] / zcnt[z];
 }
 
 __global__ __launch_bounds__(256) void std_images_final_kernel(const double *__restrict__ part,
@@ -565,8 +585,9 @@ int origin_dct_resid_sums(origin_ctx *ctx, const float *d_raw, const uint8_t *d_
   CtabGuard tab(ctx);
   rc = make_ctab(ctx, Nz, order, &tab.p);
   if (rc) return rc;
-  const int spb = 4096;
+  const int spb = 8192;
   const int nchunk = cdiv(S, spb);
+  const bool vec = (S & 3) == 0;
   void *scr = nullptr;
   const size_t part_bytes = (size_t)Nz * nchunk * 2 * sizeof(double);
   rc = origin_scratch(ctx, part_bytes + 64 * sizeof(double), &scr);
@@ -578,8 +599,12 @@ int origin_dct_resid_sums(origin_ctx *ctx, const float *d_raw, const uint8_t *d_
                      ctot);
   dim3 grid(nchunk, Nz);
 #define CALL(O)                                                                                \
-  hipLaunchKernelGGL(dct_plane_sums_kernel<O>, grid, dim3(256), 0, ctx->stream, d_raw, d_mask, \
-                     d_coef, tab.p, S, spb, part);                                             \
+  if (vec)                                                                                     \
+    hipLaunchKernelGGL((dct_plane_sums_kernel<O, true>), grid, dim3(256), 0, ctx->stream, d_raw, \
+                       d_mask, d_coef, tab.p, S, spb, part);                                   \
+  else                                                                                         \
+    hipLaunchKernelGGL((dct_plane_sums_kernel<O, false>), grid, dim3(256), 0, ctx->stream,     \
+                       d_raw, d_mask, d_coef, tab.p, S, spb, part);                            \
   hipLaunchKernelGGL(dct_zsum_final_kernel<O>, dim3(cdiv(Nz, 256)), dim3(256), 0, ctx->stream, \
                      part, ctot, tab.p, Nz, nchunk, d_zsum, d_zcnt)
   DISPATCH_ORDER(order, CALL)
@@ -606,19 +631,22 @@ int origin_dct_standardize(origin_ctx *ctx, const float *d_raw, const float *d_v
   const int zchunk = cdiv(Nz, nzc0);
   const int nzc = cdiv(Nz, zchunk);
   const bool want = d_ima_std || d_ima_dct || d_o2;
-  double *part = nullptr;
-  if (want) {
+  double *part = nullptr, *zmean = nullptr;
+  {
     void *scr = nullptr;
-    rc = origin_scratch(ctx, (size_t)nzc * 3 * S * sizeof(double), &scr);
+    const size_t pbytes = want ? (size_t)nzc * 3 * S * sizeof(double) : 0;
+    rc = origin_scratch(ctx, pbytes + (size_t)Nz * sizeof(double), &scr);
     if (rc) return rc;
-    part = (double *)scr;
+    if (want) part = (double *)scr;
+    zmean = (double *)((char *)scr + pbytes);
   }
   dim3 grid(cdiv(S, 256), nzc);
   ProfScope ps(ctx, K_DCT_STANDARDIZE);
+  hipLaunchKernelGGL(zmean_kernel, dim3(cdiv(Nz, 256)), dim3(256), 0, ctx->stream, d_zsum, d_zcnt,
+                     Nz, zmean);
 #define CALL(O)                                                                               \
   hipLaunchKernelGGL(dct_standardize_kernel<O>, grid, dim3(256), 0, ctx->stream, d_raw, d_var, \
-                     d_mask, d_coef, tab.p, d_zsum, d_zcnt, Nz, S, zchunk, d_cube_std,        \
-                     d_cont_dct, part)
+                     d_mask, d_coef, tab.p, zmean, Nz, S, zchunk, d_cube_std, d_cont_dct, part)
   DISPATCH_ORDER(order, CALL)
 #undef CALL
   ORIGIN_LAUNCH_CHECK();
