@@ -327,3 +327,9 @@ def test_errors_are_raised_not_aborted(ctx):
     assert e.value.code == -1 and "order" in str(e.value)
     with pytest.raises(_capi.OriginHipError):
         kernels.GLRPlan(ctx, (8, 4, 4), np.ones((8, 4, 4)), None, [np.ones(5)])  # even PSF
+
+
+def test_graft_entry_smoke():
+    """The driver's smoke(): small Step chain on the GPU against the oracle."""
+    import __graft_entry__
+    __graft_entry__.smoke()
