@@ -214,6 +214,7 @@ def main():
         "glr_spectral": ("mfma", 2.0 * ntaps * local_vox),
     }
     glr_precision = (glr.plan if world > 1 else plan).precision
+    ext_vox = local_vox
     if world > 1:  # the GLR runs on the halo-extended tile
         ext_vox = float(Nz) * glr.eshape[1] * glr.eshape[2]
         algo["glr_spatial"] = ("mfma", 2.0 * 25 * 25 * ext_vox)
@@ -229,18 +230,33 @@ def main():
         avg_s = tot_ms / launches / 1e3
         if dominant.startswith("pca_deflate"):
             per_launch = per_launch * local_vox  # upper bound: every area active
+        extra = {}
         if bound == "hbm":
             ach, peak, unit = per_launch / avg_s / 1e9, HBM_PEAK_GBS, "GB/s"
         else:
-            # the spectral stage runs on f16 matrix cores (3 MFMA terms per product, banded
-            # Toeplitz operand) unless the plan was told to stay in fp32; the spatial stage is
-            # fp32 packed FMA (vector = matrix rate for fp32 on gfx950)
-            f16 = dominant == "glr_spectral" and glr_precision == "f16x2"
+            # Both GLR stages run on the f16 matrix cores (two-term split of both operands = 3
+            # MFMAs per product, banded Toeplitz operand) unless the plan stays in fp32.
+            # `achieved` is the ALGORITHMIC rate (2 flop per tap and voxel); `executed` counts
+            # what the matrix cores really do (MFMAs x 32768 flop), `fp32_frac` prices the
+            # algorithmic rate against the fp32 FMA peak the same problem has without them.
+            gplan = glr.plan if world > 1 else plan
+            vox = ext_vox if world > 1 else local_vox
+            on_mfma = (dominant == "glr_spectral" and glr_precision == "f16x2") or \
+                      (dominant == "glr_spatial" and gplan.spatial_on_matrix_cores)
             ach, unit = per_launch / avg_s / 1e12, "TFLOP/s"
-            peak = F16_MFMA_PEAK_TFLOPS if f16 else FP32_PEAK_TFLOPS
+            peak = F16_MFMA_PEAK_TFLOPS if on_mfma else FP32_PEAK_TFLOPS
+            if on_mfma:
+                if dominant == "glr_spectral":
+                    nks = sum(6 if (n - 1) // 2 > 16 else 4 for n in gplan.tap_lengths)
+                    mfma_per_vox = 3.0 * nks / 1024.0
+                else:
+                    mfma_per_vox = 3.0 * 4 * gplan.P / 1024.0
+                ex = mfma_per_vox * 32768.0 * vox / avg_s / 1e12
+                extra = dict(executed=round(ex, 1), executed_frac=round(ex / peak, 4),
+                             fp32_frac=round(ach / FP32_PEAK_TFLOPS, 4), arithmetic="f16x2 MFMA")
         roofline = dict(bound=bound, kernel=dominant, achieved=round(ach, 3), peak=peak,
                         unit=unit, frac=round(ach / peak, 4), traffic=None,
-                        avg_launch_ms=round(tot_ms / launches, 4), launches=launches)
+                        avg_launch_ms=round(tot_ms / launches, 4), launches=launches, **extra)
 
     # ---- CPU baseline: the oracle on a centred crop, all host cores, rank 0, N == 1 ----
     cpu_baseline = None

@@ -1409,6 +1409,13 @@ int origin_glr_run(origin_ctx *ctx, origin_glr_plan *pl, const float *d_cube,
     ProfScope ps(ctx, K_GLR_SPATIAL);
     const float *kf = pl->d_k + (size_t)f * Nz * P * P;
     const float *wf = pl->d_w ? pl->d_w + (size_t)f * S : nullptr;
+    if (pl->mode == 0 && pl->precision == 1 && !wf && pl->nfields == 1 &&
+        origin_spatial_mfma_ok(Ny, Nx, P)) {
+      // matrix cores, two-term f16 split (glr_spatial_mfma.hip)
+      int rc = origin_spatial_mfma_launch(ctx, d_cube, kf, Nz, Ny, Nx, P, fsf);
+      if (rc) return rc;
+      continue;
+    }
     spatial(d_cube, wf, kf, f > 0, fsf);
     if (pl->mode == 1) {
       const float *k2f = pl->d_k2 + (size_t)f * Nz * P * P;

@@ -135,6 +135,9 @@ class GLRPlan:
         got = C.c_int()
         _capi.call("origin_glr_plan_get_precision", self._h, C.byref(got))
         self.precision = "f16x2" if got.value == 1 else "f32"
+        # mirrors origin_spatial_mfma_ok (csrc/glr_spatial_mfma.hip): which spatial kernel runs
+        self.spatial_on_matrix_cores = (self.precision == "f16x2" and w is None and
+                                        self.P <= 25 and (self.P // 2) % 4 == 0 and Nx % 4 == 0)
 
     def close(self):
         if self._h is not None and self._h.value:

@@ -231,6 +231,36 @@ def test_glr_golden_both_arithmetics(ctx, name, precision):
     plan.close()
 
 
+@pytest.mark.parametrize("shape,P", [((70, 67, 132), 25), ((40, 30, 20), 25), ((50, 26, 140), 9),
+                                      ((33, 130, 260), 17)])
+def test_glr_matrix_core_spatial_stage(ctx, shape, P):
+    """Shapes that take the matrix-core spatial kernel (Nx % 4 == 0, P in 9/17/25): several
+    128x64 regions, partial regions, fields narrower than a region, against the float64 oracle
+    and against the fp32 kernels."""
+    from origin_amd import kernels
+    rng = np.random.default_rng(P + shape[2])
+    Nz, Ny, Nx = shape
+    cube = rng.standard_normal(shape).astype(np.float32)
+    cube[Nz // 2, Ny // 2, Nx // 3] += 40.0
+    psf = synth.moffat_psf(Nz, P).astype(np.float64)
+    psf *= 1.0 + 0.3 * rng.random(psf.shape)          # asymmetric in x and y
+    psf /= psf.sum(axis=(1, 2), keepdims=True)
+    prof = synth.dico_fwhm(3)
+    ref = cpu_ref.Correlation_GLR_test(cube.astype(np.float64), psf, None, prof, nthreads=1,
+                                       pcut=1e-8, pmeansub=True)
+    d = ctx.to_device(cube)
+    got = {}
+    for prec in ("f16x2", "f32"):
+        plan = kernels.GLRPlan(ctx, shape, psf, None, prof, 1e-8, True, precision=prec)
+        out = plan.run(d, mask=None, want_maps=False)
+        got[prec] = out["correl"].to_host()
+        assert np.max(np.abs(got[prec] - ref[0])) <= 1e-4
+        assert np.max(np.abs(out["correl_min"].to_host() - ref[2])) <= 1e-4
+        assert np.mean(out["profile"].to_host() != ref[1]) <= 1e-4
+        plan.close()
+    assert np.max(np.abs(got["f16x2"] - got["f32"])) <= 1e-4
+
+
 def test_glr_f16_split_survives_huge_dynamic_range(ctx):
     """Per-tile power-of-two scaling: slabs of channels at 1e-6, 1 and 1e+7 times unit noise must
     neither overflow the f16 halves nor lose the faint slabs.  Error bound relative to the
