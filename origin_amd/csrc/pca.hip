@@ -120,13 +120,32 @@ __global__ __launch_bounds__(1024) void pca_select_kernel(
   }
   const double thr = thr_[a];
   BlockScan scan{wtot};
-  // the selection makes ~11 passes over the area's O2 values: keep them in LDS
+  // the selection makes ~11 passes over the area's O2 values: keep them (and the spaxel list)
+  // in LDS.  Filling is two batches of independent loads (index, then value): every dependent
+  // global read costs an L2 round trip of ~0.7 us.
   const bool cached = ns <= lds_cap;
+  int *scache = reinterpret_cast<int *>(tcache + lds_cap);
   if (cached) {
-    for (int i = tid; i < ns; i += 1024) tcache[i] = test[spx[o0 + i]];
+    for (int c0 = 0; c0 < ns; c0 += 8 * 1024) {
+      int sp[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int i = c0 + tid + 1024 * e;
+        sp[e] = i < ns ? spx[o0 + i] : -1;
+      }
+      double tv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) tv[e] = sp[e] >= 0 ? test[sp[e]] : 0.0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int i = c0 + tid + 1024 * e;
+        if (i < ns) tcache[i] = tv[e], scache[i] = sp[e];
+      }
+    }
     __syncthreads();
   }
   auto tval = [&](int i) -> double { return cached ? tcache[i] : test[spx[o0 + i]]; };
+  auto sval = [&](long i) -> int { return cached ? scache[i] : spx[o0 + i]; };
 
   // ---- pass 1: nuisance compaction in index order (np.where(test > thr)), candidates count
   int n = 0, ncand = 0;
@@ -135,7 +154,7 @@ __global__ __launch_bounds__(1024) void pca_select_kernel(
     const bool valid = i < ns;
     const double t = valid ? tval(i) : 0.0;
     const bool isn = valid && (t > thr);
-    const int sp = isn ? spx[o0 + i] : 0;
+    const int sp = isn ? sval(i) : 0;
     const bool cand = valid && (t > 0.0) && (t <= thr);
     int tot;
     const int r = scan.exclusive(isn, tot);
@@ -238,7 +257,7 @@ __global__ __launch_bounds__(1024) void pca_select_kernel(
       const bool emit = cand && (key < tau || (eq && (neq + re) < need_equal));
       const int rm = scan.exclusive(emit, tm);
       if (emit) {
-        bg[o0 + nemit + rm] = spx[o0 + nfilt + rf];
+        bg[o0 + nemit + rm] = sval(nfilt + rf);
         bg_pos[o0 + nemit + rm] = (int)(o0 + nfilt + rf);
       }
       nfilt += tf;
@@ -269,10 +288,20 @@ __global__ __launch_bounds__(1024) void cbar_kernel(const double *__restrict__ C
   const int nb = (int)DSC(DF_NB, k);
   const long o0 = DSC(DF_LIST0, k);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // every read below is an L2 round trip (~0.7 us): fetch the positions once, then keep the
+  // gathers of a row independent (first 8 positions per lane from registers)
+  int pos[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) pos[e] = lane + 64 * e < nb ? bg_pos[o0 + lane + 64 * e] : -1;
   for (int q = wave; q < T; q += 16) {
     const double *row = C + (long)q * ntot;
+    double v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = pos[e] >= 0 ? row[pos[e]] : 0.0;
     double acc = 0.0;
-    for (int i = lane; i < nb; i += 64) acc += row[bg_pos[o0 + i]];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc += v[e];  // same order as the plain loop
+    for (int i = lane + 512; i < nb; i += 64) acc += row[bg_pos[o0 + i]];
     acc = wave_sum_d(acc);
     if (lane == 0) cbar[(long)k * PCA_CAP + q] = acc / (double)nb;
   }
@@ -920,9 +949,29 @@ __global__ __launch_bounds__(256) void deflate_finish_kernel(const int *__restri
   const long pos = DSC(DF_LIST0, k) + li;
   const long ci = DSC(DF_CBASE, k) + li;
   double c = 0.0;
-  for (int q = 0; q < nzs; ++q) c += cpart[(long)q * cb_tot + ci];
+  {  // loads of a batch are independent (L2 latency), the sums keep their order
+    int q = 0;
+    for (; q + 8 <= nzs; q += 8) {
+      double v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = cpart[(long)(q + e) * cb_tot + ci];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) c += v[e];
+    }
+    for (; q < nzs; ++q) c += cpart[(long)q * cb_tot + ci];
+  }
   const double *w = wq + (long)k * PCA_CAP;
-  for (int q = 0; q < T; ++q) c = fma(-w[q], C[(long)q * ntot + pos], c);
+  {
+    int q = 0;
+    for (; q + 8 <= T; q += 8) {
+      double v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = C[(long)(q + e) * ntot + pos];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) c = fma(-w[q + e], v[e], c);
+    }
+    for (; q < T; ++q) c = fma(-w[q], C[(long)q * ntot + pos], c);
+  }
   C[(long)T * ntot + pos] = c;
   const long sp = spx[pos];
   test[sp] = test[sp] - c * c / (double)Nz;
@@ -1209,8 +1258,8 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
   // LDS cache of the select kernel: the largest area, if it fits in 120 KiB
   int nsmax_all = 0;
   for (int a = 0; a < na; ++a) nsmax_all = std::max(nsmax_all, (int)(h_spx_off[a + 1] - h_spx_off[a]));
-  int sel_cap = nsmax_all <= 15360 ? nsmax_all : 0;
-  size_t sel_lds = (size_t)sel_cap * sizeof(double);
+  int sel_cap = nsmax_all <= 12288 ? nsmax_all : 0;  // 12 B per spaxel: O2 value + spaxel index
+  size_t sel_lds = (size_t)sel_cap * (sizeof(double) + sizeof(int));
   if (sel_lds > 48 * 1024 &&
       hipFuncSetAttribute((const void *)pca_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)sel_lds) != hipSuccess) {
