@@ -32,6 +32,7 @@ enum OriginKernelId {
   K_GLR_TABLES,
   K_LOCAL_MAX,
   K_SMALL,
+  K_PCA_TOTAL,  // the whole greedy PCA as one scope (level 1; its kernels are level-2 scopes)
   K_COUNT
 };
 
@@ -54,7 +55,7 @@ struct origin_ctx {
   double *ctab;
   int ctab_nz, ctab_order;
   // per-kernel-class timing with HIP events on the stream the kernels run on
-  bool prof_on;
+  int prof_level;  // 0 off, 1 coarse (one scope per large kernel / per PCA run), 2 + every PCA kernel
   std::vector<OriginProfEvent> prof_pending;
   std::vector<hipEvent_t> prof_free;
   double prof_ms[K_COUNT];
@@ -64,24 +65,29 @@ struct origin_ctx {
   void (*pca_ws_free)(void *);
 };
 
-void origin_prof_begin(origin_ctx *ctx, int id);
-void origin_prof_end(origin_ctx *ctx);
-// close the open scope and open a new one of class `id` (no-op when profiling is off)
-static inline void origin_prof_end_begin(origin_ctx *ctx, int id) {
-  if (ctx->prof_on) {
-    origin_prof_end(ctx);
-    origin_prof_begin(ctx, id);
-  }
-}
+// An event pair costs ~10 us of stream time on this hardware (barrier packets): 13 scopes in each
+// of the 56 PCA iterations add 5 ms to a 95 ms step.  Scopes therefore carry a level; bench.py
+// times its steps at level 1 (a handful of pairs per step) and takes the per-kernel PCA detail
+// from an extra, untimed step at level 2.
+int origin_prof_begin(origin_ctx *ctx, int id);  // returns the entry index
+void origin_prof_end(origin_ctx *ctx, int entry);
 
 // RAII: times everything enqueued on ctx->stream during its lifetime as kernel class `id`
 struct ProfScope {
   origin_ctx *ctx;
-  ProfScope(origin_ctx *c, int id) : ctx(c) {
-    if (ctx->prof_on) origin_prof_begin(ctx, id);
+  int entry;
+  ProfScope(origin_ctx *c, int id, int level = 1) : ctx(c), entry(-1) {
+    if (ctx->prof_level >= level) entry = origin_prof_begin(ctx, id);
+  }
+  // close the scope and open a new one of class `id` (same level)
+  void next(int id) {
+    if (entry >= 0) {
+      origin_prof_end(ctx, entry);
+      entry = origin_prof_begin(ctx, id);
+    }
   }
   ~ProfScope() {
-    if (ctx->prof_on) origin_prof_end(ctx);
+    if (entry >= 0) origin_prof_end(ctx, entry);
   }
 };
 

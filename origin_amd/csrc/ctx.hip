@@ -70,21 +70,21 @@ static void prof_drain(origin_ctx *ctx) {
   ctx->prof_pending.clear();
 }
 
-void origin_prof_begin(origin_ctx *ctx, int id) {
+int origin_prof_begin(origin_ctx *ctx, int id) {
   OriginProfEvent p;
   p.a = prof_event(ctx);
   p.b = nullptr;
   p.id = id;
   if (p.a) (void)hipEventRecord(p.a, ctx->stream);
   ctx->prof_pending.push_back(p);
+  return (int)ctx->prof_pending.size() - 1;
 }
 
-void origin_prof_end(origin_ctx *ctx) {
-  if (ctx->prof_pending.empty()) return;
-  OriginProfEvent &p = ctx->prof_pending.back();
+void origin_prof_end(origin_ctx *ctx, int entry) {
+  if (entry < 0 || entry >= (int)ctx->prof_pending.size()) return;
+  OriginProfEvent &p = ctx->prof_pending[entry];
   p.b = prof_event(ctx);
   if (p.b) (void)hipEventRecord(p.b, ctx->stream);
-  if (ctx->prof_pending.size() > 4096) prof_drain(ctx);
 }
 
 static const char *kKernelNames[K_COUNT] = {
@@ -92,14 +92,14 @@ static const char *kKernelNames[K_COUNT] = {
     "pca_select",      "pca_bmean",          "pca_gather",      "pca_project",   "pca_gram",
     "pca_eig",         "pca_uvec",
     "pca_deflate_dot", "pca_deflate_finish", "pca_flush", "glr_spatial",     "glr_spectral",  "glr_border", "glr_tables",
-    "local_max",       "small"};
+    "local_max",       "small",              "pca_total"};
 
 extern "C" {
 
 int origin_prof_enable(origin_ctx *ctx, int on) {
   ORIGIN_USE(ctx);
   prof_drain(ctx);
-  ctx->prof_on = on != 0;
+  ctx->prof_level = on < 0 ? 0 : (on > 2 ? 2 : on);
   return ORIGIN_OK;
 }
 
@@ -158,7 +158,7 @@ int origin_ctx_create(int device, origin_ctx **out) {
   ctx->num_cu = 0;
   ctx->ctab = nullptr;
   ctx->ctab_nz = ctx->ctab_order = 0;
-  ctx->prof_on = false;
+  ctx->prof_level = false;
   ctx->pca_ws = nullptr;
   ctx->pca_ws_free = nullptr;
   memset(ctx->prof_ms, 0, sizeof(ctx->prof_ms));

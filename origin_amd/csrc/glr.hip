@@ -1492,7 +1492,7 @@ int origin_glr_run(origin_ctx *ctx, origin_glr_plan *pl, const float *d_cube,
     if (gen) LAUNCH((spectral_generic_kernel<true>)); else LAUNCH((spectral_generic_kernel<false>));
   }
   if (packed && pl->nborder > 0) {  // border spaxels: exact per-class normalisation
-    origin_prof_end_begin(ctx, K_GLR_BORDER);
+    ps.next(K_GLR_BORDER);
     // few spaxels: cut z finer so that the pass still fills the chip (its maps are redone
     // from the final cubes below, so it writes no partials)
     const long bb = cdiv(pl->nborder, 256);

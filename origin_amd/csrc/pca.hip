@@ -1085,7 +1085,7 @@ int gram_launch(origin_ctx *ctx, const double *d_Xp, const long *d_xp_off, const
   void *scr = nullptr;
   int rc = origin_scratch(ctx, (size_t)ksplit * g_total * sizeof(double), &scr);
   if (rc) return rc;
-  ProfScope ps(ctx, K_PCA_GRAM);
+  ProfScope ps(ctx, K_PCA_GRAM, 2);
   hipLaunchKernelGGL(gram_kernel, dim3(ntiles, ksplit), dim3(64), 0, ctx->stream, d_Xp, d_xp_off,
                      d_ld, d_ti, d_tj, d_ta, Nz, ksplit, (double *)scr, d_g_off, g_total);
   hipLaunchKernelGGL(gram_reduce_kernel, dim3(ntiles), dim3(256), 0, ctx->stream,
@@ -1129,7 +1129,7 @@ int origin_pca_eig(origin_ctx *ctx, const double *d_G, const long *d_g_off, cons
   ORIGIN_HIP(hipStreamSynchronize(ctx->stream));
   long ldmax = 0;
   for (long x : h_ld) ldmax = std::max(ldmax, x);
-  ProfScope ps(ctx, K_PCA_EIG);
+  ProfScope ps(ctx, K_PCA_EIG, 2);
   return eig_launch(ctx, nmat, ldmax, d_G, d_g_off, d_ld, d_n, (double *)scr, d_q_off, d_v, d_v_off,
                     d_info);
 }
@@ -1147,6 +1147,7 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
                        Nz > 0 && S > 0 && na > 0,
                    "bad arguments");
   ORIGIN_CHECK_ARG(noise_pop > 0 && itermax >= 0, "bad Noise_population / itermax");
+  ProfScope ps_total(ctx, K_PCA_TOTAL, 1);
   if (!d_X) d_X = d_F;
   const float *src = d_X;  // where the not-yet-deflated cube is read from
   const long ntot = h_spx_off[na];
@@ -1245,7 +1246,7 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
       ORIGIN_HIP(hipMemcpyAsync(b_fd.p, fd.data(), fd.size() * sizeof(long), hipMemcpyHostToDevice,
                                 st));
       ORIGIN_HIP(hipStreamSynchronize(st));
-      ProfScope ps(ctx, K_PCA_FLUSH);
+      ProfScope ps(ctx, K_PCA_FLUSH, 2);
       hipLaunchKernelGGL(flush_kernel, dim3(cdiv(nsmax, 256), cdiv(Nz, 16), nf), dim3(256), 0, st,
                          src, d_F, Nz, S, d_spx, (const long *)b_fd.p, nf, d_U, d_C, ntot);
       ORIGIN_LAUNCH_CHECK();
@@ -1290,7 +1291,7 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
   int iters = 0;
   for (;;) {
     {
-      ProfScope ps(ctx, K_PCA_SELECT);
+      ProfScope ps(ctx, K_PCA_SELECT, 2);
       hipLaunchKernelGGL(pca_select_kernel, dim3(na), dim3(1024), sel_lds, st, d_spx, d_spx_off,
                          d_test, d_thr, noise_pop, itermax, d_active, d_nbiter, d_nstop, d_mapO2,
                          d_nuis, d_bg, d_nuis_pos, d_bg_pos, d_n, d_nb, sel_cap);
@@ -1386,7 +1387,7 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
     const long *dN = dD + (size_t)DF_N * nw, *dC = dD + (size_t)DF_C * nw;
 
     {
-      ProfScope ps(ctx, K_PCA_BMEAN);
+      ProfScope ps(ctx, K_PCA_BMEAN, 2);
       hipLaunchKernelGGL(cbar_kernel, dim3(nw), dim3(1024), 0, st, d_C, ntot, d_bg_pos, dD, nw,
                          d_cbar);
       hipLaunchKernelGGL(bmean_kernel, dim3(cdiv(Nz, 4), nw), dim3(64, 4), 0, st, src, Nz, S, d_bg,
@@ -1401,13 +1402,13 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
     if ((rc = b_cpart.reserve(ctx, (size_t)nzb * c * sizeof(double)))) return rc;
     double *d_cpart = (double *)b_cpart.p;
     {
-      ProfScope ps(ctx, K_PCA_GATHER);
+      ProfScope ps(ctx, K_PCA_GATHER, 2);
       hipLaunchKernelGGL(gather_xp_kernel, dim3(cdiv(ldmax, 64), nw, nzb), dim3(64, 16), 0, st,
                          src, Nz, S, d_nuis, d_nuis_pos, dD, nw, d_b, d_U, d_C, ntot, d_Xp, d_cpart,
                          c, gzper);
     }
     {
-      ProfScope ps(ctx, K_PCA_PROJECT);
+      ProfScope ps(ctx, K_PCA_PROJECT, 2);
       hipLaunchKernelGGL(project_xp_kernel, dim3(cdiv(Nz, 16), nw), dim3(256), 0, st, d_b, Nz, dD,
                          nw, d_Xp, d_cpart, c, nzb);
     }
@@ -1423,7 +1424,7 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
         d_info = (double *)b_info.p;
       }
       {
-        ProfScope ps(ctx, K_PCA_EIG);
+        ProfScope ps(ctx, K_PCA_EIG, 2);
         if ((rc = eig_launch(ctx, nw, ldmax, d_G, dG, dLD, dN, (double *)scr, dQ, d_v, dC, d_info)))
           return rc;
       }
@@ -1445,7 +1446,7 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
       }
     }
     {
-      ProfScope ps(ctx, K_PCA_UVEC);
+      ProfScope ps(ctx, K_PCA_UVEC, 2);
       hipLaunchKernelGGL(xv_kernel, dim3(cdiv(Nz, 4), nw), dim3(64, 4), 0, st, d_Xp, dD, nw, Nz,
                          d_v, d_u);
       hipLaunchKernelGGL(uw_partial_kernel, dim3(UW_SLICES, nw), dim3(256), 0, st, d_u, Nz, dD, nw,
@@ -1465,12 +1466,12 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
     if ((rc = origin_scratch(ctx, (size_t)nzs * cb * sizeof(double), &scr))) return rc;
     double *cpart = (double *)scr;
     {
-      ProfScope ps(ctx, K_PCA_DEFLATE_DOT);
+      ProfScope ps(ctx, K_PCA_DEFLATE_DOT, 2);
       hipLaunchKernelGGL(deflate_dot_kernel, dim3(cdiv(nsmax, 256), nzs, nw), dim3(256), 0, st, src,
                          Nz, S, d_spx, dD, nw, d_u, zper, cpart, cb);
     }
     {
-      ProfScope ps(ctx, K_PCA_DEFLATE_UPDATE);
+      ProfScope ps(ctx, K_PCA_DEFLATE_UPDATE, 2);
       hipLaunchKernelGGL(deflate_finish_kernel, dim3(cdiv(nsmax, 256), nw), dim3(256), 0, st, d_spx,
                          dD, nw, nzs, Nz, cb, cpart, d_wq, d_C, ntot, d_test);
     }

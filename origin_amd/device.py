@@ -62,8 +62,10 @@ class Context:
         return ms.value
 
     # -- built-in per-kernel-class profiler (HIP events on the stream) --------
-    def prof_enable(self, on=True):
-        _capi.call("origin_prof_enable", self._h, int(bool(on)))
+    def prof_enable(self, level=1):
+        """0 / False: off.  1 / True: one HIP-event pair per large kernel and per greedy-PCA run.
+        2: every PCA kernel as well (an event pair costs ~10 us of stream time: ~5 ms per step)."""
+        _capi.call("origin_prof_enable", self._h, int(level))
 
     def prof_reset(self):
         _capi.call("origin_prof_reset", self._h)
