@@ -276,6 +276,206 @@ __global__ __launch_bounds__(1024) void pca_select_kernel(
   }
 }
 
+// Same selection for areas of at most 1024 * SEL_EPT spaxels (every 100 x 100 area), built for
+// the latency of a one-block kernel: thread t owns the SEL_EPT consecutive list entries
+// [t*E, (t+1)*E) in registers, so index order is (thread, local) order and each compaction is ONE
+// block scan of per-thread counts instead of one scan per 1024-entry chunk (3 scans + the 8
+// radix passes instead of ~50 scans).  Results are identical to pca_select_kernel.
+constexpr int SEL_EPT = 12;
+
+__device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long v,
+                                                             unsigned long long *wsum,
+                                                             unsigned long long &total) {
+  // inclusive scan inside the wave, exclusive across waves; returns the exclusive prefix
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned long long o = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += o;
+  }
+  __syncthreads();  // previous users of wsum are done
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  unsigned long long pre = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    const unsigned long long c = wsum[w];
+    pre += (w < wave) ? c : 0ull;
+    tot += c;
+  }
+  total = tot;
+  return pre + incl - v;
+}
+
+__global__ __launch_bounds__(1024) void pca_select_fast_kernel(
+    const int *__restrict__ spx, const long *__restrict__ spx_off, const double *__restrict__ test,
+    const double *__restrict__ thr_, double noise_pop, int itermax, int *__restrict__ active,
+    int *__restrict__ nbiter, int *__restrict__ nstop, int *__restrict__ mapO2,
+    int *__restrict__ nuis, int *__restrict__ bg, int *__restrict__ nuis_pos,
+    int *__restrict__ bg_pos, int *__restrict__ n_out, int *__restrict__ nb_out) {
+  __shared__ unsigned long long wsum[16];
+  __shared__ int hist[256];
+  __shared__ unsigned long long s_prefix;
+  __shared__ int s_remaining, s_it;
+  extern __shared__ int scache[];  // spaxel index of every list entry (for the filtered-index quirk)
+  const int a = blockIdx.x;
+  const int tid = threadIdx.x;
+  const long o0 = spx_off[a];
+  const int ns = (int)(spx_off[a + 1] - o0);
+  if (!active[a]) {
+    if (tid == 0) n_out[a] = 0, nb_out[a] = 0;
+    return;
+  }
+  const double thr = thr_[a];
+  const int E = (ns + 1023) / 1024;  // entries per thread (<= SEL_EPT)
+  const int i0 = tid * E;
+  // two batches of independent loads: indices, then values
+  int sp[SEL_EPT];
+  double tv[SEL_EPT];
+#pragma unroll
+  for (int e = 0; e < SEL_EPT; ++e) sp[e] = (e < E && i0 + e < ns) ? spx[o0 + i0 + e] : -1;
+#pragma unroll
+  for (int e = 0; e < SEL_EPT; ++e) tv[e] = sp[e] >= 0 ? test[sp[e]] : 0.0;
+#pragma unroll
+  for (int e = 0; e < SEL_EPT; ++e)
+    if (sp[e] >= 0) scache[i0 + e] = sp[e];
+
+  // ---- counts: nuisance (t > thr), candidates (0 < t <= thr), positive (t > 0)
+  unsigned long long cnt = 0;  // [nuis | cand | pos] x 20 bits
+#pragma unroll
+  for (int e = 0; e < SEL_EPT; ++e) {
+    const bool v = sp[e] >= 0;
+    const bool isn = v && tv[e] > thr, pos = v && tv[e] > 0.0, cand = pos && tv[e] <= thr;
+    cnt += ((unsigned long long)isn << 40) + ((unsigned long long)cand << 20) + (unsigned long long)pos;
+  }
+  unsigned long long tot;
+  const unsigned long long pre = block_scan_u64(cnt, wsum, tot);
+  const int n = (int)(tot >> 40), ncand = (int)((tot >> 20) & 0xfffff);
+  if (n == 0) {  // while len(pypx) > 0                                           (lib :899)
+    if (tid == 0) active[a] = 0, n_out[a] = 0, nb_out[a] = 0;
+    return;
+  }
+  {  // nuisance compaction in index order (np.where(test > thr)); mapO2[pypx] += 1   (lib :901, before the itermax test)
+    int rn = (int)(pre >> 40);
+#pragma unroll
+    for (int e = 0; e < SEL_EPT; ++e)
+      if (sp[e] >= 0 && tv[e] > thr) {
+        nuis[o0 + rn] = sp[e];
+        nuis_pos[o0 + rn] = (int)(o0 + i0 + e);
+        mapO2[sp[e]] += 1;
+        ++rn;
+      }
+  }
+  if (tid == 0) {
+    const int it = nbiter[a] + 1;  // nbiter += 1                                 (lib :900)
+    nbiter[a] = it;
+    s_it = it;
+  }
+  __syncthreads();
+  if (s_it > itermax) {  // if nbiter > itermax: nstop += 1; break          (lib :902-905)
+    if (tid == 0) {
+      atomicAdd(nstop, 1);
+      active[a] = 0;
+      n_out[a] = 0;
+      nb_out[a] = 0;
+    }
+    return;
+  }
+  // nb = 1 + int(len(nind) / Noise_population), clipped by the slice [:nb]     (lib :914-917)
+  int nb = 1 + (int)floor((double)ncand / noise_pop);
+  if (nb > ncand) nb = ncand;
+
+  if (nb > 0) {
+    // ---- radix select of the nb-th smallest candidate (keys: bits of positive doubles)
+    if (tid == 0) s_prefix = 0ull, s_remaining = nb - 1;
+    unsigned long long maskbits = 0ull;
+    for (int pass = 7; pass >= 0; --pass) {
+      const int shift = pass * 8;
+      if (tid < 256) hist[tid] = 0;
+      __syncthreads();
+      const unsigned long long prefix = s_prefix;
+#pragma unroll
+      for (int e = 0; e < SEL_EPT; ++e)
+        if (sp[e] >= 0 && tv[e] > 0.0 && tv[e] <= thr) {
+          const unsigned long long key = (unsigned long long)__double_as_longlong(tv[e]);
+          if ((key & maskbits) == prefix) atomicAdd(&hist[(int)((key >> shift) & 255ull)], 1);
+        }
+      __syncthreads();
+      if (tid < 64) {  // wave 0: bucket holding rank `remaining` via a 64-lane prefix scan
+        const int rem0 = s_remaining;
+        const int h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2],
+                  h3 = hist[4 * tid + 3];
+        const int mine = h0 + h1 + h2 + h3;
+        int incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const int v = __shfl_up(incl, off, 64);
+          if ((int)tid >= off) incl += v;
+        }
+        const int excl = incl - mine;
+        if (rem0 >= excl && rem0 < incl) {  // exactly one lane
+          int rem = rem0 - excl, b = 4 * tid;
+          if (rem >= h0) {
+            rem -= h0, ++b;
+            if (rem >= h1) {
+              rem -= h1, ++b;
+              if (rem >= h2) rem -= h2, ++b;
+            }
+          }
+          s_remaining = rem;
+          s_prefix = prefix | ((unsigned long long)b << shift);
+        }
+      }
+      maskbits |= 255ull << shift;
+      __syncthreads();
+    }
+    const unsigned long long tau = s_prefix;
+    const int need_equal = s_remaining + 1;
+    // ---- emit the background columns.  The reference indexes the *filtered* vector
+    // test[test > 0] and uses those indices on the unfiltered columns (lib :908-917): the
+    // column of a selected element is its rank among the elements with test > 0.
+    unsigned long long ce = 0;  // [eq | below] x 20 bits
+#pragma unroll
+    for (int e = 0; e < SEL_EPT; ++e)
+      if (sp[e] >= 0 && tv[e] > 0.0 && tv[e] <= thr) {
+        const unsigned long long key = (unsigned long long)__double_as_longlong(tv[e]);
+        ce += ((unsigned long long)(key == tau) << 20) + (unsigned long long)(key < tau);
+      }
+    unsigned long long tot2;
+    const unsigned long long pre2 = block_scan_u64(ce, wsum, tot2);
+    // emitted before this thread: all smaller keys before it + the first equal ones (index order)
+    int eq_before = (int)(pre2 >> 20);
+    int emit_before = (int)(pre2 & 0xfffff) + min(eq_before, need_equal);
+    int rp = (int)(pre & 0xfffff);  // rank among the positive elements
+#pragma unroll
+    for (int e = 0; e < SEL_EPT; ++e) {
+      if (sp[e] < 0 || !(tv[e] > 0.0)) continue;
+      if (tv[e] <= thr) {
+        const unsigned long long key = (unsigned long long)__double_as_longlong(tv[e]);
+        const bool eq = key == tau;
+        const bool emit = key < tau || (eq && eq_before < need_equal);
+        if (emit) {
+          bg[o0 + emit_before] = scache[rp];
+          bg_pos[o0 + emit_before] = (int)(o0 + rp);
+          ++emit_before;
+        }
+        eq_before += eq;
+      }
+      ++rp;
+    }
+  }
+  if (tid == 0) {
+    nb_out[a] = nb;
+    if (n == 1) {  // if x_red.shape[1] == 1: break                              (lib :927-928)
+      active[a] = 0;
+      n_out[a] = 0;
+    } else {
+      n_out[a] = n;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------
 // cbar_k[q] = mean_{i in bg_k} C[q][bg_pos_i], q < T_k           grid (nw), block 1024
 // ------------------------------------------------------------------------------------
@@ -1292,9 +1492,15 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
   for (;;) {
     {
       ProfScope ps(ctx, K_PCA_SELECT, 2);
-      hipLaunchKernelGGL(pca_select_kernel, dim3(na), dim3(1024), sel_lds, st, d_spx, d_spx_off,
-                         d_test, d_thr, noise_pop, itermax, d_active, d_nbiter, d_nstop, d_mapO2,
-                         d_nuis, d_bg, d_nuis_pos, d_bg_pos, d_n, d_nb, sel_cap);
+      if (nsmax_all <= 1024 * SEL_EPT)
+        hipLaunchKernelGGL(pca_select_fast_kernel, dim3(na), dim3(1024),
+                           (size_t)nsmax_all * sizeof(int), st, d_spx, d_spx_off, d_test, d_thr,
+                           noise_pop, itermax, d_active, d_nbiter, d_nstop, d_mapO2, d_nuis, d_bg,
+                           d_nuis_pos, d_bg_pos, d_n, d_nb);
+      else
+        hipLaunchKernelGGL(pca_select_kernel, dim3(na), dim3(1024), sel_lds, st, d_spx, d_spx_off,
+                           d_test, d_thr, noise_pop, itermax, d_active, d_nbiter, d_nstop, d_mapO2,
+                           d_nuis, d_bg, d_nuis_pos, d_bg_pos, d_n, d_nb, sel_cap);
     }
     ORIGIN_LAUNCH_CHECK();
     ORIGIN_HIP(hipMemcpyAsync(h_nnb, d_n, (size_t)2 * na * sizeof(int), hipMemcpyDeviceToHost, st));
