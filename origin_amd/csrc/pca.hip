@@ -33,6 +33,7 @@
 // A block never straddles two areas, so per-area vectors (b, u) are wave-uniform.
 #include <algorithm>
 #include <cstdlib>
+#include <chrono>
 #include <vector>
 
 #include "common.h"
@@ -99,7 +100,7 @@ struct BlockScan {
   }
 };
 
-__global__ __launch_bounds__(1024) void pca_select_kernel(
+__device__ __forceinline__ void pca_select_body(
     const int *__restrict__ spx, const long *__restrict__ spx_off, const double *__restrict__ test,
     const double *__restrict__ thr_, double noise_pop, int itermax, int *__restrict__ active,
     int *__restrict__ nbiter, int *__restrict__ nstop, int *__restrict__ mapO2,
@@ -308,7 +309,7 @@ __device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long 
   return pre + incl - v;
 }
 
-__global__ __launch_bounds__(1024) void pca_select_fast_kernel(
+__device__ __forceinline__ void pca_select_fast_body(
     const int *__restrict__ spx, const long *__restrict__ spx_off, const double *__restrict__ test,
     const double *__restrict__ thr_, double noise_pop, int itermax, int *__restrict__ active,
     int *__restrict__ nbiter, int *__restrict__ nstop, int *__restrict__ mapO2,
@@ -474,6 +475,47 @@ __global__ __launch_bounds__(1024) void pca_select_fast_kernel(
       n_out[a] = n;
     }
   }
+}
+
+// The host sizes every launch of an iteration from n / nb of each area.  Instead of a D2H copy
+// and a stream synchronisation (~30 us of wake-up latency per iteration), each block stores its
+// two numbers straight into mapped, coherent host memory; the last block to finish (device
+// counter) raises the generation flag the host spins on.
+__device__ __forceinline__ void select_publish(int a, int na, const int *n_out, const int *nb_out,
+                                               int *host_out, unsigned *counter, int gen) {
+  if (threadIdx.x != 0 || !host_out) return;
+  host_out[a] = n_out[a];
+  host_out[na + a] = nb_out[a];
+  __threadfence_system();
+  const unsigned old = atomicAdd(counter, 1u);
+  if (old + 1u == (unsigned)na * (unsigned)gen) {
+    __threadfence_system();
+    __hip_atomic_store(host_out + 2 * na, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+__global__ __launch_bounds__(1024) void pca_select_kernel(
+    const int *__restrict__ spx, const long *__restrict__ spx_off, const double *__restrict__ test,
+    const double *__restrict__ thr_, double noise_pop, int itermax, int *__restrict__ active,
+    int *__restrict__ nbiter, int *__restrict__ nstop, int *__restrict__ mapO2,
+    int *__restrict__ nuis, int *__restrict__ bg, int *__restrict__ nuis_pos,
+    int *__restrict__ bg_pos, int *__restrict__ n_out, int *__restrict__ nb_out, int lds_cap,
+    int *host_out, unsigned *counter, int gen) {
+  pca_select_body(spx, spx_off, test, thr_, noise_pop, itermax, active, nbiter, nstop, mapO2, nuis,
+                  bg, nuis_pos, bg_pos, n_out, nb_out, lds_cap);
+  select_publish(blockIdx.x, gridDim.x, n_out, nb_out, host_out, counter, gen);
+}
+
+__global__ __launch_bounds__(1024) void pca_select_fast_kernel(
+    const int *__restrict__ spx, const long *__restrict__ spx_off, const double *__restrict__ test,
+    const double *__restrict__ thr_, double noise_pop, int itermax, int *__restrict__ active,
+    int *__restrict__ nbiter, int *__restrict__ nstop, int *__restrict__ mapO2,
+    int *__restrict__ nuis, int *__restrict__ bg, int *__restrict__ nuis_pos,
+    int *__restrict__ bg_pos, int *__restrict__ n_out, int *__restrict__ nb_out, int *host_out,
+    unsigned *counter, int gen) {
+  pca_select_fast_body(spx, spx_off, test, thr_, noise_pop, itermax, active, nbiter, nstop, mapO2,
+                       nuis, bg, nuis_pos, bg_pos, n_out, nb_out);
+  select_publish(blockIdx.x, gridDim.x, n_out, nb_out, host_out, counter, gen);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1391,6 +1433,7 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
   int *d_nb = (int *)sp;
   sp += (size_t)na * sizeof(int);
   int *d_nstop = (int *)sp;
+  unsigned *d_selcnt = (unsigned *)(d_nstop + 1);  // blocks of all selections that have finished
   std::vector<int> ones(na, 1);
   ORIGIN_HIP(hipMemcpyAsync(d_thr, h_thr, (size_t)na * sizeof(double), hipMemcpyHostToDevice, st));
   ORIGIN_HIP(hipMemcpyAsync(d_spx_off, h_spx_off, (size_t)(na + 1) * sizeof(long),
@@ -1398,7 +1441,7 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
   ORIGIN_HIP(hipMemcpyAsync(d_active, ones.data(), (size_t)na * sizeof(int), hipMemcpyHostToDevice,
                             st));
   ORIGIN_HIP(hipMemsetAsync(d_nbiter, 0, (size_t)na * sizeof(int), st));
-  ORIGIN_HIP(hipMemsetAsync(d_nstop, 0, sizeof(int), st));
+  ORIGIN_HIP(hipMemsetAsync(d_nstop, 0, 2 * sizeof(int), st));
   ORIGIN_HIP(hipStreamSynchronize(st));  // `ones` goes out of use
   if ((rc = b_lists.reserve(ctx, (size_t)4 * ntot * sizeof(int)))) return rc;
   int *d_nuis = (int *)b_lists.p, *d_bg = d_nuis + ntot;
@@ -1413,8 +1456,14 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
   double *d_U = (double *)b_U.p, *d_C = (double *)b_C.p;
   std::vector<int> T(na, 0);  // vectors held per area since the last flush
 
-  int *h_nnb = nullptr;  // pinned read-back buffer [2*na]
-  ORIGIN_HIP(hipHostMalloc((void **)&h_nnb, (size_t)2 * na * sizeof(int), hipHostMallocDefault));
+  // read-back buffer [2*na] + [1] generation flag: mapped, coherent host memory the selection
+  // kernel writes into directly
+  int *h_nnb = nullptr;
+  ORIGIN_HIP(hipHostMalloc((void **)&h_nnb, (size_t)(2 * na + 1) * sizeof(int),
+                           hipHostMallocMapped | hipHostMallocCoherent));
+  memset(h_nnb, 0, (size_t)(2 * na + 1) * sizeof(int));
+  int *d_hostout = nullptr;
+  ORIGIN_HIP(hipHostGetDevicePointer((void **)&d_hostout, h_nnb, 0));
   struct Pinned {
     int *p;
     ~Pinned() { (void)hipHostFree(p); }
@@ -1489,6 +1538,7 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
 
   std::vector<long> D;
   int iters = 0;
+  int gen = 1;  // selections launched so far + 1
   for (;;) {
     {
       ProfScope ps(ctx, K_PCA_SELECT, 2);
@@ -1496,15 +1546,34 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
         hipLaunchKernelGGL(pca_select_fast_kernel, dim3(na), dim3(1024),
                            (size_t)nsmax_all * sizeof(int), st, d_spx, d_spx_off, d_test, d_thr,
                            noise_pop, itermax, d_active, d_nbiter, d_nstop, d_mapO2, d_nuis, d_bg,
-                           d_nuis_pos, d_bg_pos, d_n, d_nb);
+                           d_nuis_pos, d_bg_pos, d_n, d_nb, d_hostout, d_selcnt, gen);
       else
         hipLaunchKernelGGL(pca_select_kernel, dim3(na), dim3(1024), sel_lds, st, d_spx, d_spx_off,
                            d_test, d_thr, noise_pop, itermax, d_active, d_nbiter, d_nstop, d_mapO2,
-                           d_nuis, d_bg, d_nuis_pos, d_bg_pos, d_n, d_nb, sel_cap);
+                           d_nuis, d_bg, d_nuis_pos, d_bg_pos, d_n, d_nb, sel_cap, d_hostout,
+                           d_selcnt, gen);
     }
     ORIGIN_LAUNCH_CHECK();
-    ORIGIN_HIP(hipMemcpyAsync(h_nnb, d_n, (size_t)2 * na * sizeof(int), hipMemcpyDeviceToHost, st));
-    ORIGIN_HIP(hipStreamSynchronize(st));
+    {
+      // n / nb arrive in mapped host memory; wait for the generation flag of this selection
+      // (everything enqueued before it on the stream is complete by then).  Fall back to a
+      // stream synchronisation after 5 s (a faulted kernel never raises the flag).
+      int *flag = h_nnb + 2 * na;
+      const auto t_start = std::chrono::steady_clock::now();
+      long polls = 0;
+      while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != gen) {
+        __builtin_ia32_pause();
+        if ((++polls & 0xfffff) == 0 &&
+            std::chrono::steady_clock::now() - t_start > std::chrono::seconds(5)) {
+          ORIGIN_HIP(hipStreamSynchronize(st));
+          if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != gen) {
+            origin_set_error("greedy PCA: the selection kernel did not report back");
+            return ORIGIN_E_HIP;
+          }
+        }
+      }
+      ++gen;
+    }
     // ---- work list of this iteration
     int nw = 0;
     bool full = false;
