@@ -1518,23 +1518,14 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
     sel_lds = 0;
   }
 
-  // pinned staging for the per-iteration descriptors (async upload, no extra sync)
-  long *h_desc = nullptr;
-  const size_t desc_cap = (size_t)DF_COUNT * na * sizeof(long);
-  ORIGIN_HIP(hipHostMalloc((void **)&h_desc, desc_cap, hipHostMallocDefault));
-  struct PinnedL {
-    long *p;
-    ~PinnedL() { (void)hipHostFree(p); }
-  } pinned_desc{h_desc};
-
-  int *h_tiles = nullptr;  // pinned staging of the Gram tile lists (grown on demand)
-  size_t tiles_cap = 0;
-  struct PinnedI {
-    int *p;
-    ~PinnedI() {
+  char *h_stage = nullptr;  // pinned staging of descriptors + Gram tile lists (grown on demand)
+  size_t stage_cap = 0;
+  struct PinnedC {
+    char *p;
+    ~PinnedC() {
       if (p) (void)hipHostFree(p);
     }
-  } pinned_tiles{nullptr};
+  } pinned_stage{nullptr};
 
   std::vector<long> D;
   int iters = 0;
@@ -1624,27 +1615,27 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
       h_trace[2 * iters + 1] = nsum;
     }
     const int ntiles = (int)ti.size();
-    if ((rc = b_desc.reserve(ctx, D.size() * sizeof(long)))) return rc;
-    if ((rc = b_tiles.reserve(ctx, (size_t)3 * ntiles * sizeof(int)))) return rc;
+    // descriptors and tile lists go up in ONE asynchronous copy from pinned staging (free
+    // again: the selection that has just reported back is behind every earlier upload)
+    const size_t dbytes = D.size() * sizeof(long), tbytes = (size_t)3 * ntiles * sizeof(int);
+    if ((rc = b_desc.reserve(ctx, dbytes + tbytes))) return rc;
     long *dD = (long *)b_desc.p;
-    int *d_ti = (int *)b_tiles.p, *d_tj = d_ti + ntiles, *d_ta = d_tj + ntiles;
-    // descriptors and tile lists go up from pinned staging, asynchronously: the staging is
-    // free again because the last synchronisation (after the selection) is behind every
-    // earlier upload, and nothing below waits for the host
-    memcpy(h_desc, D.data(), D.size() * sizeof(long));
-    ORIGIN_HIP(hipMemcpyAsync(dD, h_desc, D.size() * sizeof(long), hipMemcpyHostToDevice, st));
-    if ((size_t)3 * ntiles > tiles_cap) {
-      if (h_tiles) (void)hipHostFree(h_tiles);
-      h_tiles = nullptr;
-      tiles_cap = (size_t)3 * ntiles * 2;
-      ORIGIN_HIP(hipHostMalloc((void **)&h_tiles, tiles_cap * sizeof(int), hipHostMallocDefault));
-      pinned_tiles.p = h_tiles;
+    int *d_ti = (int *)((char *)b_desc.p + dbytes), *d_tj = d_ti + ntiles, *d_ta = d_tj + ntiles;
+    if (dbytes + tbytes > stage_cap) {
+      if (h_stage) (void)hipHostFree(h_stage);
+      h_stage = nullptr;
+      stage_cap = (dbytes + tbytes) * 2;
+      ORIGIN_HIP(hipHostMalloc((void **)&h_stage, stage_cap, hipHostMallocDefault));
+      pinned_stage.p = h_stage;
     }
-    memcpy(h_tiles, ti.data(), (size_t)ntiles * sizeof(int));
-    memcpy(h_tiles + ntiles, tj.data(), (size_t)ntiles * sizeof(int));
-    memcpy(h_tiles + 2 * (size_t)ntiles, ta.data(), (size_t)ntiles * sizeof(int));
-    ORIGIN_HIP(hipMemcpyAsync(d_ti, h_tiles, (size_t)3 * ntiles * sizeof(int), hipMemcpyHostToDevice,
-                              st));
+    memcpy(h_stage, D.data(), dbytes);
+    {
+      int *ht = (int *)(h_stage + dbytes);
+      memcpy(ht, ti.data(), (size_t)ntiles * sizeof(int));
+      memcpy(ht + ntiles, tj.data(), (size_t)ntiles * sizeof(int));
+      memcpy(ht + 2 * (size_t)ntiles, ta.data(), (size_t)ntiles * sizeof(int));
+    }
+    ORIGIN_HIP(hipMemcpyAsync(b_desc.p, h_stage, dbytes + tbytes, hipMemcpyHostToDevice, st));
     if ((rc = b_xp.reserve(ctx, (size_t)xp * sizeof(double)))) return rc;
     if ((rc = b_g.reserve(ctx, (size_t)g * sizeof(double)))) return rc;
     if ((rc = b_cv.reserve(ctx, (size_t)c * sizeof(double)))) return rc;
