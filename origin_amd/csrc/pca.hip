@@ -1221,14 +1221,16 @@ __global__ __launch_bounds__(256) void deflate_finish_kernel(const int *__restri
 
 // ------------------------------------------------------------------------------------
 // flush: F[z, s] = X[z, s] - sum_{q < T_a} U[z][q] C[q][i]  (X may alias F; one float32 rounding)
-// grid (ceil(nsmax/256), ceil(Nz/16), na_flush); thread = one spaxel x 16 channels
+// grid (ceil(nsmax/256), ceil(Nz/32), na_flush); thread = one spaxel x 32 channels, U rows in LDS
 // ------------------------------------------------------------------------------------
+constexpr int FLUSH_ZB = 32;  // channels per block
 __global__ __launch_bounds__(256) void flush_kernel(const float *X, float *F, int Nz, long S,
                                                     const int *__restrict__ spx,
                                                     const long *__restrict__ FD, int nf,
                                                     const double *__restrict__ U,
                                                     const double *__restrict__ C, long ntot) {
   // FD: [4][nf] = area, list0, ns, T
+  __shared__ double Us[FLUSH_ZB][PCA_CAP];  // this block's rows of U (zero beyond T / Nz)
   const int k = blockIdx.z;
   const int ns = (int)FD[(long)2 * nf + k], T = (int)FD[(long)3 * nf + k];
   const int li = blockIdx.x * 256 + threadIdx.x;
@@ -1237,26 +1239,33 @@ __global__ __launch_bounds__(256) void flush_kernel(const float *X, float *F, in
   const long pos = FD[(long)1 * nf + k] + (live ? li : ns - 1);
   const long col = spx[pos];
   const double *Ua = U + FD[k] * (long)Nz * PCA_CAP;
-  const int z0 = blockIdx.y * 16;
-  double acc[16];
+  const int z0 = blockIdx.y * FLUSH_ZB;
+  for (int i = threadIdx.x; i < FLUSH_ZB * PCA_CAP; i += 256) {
+    const int r = i / PCA_CAP, q = i - r * PCA_CAP;
+    Us[r][q] = (z0 + r < Nz && q < T) ? Ua[(long)(z0 + r) * PCA_CAP + q] : 0.0;
+  }
+  // the X values of this thread's column: requested before the coefficient loop
+  float xv[FLUSH_ZB];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.0;
-  for (int q = 0; q < T; ++q) {
-    const double c = C[(long)q * ntot + pos];
+  for (int r = 0; r < FLUSH_ZB; ++r) xv[r] = X[(long)min(z0 + r, Nz - 1) * S + col];
+  __syncthreads();
+  double acc[FLUSH_ZB];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int z = min(z0 + r, Nz - 1);
-      acc[r] = fma(Ua[(long)z * PCA_CAP + q], c, acc[r]);  // wave-uniform -> scalar loads
-    }
+  for (int r = 0; r < FLUSH_ZB; ++r) acc[r] = 0.0;
+  for (int q0 = 0; q0 < T; q0 += 8) {
+    double c[8];  // independent loads; entries beyond T multiply zero rows of Us
+#pragma unroll
+    for (int e = 0; e < 8; ++e) c[e] = q0 + e < T ? C[(long)(q0 + e) * ntot + pos] : 0.0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+      for (int r = 0; r < FLUSH_ZB; ++r) acc[r] = fma(Us[r][q0 + e], c[e], acc[r]);
   }
   if (live) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < FLUSH_ZB; ++r) {
       const int z = z0 + r;
-      if (z < Nz) {
-        const long idx = (long)z * S + col;
-        F[idx] = (float)((double)X[idx] - acc[r]);
-      }
+      if (z < Nz) F[(long)z * S + col] = (float)((double)xv[r] - acc[r]);
     }
   }
 }
@@ -1496,7 +1505,7 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
                                 st));
       ORIGIN_HIP(hipStreamSynchronize(st));
       ProfScope ps(ctx, K_PCA_FLUSH, 2);
-      hipLaunchKernelGGL(flush_kernel, dim3(cdiv(nsmax, 256), cdiv(Nz, 16), nf), dim3(256), 0, st,
+      hipLaunchKernelGGL(flush_kernel, dim3(cdiv(nsmax, 256), cdiv(Nz, FLUSH_ZB), nf), dim3(256), 0, st,
                          src, d_F, Nz, S, d_spx, (const long *)b_fd.p, nf, d_U, d_C, ntot);
       ORIGIN_LAUNCH_CHECK();
     }
