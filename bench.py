@@ -266,8 +266,36 @@ def main():
                 ex = mfma_per_vox * 32768.0 * vox / avg_s / 1e12
                 extra = dict(executed=round(ex, 1), executed_frac=round(ex / peak, 4),
                              fp32_frac=round(ach / FP32_PEAK_TFLOPS, 4), arithmetic="f16x2 MFMA")
+        # HBM traffic of the dominant kernel: bench.py cannot read PMC counters itself, so it
+        # takes the per-launch FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 --pmc passes
+        # of this very command (profiles/, tools/summarize_rocprof.py) when the workload is the
+        # default one; null otherwise
+        traffic = None
+        try:
+            if world == 1 and (Nz, N, args.nprof) == (3681, 600, 20):
+                pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                                  "profiles", "r01_pmc_fetch_write.json")))
+                kmap = {"glr_spectral": ["spectral_mfma_kernel", "spectral3_kernel"],
+                        "glr_spatial": ["spatial_mfma_kernel", "spatial4x4_kernel"],
+                        "dct_fit": ["dct_moments_kernel"], "dct_plane_sums": ["dct_plane_sums_kernel"],
+                        "dct_standardize": ["dct_standardize_kernel"],
+                        "pca_deflate_dot": ["deflate_dot_kernel"], "pca_flush": ["flush_kernel"]}
+                for kn in kmap.get(dominant, []):
+                    if kn in pmc:
+                        e = pmc[kn]
+                        # FETCH_SIZE counts 16-byte coalesced reads at half size (MI355X_MICROARCH.md,
+                        # HBM): the MFMA spectral kernel reads with 4-byte loads (no correction)
+                        fx = 1.0 if kn == "spectral_mfma_kernel" else 2.0
+                        traffic = round((fx * e.get("FETCH_SIZE_GB_per_launch", 0.0) +
+                                         e.get("WRITE_SIZE_GB_per_launch", 0.0)) * 1e9)
+                        extra["traffic_source"] = ("profiles/r01_pmc_fetch_write.json: rocprofv3 --pmc "
+                                                   "FETCH_SIZE / WRITE_SIZE passes of this command, "
+                                                   f"kernel {kn}, bytes per launch")
+                        break
+        except (OSError, ValueError):
+            traffic = None
         roofline = dict(bound=bound, kernel=dominant, achieved=round(ach, 3), peak=peak,
-                        unit=unit, frac=round(ach / peak, 4), traffic=None,
+                        unit=unit, frac=round(ach / peak, 4), traffic=traffic,
                         avg_launch_ms=round(tot_ms / launches, 4), launches=launches, **extra)
 
     # ---- CPU baseline: the oracle on a centred crop, all host cores, rank 0, N == 1 ----
