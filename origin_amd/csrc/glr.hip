@@ -757,22 +757,22 @@ __device__ __forceinline__ float mf_min(float a, float b) {
 // accumulator chain is enough: tools/mfma_rate.hip measures the same 32-cycle issue for 1, 2
 // and 4 chains.
 template <bool WIDE>
-__device__ __forceinline__ void mf_profile(const char *__restrict__ ak, f32x16 &acc) {
+__device__ __forceinline__ void mf_profile(const char *__restrict__ ak,
+                                           const char *__restrict__ a_next, f16x8 &ah, f16x8 &al,
+                                           f32x16 &acc) {
+  // (ah, al) arrive holding the fragments of this profile's first block and leave holding those
+  // of the next profile's first block (a_next): no LDS latency is exposed between profiles
   constexpr int KS0 = WIDE ? 0 : 1, NKS = WIDE ? 6 : 4;
   constexpr int LO = 8 * MF_COPY_BYTES;
-  f16x8 ah = *reinterpret_cast<const f16x8 *>(ak + KS0 * 32);
-  f16x8 al = *reinterpret_cast<const f16x8 *>(ak + KS0 * 32 + LO);
   mf_for<0, NKS>([&](auto ic) {
     constexpr int g = decltype(ic)::value, ks = KS0 + g;
-    f16x8 nh, nl;
-    if constexpr (g + 1 < NKS) {
-      nh = *reinterpret_cast<const f16x8 *>(ak + (ks + 1) * 32);
-      nl = *reinterpret_cast<const f16x8 *>(ak + (ks + 1) * 32 + LO);
-    }
+    const char *src = g + 1 < NKS ? ak + (ks + 1) * 32 : a_next;
+    const f16x8 nh = *reinterpret_cast<const f16x8 *>(src);
+    const f16x8 nl = *reinterpret_cast<const f16x8 *>(src + LO);
     mf_mma<mf_breg(ks, 0), g == 0>(acc, ah);
     mf_mma<mf_breg(ks, 1), false>(acc, ah);
     mf_mma<mf_breg(ks, 0), false>(acc, al);
-    if constexpr (g + 1 < NKS) ah = nh, al = nl;
+    ah = nh, al = nl;
   });
   asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc));  // MFMA result -> VALU reader
 }
@@ -914,24 +914,36 @@ __global__ __launch_bounds__(64 * MF_WAVES, 1) void spectral_mfma_kernel(
     int bk[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) best[i] = -INFINITY, worst[i] = INFINITY, bk[i] = 0;
+    auto first_block = [&](int k) -> const char * {  // A fragments of profile k's first block
+      const int kk = k < K ? k : 0;
+      return a_lane + kk * MF_PROF_BYTES + (pwide[kk] ? 0 : 32);
+    };
+    f16x8 ah, al;
+    {
+      const char *p0 = first_block(0);
+      ah = *reinterpret_cast<const f16x8 *>(p0);
+      al = *reinterpret_cast<const f16x8 *>(p0 + 8 * MF_COPY_BYTES);
+    }
     for (int k = 0; k < K; ++k) {
       f32x16 acc;
       f32x4v f[4];
+      // 1/sqrt(den) of this profile: requested before its MFMAs, used after them
       if (bwave) {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
           f[g] = *reinterpret_cast<const f32x4v *>(rdb + (long)k * NzP + z0 + 8 * g);
-      }
-      const char *ak = a_lane + k * MF_PROF_BYTES;
-      if (pwide[k]) mf_profile<true>(ak, acc);
-      else mf_profile<false>(ak, acc);
-      if (bwave) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) f[g] *= inv;
       } else {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
           f[g] = *reinterpret_cast<const f32x4v *>(rd_lane + k * MF_RD_BYTES + 32 * g);
+      }
+      const char *ak = a_lane + k * MF_PROF_BYTES;
+      const char *an = first_block(k + 1);
+      if (pwide[k]) mf_profile<true>(ak, an, ah, al, acc);
+      else mf_profile<false>(ak, an, ah, al, acc);
+      if (bwave) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) f[g] *= inv;
       }
       mf_epilogue(acc, f, k, best, bk, worst);
     }
