@@ -850,10 +850,14 @@ struct SmallWork {
 };
 
 __device__ void lanczos_small_wave(const double *__restrict__ Gk, int n, int ld, int lane,
-                                   SmallWork &sw, double *__restrict__ v, double *info3) {
+                                   SmallWork &sw, double *__restrict__ v, double *info3,
+                                   const double *__restrict__ slab = nullptr, long slab_stride = 0,
+                                   int ksplit = 0) {
   const bool own = lane < n;
-  for (int c = 0; c < n; ++c)
-    if (own) sw.G[c][lane] = Gk[(long)c * ld + lane];
+  if (!slab) {  // (with slabs the caller has filled sw.G: see lanczos_kernel)
+    for (int c = 0; c < n; ++c)
+      if (own) sw.G[c][lane] = Gk[(long)c * ld + lane];
+  }
   // start vector G * ones
   double y = 0.0;
   for (int c = 0; c < n; ++c) y += own ? sw.G[c][lane] : 0.0;
@@ -910,7 +914,9 @@ __global__ __launch_bounds__(1024) void lanczos_kernel(const double *__restrict_
                                                        double *__restrict__ vout,
                                                        const long *__restrict__ v_off,
                                                        int max_restart, double tol,
-                                                       double *__restrict__ info) {
+                                                       double *__restrict__ info,
+                                                       const double *__restrict__ slab,
+                                                       long slab_stride, int ksplit) {
   __shared__ double alpha[LANCZOS_M], beta[LANCZOS_M], h[LANCZOS_M + 1];
   __shared__ TriWork ws;
   __shared__ double red[16];
@@ -929,7 +935,31 @@ __global__ __launch_bounds__(1024) void lanczos_kernel(const double *__restrict_
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (n <= LANCZOS_M) {  // whole-space Lanczos inside one wave, no barriers
     SmallWork &sw = *reinterpret_cast<SmallWork *>(lz_dyn);
-    if (wave == 0) lanczos_small_wave(Gk, n, ld, lane, sw, v, info ? info + 3 * k : nullptr);
+    if (slab) {
+      // G straight from the K-split slabs of gram_kernel (the reduction kernel is skipped when
+      // every matrix of the launch is small): same sums, in the same order, as
+      // gram_reduce_kernel.  Only tiles (ti <= tj) exist: the lower-left one is read mirrored.
+      // All 16 waves share the rows; the <= 32 slab values of an element are independent loads
+      // (one L2 round trip), summed in slab order.
+      const double *sk = slab + g_off[k];
+      for (int c = wave; c < n; c += 16) {
+        if (lane < n) {
+          const bool up = (c >> 5) <= (lane >> 5);
+          const long off = up ? (long)c * ld + lane : (long)lane * ld + c;
+          double part[32];
+#pragma unroll
+          for (int ks = 0; ks < 32; ++ks) part[ks] = ks < ksplit ? sk[(long)ks * slab_stride + off] : 0.0;
+          double acc = 0.0;
+#pragma unroll
+          for (int ks = 0; ks < 32; ++ks) acc += part[ks];  // trailing zeros do not change the sum
+          sw.G[c][lane] = acc;
+        }
+      }
+      __syncthreads();
+    }
+    if (wave == 0)
+      lanczos_small_wave(Gk, n, ld, lane, sw, v, info ? info + 3 * k : nullptr,
+                         slab ? slab + g_off[k] : nullptr, slab_stride, ksplit);
     return;
   }
   const int mfull = min(LANCZOS_M, n);
@@ -1304,7 +1334,8 @@ struct PcaWorkspace {
 // launches lanczos_kernel with the basis in LDS when the largest matrix allows it
 int eig_launch(origin_ctx *ctx, int nmat, long ldmax, const double *d_G, const long *d_g_off,
                const long *d_ld, const long *d_n, double *d_q, const long *d_q_off, double *d_v,
-               const long *d_v_off, double *d_info) {
+               const long *d_v_off, double *d_info, const double *d_slab = nullptr,
+               long slab_stride = 0, int ksplit = 0) {
   static bool attr_done = false;
   if (!attr_done) {
     ORIGIN_HIP(hipFuncSetAttribute((const void *)lanczos_kernel<true>,
@@ -1316,10 +1347,12 @@ int eig_launch(origin_ctx *ctx, int nmat, long ldmax, const double *d_G, const l
     const size_t lds = std::max(sizeof(SmallWork),
                                 (size_t)(LANCZOS_M + 2) * (size_t)ldmax * sizeof(double));
     hipLaunchKernelGGL(lanczos_kernel<true>, dim3(nmat), dim3(1024), lds, ctx->stream, d_G, d_g_off,
-                       d_ld, d_n, d_q, d_q_off, d_v, d_v_off, 60, 1e-14, d_info);
+                       d_ld, d_n, d_q, d_q_off, d_v, d_v_off, 60, 1e-14, d_info, d_slab, slab_stride,
+                       ksplit);
   } else {
     hipLaunchKernelGGL(lanczos_kernel<false>, dim3(nmat), dim3(1024), sizeof(SmallWork), ctx->stream,
-                       d_G, d_g_off, d_ld, d_n, d_q, d_q_off, d_v, d_v_off, 60, 1e-14, d_info);
+                       d_G, d_g_off, d_ld, d_n, d_q, d_q_off, d_v, d_v_off, 60, 1e-14, d_info, d_slab,
+                       slab_stride, ksplit);
   }
   ORIGIN_LAUNCH_CHECK();
   return ORIGIN_OK;
@@ -1327,7 +1360,8 @@ int eig_launch(origin_ctx *ctx, int nmat, long ldmax, const double *d_G, const l
 
 int gram_launch(origin_ctx *ctx, const double *d_Xp, const long *d_xp_off, const long *d_ld, int Nz,
                 int ntiles, const int *d_ti, const int *d_tj, const int *d_ta, long g_total,
-                double *d_G, const long *d_g_off) {
+                double *d_G, const long *d_g_off, bool skip_reduce = false,
+                const double **slab_out = nullptr, int *ksplit_out = nullptr) {
   // K-split so that small problems still put >= ~8 waves on every CU
   int ksplit = (int)(((long)ctx->num_cu * 8 + ntiles - 1) / ntiles);
   if (ksplit < 1) ksplit = 1;
@@ -1339,8 +1373,12 @@ int gram_launch(origin_ctx *ctx, const double *d_Xp, const long *d_xp_off, const
   ProfScope ps(ctx, K_PCA_GRAM, 2);
   hipLaunchKernelGGL(gram_kernel, dim3(ntiles, ksplit), dim3(64), 0, ctx->stream, d_Xp, d_xp_off,
                      d_ld, d_ti, d_tj, d_ta, Nz, ksplit, (double *)scr, d_g_off, g_total);
-  hipLaunchKernelGGL(gram_reduce_kernel, dim3(ntiles), dim3(256), 0, ctx->stream,
-                     (const double *)scr, g_total, ksplit, d_ld, d_ti, d_tj, d_ta, d_G, d_g_off);
+  if (slab_out) *slab_out = (const double *)scr;
+  if (ksplit_out) *ksplit_out = ksplit;
+  // the one-wave eigen-solver sums the slabs itself when every matrix of the launch is small
+  if (!skip_reduce)
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3(ntiles), dim3(256), 0, ctx->stream,
+                       (const double *)scr, g_total, ksplit, d_ld, d_ti, d_tj, d_ta, d_G, d_g_off);
   ORIGIN_LAUNCH_CHECK();
   return ORIGIN_OK;
 }
@@ -1688,7 +1726,12 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
                          nw, d_Xp, d_cpart, c, nzb);
     }
     ORIGIN_LAUNCH_CHECK();
-    if ((rc = gram_launch(ctx, d_Xp, dXP, dLD, Nz, ntiles, d_ti, d_tj, d_ta, g, d_G, dG))) return rc;
+    const bool all_small = ldmax <= LANCZOS_M;  // (ld is n rounded up to 16: n <= 48)
+    const double *d_slab = nullptr;
+    int gram_ksplit = 0;
+    if ((rc = gram_launch(ctx, d_Xp, dXP, dLD, Nz, ntiles, d_ti, d_tj, d_ta, g, d_G, dG, all_small,
+                          &d_slab, &gram_ksplit)))
+      return rc;
     {
       void *scr = nullptr;
       if ((rc = b_part.reserve(ctx, (size_t)q * sizeof(double)))) return rc;
@@ -1700,7 +1743,8 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
       }
       {
         ProfScope ps(ctx, K_PCA_EIG, 2);
-        if ((rc = eig_launch(ctx, nw, ldmax, d_G, dG, dLD, dN, (double *)scr, dQ, d_v, dC, d_info)))
+        if ((rc = eig_launch(ctx, nw, ldmax, d_G, dG, dLD, dN, (double *)scr, dQ, d_v, dC, d_info,
+                             all_small ? d_slab : nullptr, g, gram_ksplit)))
           return rc;
       }
       if (debug) {
