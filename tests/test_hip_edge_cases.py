@@ -178,3 +178,17 @@ def test_bad_arguments_raise(ctx, hip):
     with pytest.raises(ValueError):
         hip.Compute_GreedyPCA_area(1, np.zeros((5, 2, 2)), np.ones((2, 2), int), 50, [1.0], 10,
                                    [np.zeros(3)])  # testO2 length != area size
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1), (2, 3, 5), (7, 1, 70), (5, 17, 1), (40, 19, 130)])
+@pytest.mark.parametrize("size", [3, 5])
+def test_local_max_small_and_ragged_shapes(hip, shape, size):
+    """3x3x3 z-marching kernel (size 3) and the generic kernel on shapes smaller than a tile,
+    single planes / rows / columns; plateaus (equal neighbours) and masked voxels included."""
+    rng = np.random.default_rng(sum(shape) + size)
+    correl = np.round(rng.standard_normal(shape) * 2).astype(np.float32).astype(float)  # ties
+    cmin = -np.abs(np.round(rng.standard_normal(shape) * 2)).astype(np.float32).astype(float)
+    mask = rng.random(shape) < 0.1
+    got = hip.compute_local_max(correl, cmin, mask, size)
+    ref = cpu_ref.compute_local_max(correl, cmin, mask, size)
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
