@@ -65,6 +65,18 @@ int origin_copy_box(origin_ctx *ctx, int kind, void *dst, long dst_pitch_y, long
                     const void *src, long src_pitch_y, long src_pitch_z, int nz, int ny,
                     int nx, int elem);
 
+/* ---- purity threshold reductions -----------------------------------
+ * Device side of Compute_threshold_purity (lib_origin.py:1391-1479, called by
+ * ComputePurityThreshold.run, steps.py:874-890): the default threshold list needs the
+ * per-spaxel maxima of the local-maximum cubes (:1437-1442), the purity curve the number of
+ * voxels above each threshold (:1444-1452).  d_keep: uint8 [Ny*Nx] or NULL, 0 = spaxel
+ * excluded (cube_local_min * (segmap == 0), :1430). */
+int origin_zmax_map(origin_ctx *ctx, const float *d_cube, const uint8_t *d_keep, int Nz, long S,
+                    float *d_map /* [S] */);
+/* h_counts[t] = #{ voxels : (double) value > h_thr[t] }, thresholds in any order, nthr <= 1024 */
+int origin_count_above(origin_ctx *ctx, const float *d_cube, const uint8_t *d_keep, int Nz, long S,
+                       int nthr, const double *h_thr, long *h_counts);
+
 /* ---- inter-GPU exchange (one process per GPU; RCCL over xGMI on the context's stream) ----
  * The reference has no multi-GPU path (its only parallelism is the joblib pool of
  * lib_origin.py:1150-1160); these serve the spatial tiling of origin_amd/multigpu.py.

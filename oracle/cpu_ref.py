@@ -501,6 +501,46 @@ def compute_local_max(correl, correl_min, mask, size=3):
 
 
 # --------------------------------------------------------------------------
+# Purity threshold  (lib_origin.py:1391-1479)
+# --------------------------------------------------------------------------
+def Compute_threshold_purity(purity, cube_local_max, cube_local_min, segmap=None, threshlist=None):
+    """lib_origin.py:1391-1479 without the astropy Table: returns (threshold, columns) where
+    columns = dict(Tval_r, Pval_r, Det_m, Det_M) sorted by Tval_r like ``res.sort('Tval_r')``."""
+    L1 = np.prod(cube_local_min.shape[1:])                                    # :1425
+    if segmap is not None:                                                    # :1428-1435
+        segmask = segmap == 0
+        cube_local_min = cube_local_min * segmask
+        L0 = np.count_nonzero(segmask)
+    else:
+        L0 = L1
+    if threshlist is None:                                                    # :1437-1442
+        threshmax = min(cube_local_min.max(), cube_local_max.max())
+        threshmin = np.median(np.amax(cube_local_max, axis=0)) * 1.1
+        threshlist = np.linspace(threshmin, threshmax, 50)
+    else:
+        threshmin = np.min(threshlist)
+    locM = cube_local_max[cube_local_max > threshmin]                         # :1444-1445
+    locm = cube_local_min[cube_local_min > threshmin]
+    n0, n1 = [], []
+    for thresh in threshlist:                                                 # :1447-1450
+        n1.append(np.count_nonzero(locM > thresh))
+        n0.append(np.count_nonzero(locm > thresh))
+    n0 = np.array(n0) * (L1 / L0)                                             # :1452
+    n1 = np.array(n1)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        est_purity = 1 - n0 / n1                                              # :1454
+    tval = np.asarray(threshlist, dtype=float)
+    order = np.argsort(tval, kind="stable")                                   # res.sort('Tval_r')
+    cols = dict(Tval_r=tval[order], Pval_r=est_purity[order],
+                Det_m=n0.astype(int)[order], Det_M=n1[order])
+    if est_purity[-1] < purity:                                               # :1464-1468
+        threshold = np.inf
+    else:
+        threshold = np.interp(purity, cols["Pval_r"], cols["Tval_r"])         # :1470
+    return float(threshold), cols
+
+
+# --------------------------------------------------------------------------
 # Whole chain in Step order (substitute for BASELINE config 0, SURVEY G7)
 # --------------------------------------------------------------------------
 def run_chain(cube_raw, var, mask, PSF, wfields, profiles, areamap, nbAreas,

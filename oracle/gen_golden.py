@@ -303,8 +303,33 @@ def check_dictionary():
     REPORT.append(line)
 
 
+def gen_g8():
+    """Compute_threshold_purity (lib_origin.py:1391-1479): default threshold list with and
+    without segmap, explicit (unsorted) list."""
+    inp = INPUTS["g8"]
+    out = {}
+    cases = dict(seg=(0.9, inp["segmap"], None), noseg=(0.8, None, None),
+                 lst=(0.7, inp["segmap"], list(inp["threshlist"])))
+    for name, (purity, segmap, tl) in cases.items():
+        with np.errstate(all="ignore"):
+            thr, res = ref.Compute_threshold_purity(purity, inp["lmax"].copy(), inp["lmin"].copy(),
+                                                    segmap, threshlist=tl)
+            thr2, cols = cpu_ref.Compute_threshold_purity(purity, inp["lmax"].copy(),
+                                                          inp["lmin"].copy(), segmap, threshlist=tl)
+        for c in ("Tval_r", "Pval_r", "Det_m", "Det_M"):
+            a, b = np.asarray(res[c], dtype=float), np.asarray(cols[c], dtype=float)
+            ok = np.array_equal(a, b, equal_nan=True)
+            report("G8", f"{name} {c}", 0.0 if ok else 1.0, 0.0)
+            out[f"{name}_{c}"] = np.asarray(res[c])
+        report("G8", f"{name} threshold", 0.0 if (thr == thr2 or abs(thr - thr2) < 1e-12) else 1.0,
+               0.0)
+        out[f"{name}_threshold"] = np.array(thr)
+        out[f"{name}_purity"] = np.array(purity)
+    save("g8_purity", sha=np.array(gc.digest(inp["lmax"], inp["lmin"], inp["segmap"])), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["dico", "g1", "g3", "g4", "g5", "g7"]
+    which = sys.argv[1:] or ["dico", "g1", "g3", "g4", "g5", "g7", "g8"]
     if "dico" in which:
         check_dictionary()
     if "g1" in which:
@@ -317,6 +342,8 @@ if __name__ == "__main__":
         gen_g5_g6()
     if "g7" in which:
         gen_g7()
+    if "g8" in which:
+        gen_g8()
     if not sys.argv[1:]:
         with open(os.path.join(HERE, "PINNING_REPORT.txt"), "w") as f:
             f.write("oracle/cpu_ref.py vs the reference's lib_origin.py (imported unmodified), "

@@ -179,6 +179,27 @@ def g7_inputs():
 # import the reference and the system python3.10 that runs the tests would make the
 # float inputs differ in the last bit.  So the inputs are always *produced* by the
 # system python (this file run as a script) and handed to gen_golden.py as an .npz.
+def g8_inputs():
+    """Purity threshold: local-maximum cubes as compute_local_max leaves them
+    (mostly zeros, positive maxima), a segmentation map, an explicit threshold list."""
+    rng = np.random.default_rng(88)
+    shape = (120, 30, 34)
+
+    def sparse_maxima(scale, frac):
+        v = np.abs(rng.standard_normal(shape)) * scale + 2.0
+        v[rng.random(shape) > frac] = 0.0
+        return v.astype(np.float32).astype(np.float64)
+
+    lmax = sparse_maxima(3.0, 0.03)
+    lmax[40:44, 10:13, 12:16] += 9.0 * (lmax[40:44, 10:13, 12:16] > 0)   # real detections
+    lmin = sparse_maxima(2.0, 0.03)
+    segmap = np.zeros(shape[1:], dtype=int)
+    segmap[8:15, 10:18] = 1
+    segmap[20:24, 3:9] = 2
+    return dict(lmax=lmax, lmin=lmin, segmap=segmap,
+                threshlist=np.array([9.5, 4.0, 6.25, 5.0, 7.75, 3.0, 12.0]))
+
+
 def _flatten(prefix, obj, out):
     if isinstance(obj, dict):
         for k, v in obj.items():
@@ -215,7 +236,8 @@ def _unflatten(flat):
 
 
 def all_inputs():
-    return dict(g1=g1_inputs(), g3=g3_inputs(), g4=g4_inputs(), g5=g5_inputs(), g7=g7_inputs())
+    return dict(g1=g1_inputs(), g3=g3_inputs(), g4=g4_inputs(), g5=g5_inputs(), g7=g7_inputs(),
+                g8=g8_inputs())
 
 
 def dump_inputs(path):

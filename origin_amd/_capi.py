@@ -35,6 +35,8 @@ SIGNATURES = {
     "origin_d2h": [vp, vp, vp, sz],
     "origin_d2d": [vp, vp, vp, sz],
     "origin_copy_box": [vp, i32, vp, i64, i64, vp, i64, i64, i32, i32, i32, i32],
+    "origin_zmax_map": [vp, vp, vp, i32, i64, vp],
+    "origin_count_above": [vp, vp, vp, i32, i64, i32, vp, vp],
     "origin_comm_unique_id": [vp],
     "origin_comm_create": [vp, vp, i32, i32, PP(vp)],
     "origin_comm_destroy": [vp],

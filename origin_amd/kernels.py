@@ -178,3 +178,22 @@ def local_max(ctx, correl, correl_min, mask, size=3, out_max=None, out_min=None)
     _capi.call("origin_local_max", ctx.handle, correl.p, correl_min.p, _p(mask), Nz, Ny, Nx,
                int(size), out_max.p, out_min.p)
     return out_max, out_min
+
+
+def zmax_map(ctx, cube, keep=None):
+    """Per-spaxel maximum over z of a float32 device cube -> host float64 (Ny, Nx);
+    ``keep`` (uint8 DeviceArray [Ny*Nx], 0 = excluded) zeroes spaxels first."""
+    Nz, Ny, Nx = cube.shape
+    m = ctx.empty((Ny, Nx), np.float32)
+    _capi.call("origin_zmax_map", ctx.handle, cube.p, _p(keep), Nz, Ny * Nx, m.p)
+    return m.to_host().astype(np.float64)
+
+
+def count_above(ctx, cube, thresholds, keep=None):
+    """counts[t] = #{voxels of cube (x keep) with value > thresholds[t]} (int64, host)."""
+    Nz, Ny, Nx = cube.shape
+    thr = np.ascontiguousarray(thresholds, dtype=np.float64)
+    out = np.zeros(thr.size, dtype=np.int64)
+    _capi.call("origin_count_above", ctx.handle, cube.p, _p(keep), Nz, Ny * Nx, thr.size,
+               thr.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    return out

@@ -29,6 +29,7 @@ __all__ = (
     'Correlation_GLR_test',
     'compute_local_max',
     'compute_thresh_gaussfit',
+    'Compute_threshold_purity',
 )
 
 
@@ -130,3 +131,66 @@ def compute_local_max(correl, correl_min, mask, size=3):
     dmask = ctx.to_device(_mask_u8(mask, correl.shape))
     lmax, lmin = kernels.local_max(ctx, dc, dm, dmask, size)
     return lmax.to_host().astype(np.float64), lmin.to_host().astype(np.float64)
+
+
+class PurityTable(dict):
+    """Columns Tval_r, Pval_r, Det_m, Det_M of the purity curve, sorted by Tval_r (what the
+    reference returns as an astropy Table, lib_origin.py:1455-1461).  ``as_table()`` builds the
+    astropy Table when astropy is installed."""
+
+    colnames = ('Tval_r', 'Pval_r', 'Det_m', 'Det_M')
+
+    def as_table(self):
+        from astropy.table import Table
+        res = Table([self[c] for c in self.colnames], names=self.colnames)
+        res['Tval_r'].format = '.2f'
+        res['Pval_r'].format = '.2f'
+        return res
+
+
+def Compute_threshold_purity(purity, cube_local_max, cube_local_min, segmap=None,
+                             threshlist=None):
+    """Threshold for a given purity (reference lib_origin.py:1391-1479).  The cubes may be host
+    arrays or float32 ``DeviceArray`` s (no PCIe traffic then); only per-spaxel maxima and the
+    counts per threshold leave the GPU.  Returns (threshold, PurityTable)."""
+    import logging
+
+    from .device import DeviceArray
+    ctx = _ctx()
+    logger = logging.getLogger(__name__)
+
+    def dev(c):
+        return c if isinstance(c, DeviceArray) else ctx.to_device(np.asarray(c), np.float32)
+
+    lmax, lmin = dev(cube_local_max), dev(cube_local_min)
+    L1 = int(np.prod(lmin.shape[1:]))                                          # :1425
+    keep = None
+    if segmap is not None:                                                     # :1428-1435
+        segmask = np.asarray(segmap) == 0
+        keep = ctx.to_device(np.ascontiguousarray(segmask, dtype=np.uint8).reshape(-1))
+        L0 = int(np.count_nonzero(segmask))
+        logger.info('using only background pixels (%.1f%%)', L0 / L1 * 100)
+    else:
+        L0 = L1
+    if threshlist is None:                                                     # :1437-1442
+        map_max = kernels.zmax_map(ctx, lmax)
+        threshmax = min(kernels.zmax_map(ctx, lmin, keep).max(), map_max.max())
+        threshmin = np.median(map_max) * 1.1
+        threshlist = np.linspace(threshmin, threshmax, 50)
+    threshlist = np.asarray(threshlist, dtype=np.float64)
+    n1 = kernels.count_above(ctx, lmax, threshlist)                            # :1444-1450
+    n0 = kernels.count_above(ctx, lmin, threshlist, keep) * (L1 / L0)          # :1452
+    with np.errstate(divide='ignore', invalid='ignore'):
+        est_purity = 1 - n0 / n1                                               # :1454
+    order = np.argsort(threshlist, kind='stable')                              # res.sort('Tval_r')
+    res = PurityTable(Tval_r=threshlist[order], Pval_r=est_purity[order],
+                      Det_m=n0.astype(int)[order], Det_M=n1[order])
+    if est_purity[-1] < purity:                                                # :1464-1468
+        logger.warning('Maximum computed purity %.2f is below %.2f', est_purity[-1], purity)
+        threshold = np.inf
+    else:
+        threshold = np.interp(purity, res['Pval_r'], res['Tval_r'])            # :1470
+        detect = np.interp(threshold, res['Tval_r'], res['Det_M'])
+        logger.info('Interpolated Threshold %.2f Detection %d for Purity %.2f', threshold,
+                    detect, purity)
+    return float(threshold), res

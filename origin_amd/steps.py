@@ -358,6 +358,55 @@ class _ComputeTGLRRun(_HipStepMixin):
         self._put_cube(orig, 'cube_local_min', out['local_min'])
 
 
+class _ComputePurityThresholdRun(_HipStepMixin):
+    """ComputePurityThreshold.run (reference steps.py:848-890): the purity curves come from
+    reductions of the local-maximum cubes that are still in HBM."""
+    name = 'compute_purity_threshold'
+    desc = 'Compute Purity threshold'
+    require = ('compute_TGLR',)
+
+    def run(self, orig, purity=0.9, purity_std=None, threshlist=None, pfasegfinal=1e-5,
+            bins='fd'):
+        from .lib_origin import Compute_threshold_purity
+        ctx = _ctx_of(orig)
+        if purity_std is None:
+            purity_std = purity
+        orig.param.update(dict(purity=purity, purity_std=purity_std))
+        # another segmap on the maxmap, merged with segmap_merged          (steps.py:862-867)
+        thresh, map_res = compute_segmap_gauss(_data(orig.maxmap), pfasegfinal, 0, bins=bins)
+        segmap, nlabels = ndi.label((map_res > 0) | (_data(orig.segmap_merged) > 0))
+        self.store_image('segmap_purity', segmap)
+
+        self._loginfo('Estimation of threshold with purity = %.2f', purity)
+        threshold, pval = Compute_threshold_purity(
+            purity, self._get_cube(orig, ctx, 'cube_local_max'),
+            self._get_cube(orig, ctx, 'cube_local_min'), segmap, threshlist=threshlist)
+        self.Pval = _table(pval)
+        orig.param['threshold'] = threshold
+        self._loginfo('Threshold: %.2f ', threshold)
+
+        self._loginfo('Estimation of threshold std with purity = %.2f', purity_std)
+        threshold_std, pval = Compute_threshold_purity(
+            purity_std, self._get_cube(orig, ctx, 'cube_std_local_max'),
+            self._get_cube(orig, ctx, 'cube_std_local_min'), threshlist=threshlist)
+        self.Pval_comp = _table(pval)
+        orig.param['threshold_std'] = threshold_std
+        self._loginfo('Threshold: %.2f ', threshold_std)
+
+
+def _data(img):
+    """ndarray of an image attribute (mpdaf Image under the reference, ndarray here)."""
+    return np.asarray(getattr(img, '_data', img))
+
+
+def _table(pval):
+    """astropy Table when astropy is there (the reference's DataObj('table')), else the dict."""
+    try:
+        return pval.as_table()
+    except ImportError:
+        return pval
+
+
 # ----------------------------------------------------------------------------- stand-alone
 class Preprocessing(_PreprocessingRun, Step):
     cube_std = DataObj('cube')
@@ -408,7 +457,15 @@ class ComputeTGLR(_ComputeTGLRRun, Step):
     minmap = DataObj('image')
 
 
-STEPS = [Preprocessing, Areas, ComputePCAThreshold, ComputeGreedyPCA, ComputeTGLR]
+class ComputePurityThreshold(_ComputePurityThresholdRun, Step):
+    __doc__ = _ComputePurityThresholdRun.__doc__
+    Pval = DataObj('table')
+    Pval_comp = DataObj('table')
+    segmap_purity = DataObj('image')
+
+
+STEPS = [Preprocessing, Areas, ComputePCAThreshold, ComputeGreedyPCA, ComputeTGLR,
+         ComputePurityThreshold]
 
 
 class SimpleOrig:
@@ -456,7 +513,8 @@ def register():
     for mixin, refname in ((_PreprocessingRun, 'Preprocessing'),
                            (_ComputePCAThresholdRun, 'ComputePCAThreshold'),
                            (_ComputeGreedyPCARun, 'ComputeGreedyPCA'),
-                           (_ComputeTGLRRun, 'ComputeTGLR')):
+                           (_ComputeTGLRRun, 'ComputeTGLR'),
+                           (_ComputePurityThresholdRun, 'ComputePurityThreshold')):
         base = getattr(ref, refname)
         new = type(base)(refname, (mixin, base), {'__doc__': base.__doc__})
         ref.STEPS[ref.STEPS.index(base)] = new

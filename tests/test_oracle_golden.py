@@ -162,3 +162,22 @@ def test_next_fast_len():
             while k % p == 0:
                 k //= p
         assert k == 1 and m >= n
+
+
+def test_g8_purity_threshold_oracle_matches_reference():
+    """oracle.cpu_ref.Compute_threshold_purity against the reference's outputs (G8: default
+    list with / without segmap, explicit unsorted list), lib_origin.py:1391-1479."""
+    g = load("g8_purity")
+    inp = gc.g8_inputs()
+    assert str(g["sha"]) == gc.digest(inp["lmax"], inp["lmin"], inp["segmap"])
+    cases = dict(seg=(inp["segmap"], None), noseg=(None, None),
+                 lst=(inp["segmap"], list(inp["threshlist"])))
+    for name, (segmap, tl) in cases.items():
+        with np.errstate(all="ignore"):
+            thr, cols = cpu_ref.Compute_threshold_purity(float(g[name + "_purity"]),
+                                                         inp["lmax"].copy(), inp["lmin"].copy(),
+                                                         segmap, threshlist=tl)
+        assert thr == float(g[name + "_threshold"])
+        for c in ("Tval_r", "Pval_r", "Det_m", "Det_M"):
+            assert np.array_equal(np.asarray(cols[c], float), np.asarray(g[f"{name}_{c}"], float),
+                                  equal_nan=True), (name, c)
