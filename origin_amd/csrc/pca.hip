@@ -71,6 +71,9 @@ enum {
   DF_AREA = 0, DF_LIST0, DF_N, DF_NB, DF_LD, DF_XP, DF_C, DF_G, DF_Q, DF_NS, DF_CBASE,
   DF_T,    // vectors already removed from this area (rows of C / columns of U in use)
   DF_CN,   // offset of the gathered coefficient block Cn[T][ld] of this area
+  DF_FBOLD,  // offset of this area's nuisance block of the previous iteration (-1: none)
+  DF_LDOLD,  // its row stride
+  DF_NOLD,   // its number of columns
   DF_COUNT
 };
 constexpr int PCA_CAP = 64;  // vectors kept per area before the cube is flushed (F = X - U C)
@@ -576,15 +579,23 @@ __global__ __launch_bounds__(256) void bmean_kernel(const float *__restrict__ X,
 }
 
 // ------------------------------------------------------------------------------------
-// Nuisance block of F_t (float64, [Nz][ld]):  Xp[z][j] = X[z, col_j] - sum_q U[z][q] C[q][pos_j]
-// and the partial c_j = b^T Xp_j of the block's z slice.
+// Nuisance block of F_t (float64, [Nz][ld]):  Fb[z][j] = F_t[z, col_j]
+// and the partial c_j = b^T Fb_j of the block's z slice.
+// The nuisance set only shrinks (the O2 tests only decrease), so the columns of iteration t are
+// a subsequence of those of iteration t-1: when the previous block of the area is at hand
+// (DF_FBOLD >= 0) column j is its old column (found by the list position, binary search) minus
+// the one deflation since,  F_t = F_{t-1} - u_{t-1} c_{t-1}^T  -- no read of the cube (a
+// scattered column costs a 64-byte sector per 4-byte sample).  Otherwise (first iteration of an
+// area, or after a flush)  Fb[z][j] = X[z, col_j] - sum_q U[z][q] C[q][pos_j].
 // grid (ceil(ldmax/64), nw, z slices), block (64 columns, 16 waves over z)
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void gather_xp_kernel(
     const float *__restrict__ X, int Nz, long S, const int *__restrict__ nuis,
-    const int *__restrict__ nuis_pos, const long *__restrict__ D, int nw,
-    const double *__restrict__ b, const double *__restrict__ U, const double *__restrict__ C,
-    long ntot, double *__restrict__ Xp, double *__restrict__ cpart, long ctot, int zper) {
+    const int *__restrict__ nuis_pos, const int *__restrict__ nuis_pos_old,
+    const long *__restrict__ D, int nw, const double *__restrict__ b,
+    const double *__restrict__ U, const double *__restrict__ C, long ntot,
+    const double *__restrict__ Fold, double *__restrict__ Fb, double *__restrict__ cpart,
+    long ctot, int zper) {
   __shared__ double red[16][64];
   __shared__ double Cn[PCA_CAP][64];  // coefficients of this block's 64 columns
   const int k = blockIdx.y;
@@ -594,22 +605,47 @@ __global__ __launch_bounds__(1024) void gather_xp_kernel(
   const int n = (int)DSC(DF_N, k), T = (int)DSC(DF_T, k);
   const bool live = j < n;   // real nuisance column
   const bool inld = j < ld;  // padded column (stored as zeros)
-  const long col = live ? (long)nuis[DSC(DF_LIST0, k) + j] : 0;
-  const long pos = live ? (long)nuis_pos[DSC(DF_LIST0, k) + j] : 0;
+  const long list0 = DSC(DF_LIST0, k);
+  const long col = live ? (long)nuis[list0 + j] : 0;
+  const long pos = live ? (long)nuis_pos[list0 + j] : 0;
   const double *bk = b + (long)k * Nz;
   const double *Ua = U + (long)DSC(DF_AREA, k) * Nz * PCA_CAP;
-  double *Xk = Xp + DSC(DF_XP, k);
+  double *Fk = Fb + DSC(DF_XP, k);
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.y);
-  for (int q = w; q < T; q += 16) Cn[q][threadIdx.x] = live ? C[(long)q * ntot + pos] : 0.0;
-  __syncthreads();
   const int z0 = blockIdx.z * zper, z1 = min(Nz, z0 + zper);
+  const long fbold = DSC(DF_FBOLD, k);
   double acc = 0.0;
-  for (int z = z0 + w; z < z1; z += 16) {
-    double v = live ? (double)X[(long)z * S + col] : 0.0;
-    const double *uz = Ua + (long)z * PCA_CAP;  // wave-uniform row of U -> scalar loads
-    for (int q = 0; q < T; ++q) v = fma(-uz[q], Cn[q][threadIdx.x], v);
-    if (inld) Xk[(long)z * ld + j] = v;
-    acc = fma(bk[z], v, acc);
+  if (fbold >= 0) {
+    // ---- from the previous block: column with the same list position
+    const int nold = (int)DSC(DF_NOLD, k), ldold = (int)DSC(DF_LDOLD, k);
+    int io = 0;
+    if (live) {
+      int lo = 0, hi = nold - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((long)nuis_pos_old[list0 + mid] < pos) lo = mid + 1;
+        else hi = mid;
+      }
+      io = lo;
+    }
+    const double cprev = live ? C[(long)(T - 1) * ntot + pos] : 0.0;
+    const double *Fo = Fold + fbold;
+    for (int z = z0 + w; z < z1; z += 16) {
+      double v = 0.0;
+      if (live) v = fma(-Ua[(long)z * PCA_CAP + (T - 1)], cprev, Fo[(long)z * ldold + io]);
+      if (inld) Fk[(long)z * ld + j] = v;
+      acc = fma(bk[z], v, acc);
+    }
+  } else {
+    for (int q = w; q < T; q += 16) Cn[q][threadIdx.x] = live ? C[(long)q * ntot + pos] : 0.0;
+    __syncthreads();
+    for (int z = z0 + w; z < z1; z += 16) {
+      double v = live ? (double)X[(long)z * S + col] : 0.0;
+      const double *uz = Ua + (long)z * PCA_CAP;  // wave-uniform row of U -> scalar loads
+      for (int q = 0; q < T; ++q) v = fma(-uz[q], Cn[q][threadIdx.x], v);
+      if (inld) Fk[(long)z * ld + j] = v;
+      acc = fma(bk[z], v, acc);
+    }
   }
   red[threadIdx.y][threadIdx.x] = acc;
   __syncthreads();
@@ -621,22 +657,25 @@ __global__ __launch_bounds__(1024) void gather_xp_kernel(
   }
 }
 
-// Xp[z][j] -= b[z] c[j]       grid (ceil(Nz/16), nw), block 256 (lanes over columns)
+// Xp[z][j] = Fb[z][j] - b[z] c[j]       grid (ceil(Nz/16), nw), block 256 (lanes over columns)
+// (out of place: Fb stays as the next iteration's source)
 __global__ __launch_bounds__(256) void project_xp_kernel(const double *__restrict__ b, int Nz,
                                                          const long *__restrict__ D, int nw,
+                                                         const double *__restrict__ Fb,
                                                          double *__restrict__ Xp,
                                                          const double *__restrict__ cpart,
                                                          long ctot, int nzb) {
   const int k = blockIdx.y;
   const int ld = (int)DSC(DF_LD, k);
+  const double *F = Fb + DSC(DF_XP, k);
   double *X = Xp + DSC(DF_XP, k);
   const double *c = cpart + DSC(DF_C, k);
   const double *bk = b + (long)k * Nz;
   const int z0 = blockIdx.x * 16, z1 = min(Nz, z0 + 16);
   for (int j = threadIdx.x; j < ld; j += 256) {
-    double cj = 0.0;  // c_j = b^T X_j, summed over the z slices of the gather in fixed order
+    double cj = 0.0;  // c_j = b^T F_j, summed over the z slices of the gather in fixed order
     for (int q = 0; q < nzb; ++q) cj += c[(long)q * ctot + j];
-    for (int z = z0; z < z1; ++z) X[(long)z * ld + j] = fma(-bk[z], cj, X[(long)z * ld + j]);
+    for (int z = z0; z < z1; ++z) X[(long)z * ld + j] = fma(-bk[z], cj, F[(long)z * ld + j]);
   }
 }
 
@@ -1328,7 +1367,7 @@ struct DevBuf {
 };
 
 struct PcaWorkspace {
-  DevBuf b[16];
+  DevBuf b[18];
 };
 
 // launches lanczos_kernel with the basis in LDS when the largest matrix allows it
@@ -1461,6 +1500,7 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
          &b_tiles = W.b[4], &b_xp = W.b[5], &b_g = W.b[6], &b_cv = W.b[7], &b_bu = W.b[8],
          &b_part = W.b[9], &b_cpart = W.b[10], &b_info = W.b[11], &b_U = W.b[12], &b_C = W.b[13],
          &b_small = W.b[14], &b_fd = W.b[15];
+  DevBuf *b_fb[2] = {&W.b[16], &W.b[17]};  // nuisance blocks of this / the previous iteration
   const bool debug = getenv("ORIGIN_PCA_DEBUG") != nullptr;
   const size_t st_bytes = (size_t)na * (sizeof(double) + 4 * sizeof(int)) + sizeof(int) * 2 +
                           (size_t)(na + 1) * sizeof(long) + 64;
@@ -1490,9 +1530,12 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
   ORIGIN_HIP(hipMemsetAsync(d_nbiter, 0, (size_t)na * sizeof(int), st));
   ORIGIN_HIP(hipMemsetAsync(d_nstop, 0, 2 * sizeof(int), st));
   ORIGIN_HIP(hipStreamSynchronize(st));  // `ones` goes out of use
-  if ((rc = b_lists.reserve(ctx, (size_t)4 * ntot * sizeof(int)))) return rc;
+  if ((rc = b_lists.reserve(ctx, (size_t)5 * ntot * sizeof(int)))) return rc;
   int *d_nuis = (int *)b_lists.p, *d_bg = d_nuis + ntot;
-  int *d_nuis_pos = d_bg + ntot, *d_bg_pos = d_nuis_pos + ntot;
+  int *d_bg_pos = d_bg + ntot;
+  int *d_npos[2] = {d_bg_pos + ntot, d_bg_pos + 2 * ntot};  // nuisance positions, ping-pong
+  // nuisance block of each area as the previous iteration left it (host bookkeeping)
+  std::vector<long> fb_off(na, -1), fb_ld(na, 0), fb_n(na, 0);
   if ((rc = b_test.reserve(ctx, (size_t)S * sizeof(double)))) return rc;
   double *d_test = (double *)b_test.p;
   ORIGIN_HIP(hipMemcpyAsync(d_test, d_test0, (size_t)S * sizeof(double), hipMemcpyDeviceToDevice,
@@ -1548,6 +1591,7 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
       ORIGIN_LAUNCH_CHECK();
     }
     for (int a = 0; a < na; ++a) T[a] = 0;
+    std::fill(fb_off.begin(), fb_off.end(), -1L);  // (blocks refer to columns of U)
     src = d_F;
     return ORIGIN_OK;
   };
@@ -1584,11 +1628,11 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
         hipLaunchKernelGGL(pca_select_fast_kernel, dim3(na), dim3(1024),
                            (size_t)nsmax_all * sizeof(int), st, d_spx, d_spx_off, d_test, d_thr,
                            noise_pop, itermax, d_active, d_nbiter, d_nstop, d_mapO2, d_nuis, d_bg,
-                           d_nuis_pos, d_bg_pos, d_n, d_nb, d_hostout, d_selcnt, gen);
+                           d_npos[iters & 1], d_bg_pos, d_n, d_nb, d_hostout, d_selcnt, gen);
       else
         hipLaunchKernelGGL(pca_select_kernel, dim3(na), dim3(1024), sel_lds, st, d_spx, d_spx_off,
                            d_test, d_thr, noise_pop, itermax, d_active, d_nbiter, d_nstop, d_mapO2,
-                           d_nuis, d_bg, d_nuis_pos, d_bg_pos, d_n, d_nb, sel_cap, d_hostout,
+                           d_nuis, d_bg, d_npos[iters & 1], d_bg_pos, d_n, d_nb, sel_cap, d_hostout,
                            d_selcnt, gen);
     }
     ORIGIN_LAUNCH_CHECK();
@@ -1644,6 +1688,11 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
       D[(size_t)DF_NS * nw + k] = ns;
       D[(size_t)DF_CBASE * nw + k] = cb;
       D[(size_t)DF_T * nw + k] = T[a];
+      // previous nuisance block of the area, usable while at least one vector is held
+      const bool have = fb_off[a] >= 0 && T[a] >= 1;
+      D[(size_t)DF_FBOLD * nw + k] = have ? fb_off[a] : -1;
+      D[(size_t)DF_LDOLD * nw + k] = fb_ld[a];
+      D[(size_t)DF_NOLD * nw + k] = fb_n[a];
       xp += (long)Nz * ld;
       c += ld;
       g += (long)ld * ld;
@@ -1684,6 +1733,8 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
     }
     ORIGIN_HIP(hipMemcpyAsync(b_desc.p, h_stage, dbytes + tbytes, hipMemcpyHostToDevice, st));
     if ((rc = b_xp.reserve(ctx, (size_t)xp * sizeof(double)))) return rc;
+    if ((rc = b_fb[iters & 1]->reserve(ctx, (size_t)xp * sizeof(double)))) return rc;
+    double *d_Fb = (double *)b_fb[iters & 1]->p;
     if ((rc = b_g.reserve(ctx, (size_t)g * sizeof(double)))) return rc;
     if ((rc = b_cv.reserve(ctx, (size_t)c * sizeof(double)))) return rc;
     if ((rc = b_bu.reserve(ctx, (size_t)2 * nw * Nz * sizeof(double)))) return rc;
@@ -1717,13 +1768,14 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
     {
       ProfScope ps(ctx, K_PCA_GATHER, 2);
       hipLaunchKernelGGL(gather_xp_kernel, dim3(cdiv(ldmax, 64), nw, nzb), dim3(64, 16), 0, st,
-                         src, Nz, S, d_nuis, d_nuis_pos, dD, nw, d_b, d_U, d_C, ntot, d_Xp, d_cpart,
-                         c, gzper);
+                         src, Nz, S, d_nuis, d_npos[iters & 1], d_npos[(iters & 1) ^ 1], dD, nw, d_b,
+                         d_U, d_C, ntot, (const double *)b_fb[(iters & 1) ^ 1]->p, d_Fb, d_cpart, c,
+                         gzper);
     }
     {
       ProfScope ps(ctx, K_PCA_PROJECT, 2);
       hipLaunchKernelGGL(project_xp_kernel, dim3(cdiv(Nz, 16), nw), dim3(256), 0, st, d_b, Nz, dD,
-                         nw, d_Xp, d_cpart, c, nzb);
+                         nw, d_Fb, d_Xp, d_cpart, c, nzb);
     }
     ORIGIN_LAUNCH_CHECK();
     const bool all_small = ldmax <= LANCZOS_M;  // (ld is n rounded up to 16: n <= 48)
@@ -1795,7 +1847,13 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
                          dD, nw, nzs, Nz, cb, cpart, d_wq, d_C, ntot, d_test);
     }
     ORIGIN_LAUNCH_CHECK();
-    for (int w = 0; w < nw; ++w) T[(int)D[(size_t)DF_AREA * nw + w]] += 1;
+    for (int w = 0; w < nw; ++w) {
+      const int a = (int)D[(size_t)DF_AREA * nw + w];
+      T[a] += 1;
+      fb_off[a] = D[(size_t)DF_XP * nw + w];  // this iteration's block becomes the source
+      fb_ld[a] = D[(size_t)DF_LD * nw + w];
+      fb_n[a] = D[(size_t)DF_N * nw + w];
+    }
     ++iters;
   }
   if ((rc = flush())) return rc;
