@@ -892,31 +892,67 @@ __device__ void lanczos_small_wave(const double *__restrict__ Gk, int n, int ld,
                                    SmallWork &sw, double *__restrict__ v, double *info3,
                                    const double *__restrict__ slab = nullptr, long slab_stride = 0,
                                    int ksplit = 0) {
+  // The caller has zeroed the whole work area: rows / columns beyond n are zeros, so every loop
+  // below runs in unrolled batches of 8 (4) with all LDS reads of a batch independent -- a loop
+  // with a run-time trip count and one dependent read per iteration costs an LDS latency per
+  // element.  The extra terms are exact zeros (same sums, same order).
   const bool own = lane < n;
+  const int nr = (n + 7) & ~7;
   if (!slab) {  // (with slabs the caller has filled sw.G: see lanczos_kernel)
-    for (int c = 0; c < n; ++c)
-      if (own) sw.G[c][lane] = Gk[(long)c * ld + lane];
+    for (int c0 = 0; c0 < nr; c0 += 8) {
+      double g[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] = (own && c0 + e < n) ? Gk[(long)(c0 + e) * ld + lane] : 0.0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sw.G[c0 + e][lane] = g[e];
+    }
   }
   // start vector G * ones
   double y = 0.0;
-  for (int c = 0; c < n; ++c) y += own ? sw.G[c][lane] : 0.0;
+  for (int c0 = 0; c0 < nr; c0 += 8) {
+    double g[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] = sw.G[c0 + e][lane];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) y += g[e];
+  }
   double nrm = sqrt(wave_sum_d(own ? y * y : 0.0));
   if (own) sw.Q[0][lane] = nrm > 0.0 ? y / nrm : (lane == 0 ? 1.0 : 0.0);
   int m = 0;
   double beta_last = 0.0;
   for (int j = 0; j < n; ++j) {
     double w = 0.0;  // w_l = sum_c G[c][l] q_j[c]   (G symmetric)
-    for (int c = 0; c < n; ++c) w = fma(own ? sw.G[c][lane] : 0.0, sw.Q[j][c], w);
+    for (int c0 = 0; c0 < nr; c0 += 8) {
+      double g[8], q[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] = sw.G[c0 + e][lane], q[e] = sw.Q[j][c0 + e];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) w = fma(g[e], q[e], w);
+    }
     double aj = 0.0;
+    const int jr = (j + 4) & ~3;  // j + 1 rounded up to 4 (h[i] = 0 for i > j)
     for (int pass = 0; pass < 2; ++pass) {
       if (own) sw.w[lane] = w;
       // lane i <= j: h_i = q_i . w
       double hi = 0.0;
-      if (lane <= j)
-        for (int e = 0; e < n; ++e) hi = fma(sw.Q[lane][e], sw.w[e], hi);
-      if (lane <= j) sw.h[lane] = hi;
+      if (lane <= j) {
+        for (int e0 = 0; e0 < nr; e0 += 8) {
+          double a[8], b[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[e] = sw.Q[lane][e0 + e], b[e] = sw.w[e0 + e];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) hi = fma(a[e], b[e], hi);
+        }
+        sw.h[lane] = hi;
+      }
       aj += sw.h[j];
-      for (int i = 0; i <= j; ++i) w = fma(-sw.h[i], own ? sw.Q[i][lane] : 0.0, w);
+      for (int i0 = 0; i0 < jr; i0 += 4) {
+        double a[4], b[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] = sw.h[i0 + e], b[e] = sw.Q[i0 + e][lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w = fma(-a[e], b[e], w);
+      }
     }
     const double bj = sqrt(wave_sum_d(own ? w * w : 0.0));
     if (lane == 0) sw.alpha[j] = aj, sw.beta[j] = bj;
@@ -974,6 +1010,11 @@ __global__ __launch_bounds__(1024) void lanczos_kernel(const double *__restrict_
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (n <= LANCZOS_M) {  // whole-space Lanczos inside one wave, no barriers
     SmallWork &sw = *reinterpret_cast<SmallWork *>(lz_dyn);
+    {  // the one-wave solver relies on zeros beyond n (see lanczos_small_wave)
+      double *z8 = reinterpret_cast<double *>(&sw);
+      for (int i = tid; i < (int)(sizeof(SmallWork) / sizeof(double)); i += 1024) z8[i] = 0.0;
+      __syncthreads();
+    }
     if (slab) {
       // G straight from the K-split slabs of gram_kernel (the reduction kernel is skipped when
       // every matrix of the launch is small): same sums, in the same order, as
