@@ -12,8 +12,8 @@
 // v_mfma_f32_32x32x16_f16 with a two-term f16 split of both operands (data scaled by a power of
 // two per block and channel, taps by 2^12; Ah Bh + Ah Bl + Al Bh, fp32 accumulation).
 //
-// A block (8 waves, two per SIMD) owns a 128 x 64 region of one channel at a time and marches
-// z.  Per channel it (1) converts the (128+P-1) x (64+P-1) input tile -- staged in registers
+// A block (8 waves, two per SIMD) owns a 128 x 64 region (two of them, stacked in y, sharing
+// the channel's fragment table) of one channel at a time and marches z.  Per channel it (1) converts the (128+P-1) x (64+P-1) input tile -- staged in registers
 // while the previous channel was computed -- to f16 hi/lo images in LDS (row pitch 19 x 16 B:
 // the 16-byte B-fragment reads of a lane group fall on distinct banks), (2) expands the P x P
 // taps into the Toeplitz fragment table: per kernel row 8 copies of the zero-padded tap array
@@ -26,10 +26,6 @@
 #include <algorithm>
 
 #include "common.h"
-
-#ifndef SM_EXP
-#define SM_EXP 0
-#endif
 
 namespace {
 
@@ -60,7 +56,8 @@ template <bool DUMMY>
 __global__ __launch_bounds__(512, 1) void spatial_mfma_kernel(const float *__restrict__ A,
                                                               const float *__restrict__ taps,
                                                               int Nz, int Ny, int Nx, int P,
-                                                              int zper, float *__restrict__ out) {
+                                                              int zper, int R,
+                                                              float *__restrict__ out) {
   extern __shared__ __align__(16) char sm_lds[];
   const int copy_all = sm_copy_all(P);
   char *tab = sm_lds;                           // Toeplitz fragments
@@ -73,7 +70,11 @@ __global__ __launch_bounds__(512, 1) void spatial_mfma_kernel(const float *__res
   // all 152 columns are staged whatever P (the k-steps of a wave always read a 64-column
   // window; columns beyond x0 + 127 + H only ever meet zero taps but must be finite)
   const int iw4 = SM_IW / 4, ih = SM_RY + H;
-  const int x0 = blockIdx.x * SM_RX, y0 = blockIdx.y * SM_RY;
+  // a block serves R regions stacked in y: the fragment table of a channel is built once for
+  // all of them (the PSF differs per channel, not per region)
+  const int x0 = blockIdx.x * SM_RX;
+  const int yb = blockIdx.y * R * SM_RY;  // y0 of sub-region r is yb + r * SM_RY
+  const int nr = min(R, (Ny - yb + SM_RY - 1) / SM_RY);  // sub-regions inside the field
   const long S = (long)Ny * Nx;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(512, 1) void spatial_mfma_kernel(const float *__res
   // ---- register staging of the next channel's input tile and taps
   float4 stage[SM_NQ];
   float tapreg[2];
-  auto load_tile = [&](int z) {
+  auto load_tile = [&](int z, int y0) {
     const float *Az = A + (long)z * S;
 #pragma unroll
     for (int q = 0; q < SM_NQ; ++q) {
@@ -108,8 +109,10 @@ __global__ __launch_bounds__(512, 1) void spatial_mfma_kernel(const float *__res
   // unwritten image rows / pads must read as finite numbers (they only meet zero taps)
   for (int i = tid; i < (2 * SM_IMG) / 16; i += 512)
     reinterpret_cast<uint4 *>(img_h)[i] = make_uint4(0u, 0u, 0u, 0u);
-  load_tile(z0);
-  for (int z = z0; z < z1; ++z) {
+  load_tile(z0, yb);
+  for (int z = z0; z < z1; ++z)
+  for (int rr = 0; rr < nr; ++rr) {
+    const int y0 = yb + rr * SM_RY;
     // ---- (1) scale of this channel's tile: max |x| -> 2^e with max |y| in [2^14, 2^15)
     float m = 0.f;
 #pragma unroll
@@ -121,8 +124,10 @@ __global__ __launch_bounds__(512, 1) void spatial_mfma_kernel(const float *__res
     if (tid == 0) *redmax = 0u;
     __syncthreads();  // also: every wave is done with the previous channel's LDS images
     if (lane == 0) atomicMax(redmax, __float_as_uint(m));
-    if (tid < P * P) tapf[tid] = tapreg[0];
-    if (tid + 512 < P * P) tapf[tid + 512] = tapreg[1];
+    if (rr == 0) {  // taps of this channel (they came with the tile of sub-region 0)
+      if (tid < P * P) tapf[tid] = tapreg[0];
+      if (tid + 512 < P * P) tapf[tid + 512] = tapreg[1];
+    }
     __syncthreads();
     const int ex = (int)((*redmax >> 23) & 0xffu);
     const bool tiny = ex < 40 || ex == 255;
@@ -130,9 +135,6 @@ __global__ __launch_bounds__(512, 1) void spatial_mfma_kernel(const float *__res
     const float inv = __uint_as_float((unsigned)(tiny ? 127 - SM_TAP_LOG2 : ex - 14 - SM_TAP_LOG2)
                                       << 23);
     // ---- (2a) f16 hi / lo images of the tile
-#if SM_EXP == 2
-    if (z == z0)
-#endif
 #pragma unroll
     for (int q = 0; q < SM_NQ; ++q) {
       const int e = tid + 512 * q;
@@ -153,10 +155,7 @@ __global__ __launch_bounds__(512, 1) void spatial_mfma_kernel(const float *__res
     }
     // ---- (2b) Toeplitz fragment table: G_dy[e] = k[dy][e - 31] (0 outside), copies shifted
     // by 0..7 elements, hi and lo; group (dy, hl, copy, q) holds G_dy[8 q + copy .. + 7]
-#if SM_EXP == 1
-    if (z == z0)
-#endif
-    {
+    if (rr == 0) {
       const float tscale = (float)(1 << SM_TAP_LOG2);
       const int ngroups = P * 8 * SM_GROUPS;
       for (int gidx = tid; gidx < ngroups; gidx += 512) {
@@ -180,7 +179,9 @@ __global__ __launch_bounds__(512, 1) void spatial_mfma_kernel(const float *__res
       }
     }
     __syncthreads();
-    if (z + 1 < z1) load_tile(z + 1);  // in flight while this channel is computed
+    // next tile (same channel, next sub-region; else next channel): in flight during the MFMAs
+    if (rr + 1 < nr) load_tile(z, y0 + SM_RY);
+    else if (z + 1 < z1) load_tile(z + 1, yb);
 
     // ---- (3) P x 4 k-steps: acc += Ah Bh + Ah Bl + Al Bh
     f32x16 acc;
@@ -198,11 +199,7 @@ __global__ __launch_bounds__(512, 1) void spatial_mfma_kernel(const float *__res
         bh[ks] = *reinterpret_cast<const f16x8 *>(bp + ks * 32);
         bl[ks] = *reinterpret_cast<const f16x8 *>(bp + ks * 32 + SM_IMG);
       }
-#if SM_EXP == 3
-      for (int dy = 0; dy < 1; ++dy) {
-#else
       for (int dy = 0; dy < P; ++dy) {
-#endif
         const bool last = dy == P - 1;  // the last row re-reads itself (valid addresses)
         const char *an = last ? ap : ap + 2 * SM_GROUPS * 16;
         const char *bn = last ? bp : bp + SM_PITCH;
@@ -258,13 +255,19 @@ int origin_spatial_mfma_launch(origin_ctx *ctx, const float *A, const float *tap
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  const long regions = (long)cdiv(Nx, SM_RX) * cdiv(Ny, SM_RY);
-  int nzb = (int)(((long)ctx->num_cu * 4 + regions - 1) / regions);
+  // R regions stacked in y share a block (the per-channel fragment table is built once for all
+  // of them); more z chunks keep the number of blocks up
+  const int ry = cdiv(Ny, SM_RY);
+  int R = 1;  // largest divisor of the region count up to 5 (no idle sub-region slots)
+  for (int c = 2; c <= 5; ++c)
+    if (ry % c == 0) R = c;
+  const long groups = (long)cdiv(Nx, SM_RX) * cdiv(ry, R);
+  int nzb = (int)(((long)ctx->num_cu * 4 + groups - 1) / groups);
   nzb = std::max(1, std::min(nzb, Nz));
   const int zper = cdiv(Nz, nzb);
-  dim3 grid(cdiv(Nx, SM_RX), cdiv(Ny, SM_RY), cdiv(Nz, zper));
+  dim3 grid(cdiv(Nx, SM_RX), cdiv(ry, R), cdiv(Nz, zper));
   hipLaunchKernelGGL(spatial_mfma_kernel<true>, grid, dim3(512), lds, ctx->stream, A, taps, Nz, Ny,
-                     Nx, P, zper, out);
+                     Nx, P, zper, R, out);
   ORIGIN_LAUNCH_CHECK();
   return ORIGIN_OK;
 }
