@@ -258,8 +258,8 @@ int origin_spatial_mfma_launch(origin_ctx *ctx, const float *A, const float *tap
   // R regions stacked in y share a block (the per-channel fragment table is built once for all
   // of them); more z chunks keep the number of blocks up
   const int ry = cdiv(Ny, SM_RY);
-  int R = 1;  // largest divisor of the region count up to 5 (no idle sub-region slots)
-  for (int c = 2; c <= 5; ++c)
+  int R = 1;  // largest divisor of the region count up to 10 (no idle sub-region slots)
+  for (int c = 2; c <= 10; ++c)
     if (ry % c == 0) R = c;
   const long groups = (long)cdiv(Nx, SM_RX) * cdiv(ry, R);
   int nzb = (int)(((long)ctx->num_cu * 4 + groups - 1) / groups);
