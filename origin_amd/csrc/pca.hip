@@ -1064,8 +1064,10 @@ __global__ __launch_bounds__(1024) void lanczos_kernel(const double *__restrict_
     __syncthreads();
     int m = 0;
     double beta_last = 0.0;
-    // a dominant nuisance converges in a few steps: try a short Krylov space first
-    const int mmax = restarts == 0 ? min(mfull, LANCZOS_M / 2) : mfull;
+    // a dominant nuisance converges in a few steps: the Ritz pair is tested at LANCZOS_M/2
+    // and 3/4 LANCZOS_M, and the recurrence goes on from there (no restart) when it fails
+    const int mmax = mfull;
+    bool solved = false;
     for (int j = 0; j < mmax; ++j) {
       const double *qj = Qk + (long)j * ld;
       double *w = Qk + (long)(j + 1) * ld;
@@ -1147,14 +1149,25 @@ __global__ __launch_bounds__(1024) void lanczos_kernel(const double *__restrict_
         for (int e = tid; e < n; e += 1024) w[e] *= ib;
       }
       __syncthreads();
+      if (j + 1 < mmax && (j + 1 == LANCZOS_M / 2 || j + 1 == 3 * LANCZOS_M / 4)) {
+        if (wave == 0) {
+          const double th = tridiag_top(alpha, beta, m, lane, ws);
+          if (lane == 0) s_theta = th;
+        }
+        __syncthreads();
+        solved = fabs(bj * svec[m - 1]) <= tol * fabs(s_theta);  // block-uniform
+        if (solved) break;
+      }
     }
     __syncthreads();
     // ---- largest eigenpair of T_m (wave 0)
-    if (wave == 0) {
-      const double th = tridiag_top(alpha, beta, m, lane, ws);
-      if (lane == 0) s_theta = th;
+    if (!solved) {
+      if (wave == 0) {
+        const double th = tridiag_top(alpha, beta, m, lane, ws);
+        if (lane == 0) s_theta = th;
+      }
+      __syncthreads();
     }
-    __syncthreads();
     theta = s_theta;
     // y = Q s
     for (int e = tid; e < n; e += 1024) {
