@@ -781,26 +781,45 @@ __device__ __forceinline__ double block_sum(double v, double *red) {
   return t;
 }
 
-// number of eigenvalues of T (alpha[0..m), beta[0..m-1)) that are < x
-__device__ __forceinline__ int sturm_count(const double *alpha, const double *beta, int m, double x,
-                                           double pivmin) {
-  int cnt = 0;
-  double q = alpha[0] - x;
-  if (fabs(q) < pivmin) q = -pivmin;
-  cnt += q < 0.0;
-  for (int i = 1; i < m; ++i) {
-    q = alpha[i] - x - beta[i - 1] * beta[i - 1] / q;
-    if (fabs(q) < pivmin) q = -pivmin;
-    cnt += q < 0.0;
+// Number of eigenvalues < x of the symmetric tridiagonal with diagonal a[0..m) and squared
+// off-diagonals bb[0..m-1), both already divided by the norm of T (so |a - x| <= 3, bb <= 1):
+// sign changes of the leading principal minors p_i = (a_i - x) p_{i-1} - bb_{i-1} p_{i-2}.
+// One multiply-add on the dependency chain per row (the pivot form q_i = a_i - x - bb/q_{i-1}
+// carries a float64 division, ~15 dependent instructions).  A minor that is exactly zero takes
+// the sign opposite to its predecessor -- the same convention as replacing a zero pivot by a
+// tiny negative one.  With the scaling the minors cannot overflow for m <= 48; they are
+// rescaled every 8 rows against underflow.
+// The rows are taken eight at a time with their coefficients loaded up front (the loads do not
+// depend on the chain); the arrays are padded by 8 and rows >= m are not counted.
+constexpr int TRI_PAD = LANCZOS_M + 8;
+__device__ __forceinline__ int sturm_count(const double *a, const double *bb, int m, double x) {
+  double p0 = 1.0, p1 = a[0] - x;
+  bool s1 = p1 < 0.0 || p1 == 0.0;  // sign of p_{i-1} (true: negative), p_{-1} = 1
+  int cnt = s1;
+  for (int i0 = 0; i0 < m - 1; i0 += 8) {
+    double av[8], bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) av[e] = a[i0 + 1 + e] - x, bv[e] = bb[i0 + e];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const double p2 = fma(av[e], p1, -bv[e] * p0);
+      const bool s2 = p2 < 0.0 || (p2 == 0.0 && !s1);
+      cnt += (i0 + 1 + e < m) && (s2 != s1);
+      p0 = p1, p1 = p2, s1 = s2;
+    }
+    if (fabs(p1) < 1e-100 && fabs(p0) < 1e-100) p0 *= 1e100, p1 *= 1e100;
   }
   return cnt;
 }
 
 // Largest eigenpair of the symmetric tridiagonal T (alpha[0..m), beta[0..m-1)), executed by
-// ONE wave: 64-way multisection on Sturm counts for the eigenvalue, then inverse iteration with
-// partial pivoting (lane 0) for the unit eigenvector, left in ws.x.  Returns the eigenvalue.
+// ONE wave: 64-way multisection on Sturm counts for the eigenvalue, then two steps of inverse
+// iteration (lane 0) for the unit eigenvector, left in ws.x.  Returns the eigenvalue.
+// The shift of the inverse iteration lies just above the largest eigenvalue, so T - sigma I is
+// negative definite and its LDL^T factorisation needs no pivoting; it is formed once, with the
+// pivot reciprocals kept for both solves.
 struct TriWork {
-  double x[LANCZOS_M], d[LANCZOS_M], du[LANCZOS_M], du2[LANCZOS_M], dl[LANCZOS_M];
+  double x[TRI_PAD], a[TRI_PAD], bb[TRI_PAD], l[TRI_PAD], rd[TRI_PAD];
 };
 
 __device__ __forceinline__ double tridiag_top(const double *alpha, const double *beta, int m,
@@ -812,12 +831,24 @@ __device__ __forceinline__ double tridiag_top(const double *alpha, const double 
     hi = fmax(hi, alpha[i] + r);
     tn = fmax(tn, fabs(alpha[i]) + r);
   }
-  const double pivmin = fmax(tn * tn, 1.0) * 1e-300 + 1e-290;
-  hi += 1e-14 * tn + 1e-300;
-  for (int it = 0; it < 12; ++it) {
+  if (!(tn > 0.0)) {  // T == 0
+    if (lane == 0)
+      for (int i = 0; i < m; ++i) ws.x[i] = i == 0 ? 1.0 : 0.0;
+    return 0.0;
+  }
+  // scaled copy: a = alpha / tn, bb = (beta / tn)^2
+  const double itn = 1.0 / tn;
+  for (int i = lane; i < m; i += 64) {
+    ws.a[i] = alpha[i] * itn;
+    const double b = i < m - 1 ? beta[i] * itn : 0.0;
+    ws.bb[i] = b * b;
+  }
+  lo *= itn;
+  hi = hi * itn + 1e-14;
+  for (int it = 0; it < 10; ++it) {  // 65^10 > 2^53 * (hi - lo)
     // lane l tests x_l = lo + (l+1) (hi-lo)/65 ; count(x) == m  <=>  x > theta_max
     const double x = lo + (hi - lo) * (double)(lane + 1) / 65.0;
-    const bool above = sturm_count(alpha, beta, m, x, pivmin) >= m;
+    const bool above = sturm_count(ws.a, ws.bb, m, x) >= m;
     const unsigned long long bal = __ballot(above);
     const int first = bal ? __ffsll((long long)bal) - 1 : 64;  // first lane above
     const double nlo = first == 0 ? lo : lo + (hi - lo) * (double)first / 65.0;
@@ -825,55 +856,86 @@ __device__ __forceinline__ double tridiag_top(const double *alpha, const double 
     lo = nlo;
     hi = nhi;
   }
-  const double theta = 0.5 * (lo + hi);
+  const double theta_s = 0.5 * (lo + hi);  // in units of tn
   if (lane == 0) {
-    double *x = ws.x, *d = ws.d, *du = ws.du, *du2 = ws.du2, *dl = ws.dl;
-    const int mm = m;
-    double tnorm = 0.0;
-    for (int i = 0; i < mm; ++i)
-      tnorm = fmax(tnorm, fabs(alpha[i]) + (i < mm - 1 ? fabs(beta[i]) : 0.0));
-    const double sigma = theta + 4e-16 * tnorm;
-    for (int i = 0; i < mm; ++i) x[i] = 1.0 / sqrt((double)mm);
+    double *x = ws.x, *l = ws.l, *rd = ws.rd;
+    const double sigma = theta_s + 4e-16;
+    // LDL^T of (T - sigma I) / tn:  d_0 = a_0 - sigma, l_i = b_i / d_i,
+    // d_{i+1} = a_{i+1} - sigma - b_i^2 / d_i   (all d < 0; a pivot that rounding pushed to
+    // zero or above is replaced by a tiny negative one).  Every loop below is a serial
+    // recurrence: eight rows at a time, operands loaded before and results stored after the
+    // chain, so that an LDS round trip is paid per eight rows instead of per row.
+    double d = ws.a[0] - sigma;
+    for (int i0 = 0; i0 < m; i0 += 8) {
+      double an[8], bq[8], bl[8], rr[8], ll[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        an[e] = ws.a[i0 + e + 1] - sigma;  // row i0 + e + 1 (padding beyond m: unused)
+        bq[e] = ws.bb[i0 + e];
+        bl[e] = i0 + e < m - 1 ? beta[i0 + e] * itn : 0.0;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (!(d < -1e-30)) d = -1e-30;
+        const double r = 1.0 / d;
+        rr[e] = r;
+        ll[e] = bl[e] * r;
+        d = an[e] - bq[e] * r;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) rd[i0 + e] = rr[e], l[i0 + e] = ll[e];
+    }
+    // rows >= m of l / rd hold padding values: the solves below never use them
+    const double x0 = 1.0 / sqrt((double)m);
+    for (int i = 0; i < TRI_PAD; ++i) x[i] = i < m ? x0 : 0.0;
     for (int iter = 0; iter < 2; ++iter) {
-      for (int i = 0; i < mm; ++i) {
-        d[i] = alpha[i] - sigma;
-        du[i] = i < mm - 1 ? beta[i] : 0.0;
-        dl[i] = du[i];
-        du2[i] = 0.0;
-      }
-      // LU with partial pivoting (dgtsv), solving in place
-      for (int i = 0; i < mm - 1; ++i) {
-        if (fabs(d[i]) >= fabs(dl[i])) {
-          if (d[i] == 0.0) d[i] = 1e-300;
-          const double f = dl[i] / d[i];
-          d[i + 1] -= f * du[i];
-          x[i + 1] -= f * x[i];
-          dl[i] = 0.0;
-        } else {
-          const double f = d[i] / dl[i];
-          d[i] = dl[i];
-          const double t = d[i + 1];
-          d[i + 1] = du[i] - f * t;
-          du2[i] = (i < mm - 2) ? du[i + 1] : 0.0;
-          if (i < mm - 2) du[i + 1] = -f * du2[i];
-          du[i] = t;
-          const double tx = x[i];
-          x[i] = x[i + 1];
-          x[i + 1] = tx - f * x[i + 1];
+      // L y = x   (y_0 = x_0, y_i = x_i - l_{i-1} y_{i-1})
+      double y = x[0];
+      for (int i0 = 1; i0 < m; i0 += 8) {
+        double lv[8], xv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) lv[e] = l[i0 + e - 1], xv[e] = x[i0 + e];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          y = fma(-lv[e], y, xv[e]);
+          xv[e] = y;
         }
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (i0 + e < m) x[i0 + e] = xv[e];
       }
-      if (d[mm - 1] == 0.0) d[mm - 1] = 1e-300;
-      x[mm - 1] /= d[mm - 1];
-      if (mm > 1) x[mm - 2] = (x[mm - 2] - du[mm - 2] * x[mm - 1]) / d[mm - 2];
-      for (int i = mm - 3; i >= 0; --i)
-        x[i] = (x[i] - du[i] * x[i + 1] - du2[i] * x[i + 2]) / d[i];
-      double nx = 0.0;
-      for (int i = 0; i < mm; ++i) nx += x[i] * x[i];
+      // D z = y ; L^T w = z   (w_{m-1} = y_{m-1} / d_{m-1}, w_i = y_i / d_i - l_i w_{i+1})
+      double w = 0.0, nx = 0.0;
+      for (int i0 = (m - 1) & ~7; i0 >= 0; i0 -= 8) {
+        double lv[8], zv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const bool in = i0 + e < m;
+          lv[e] = (i0 + e < m - 1) ? l[i0 + e] : 0.0;
+          zv[e] = in ? x[i0 + e] * rd[i0 + e] : 0.0;
+        }
+#pragma unroll
+        for (int e = 7; e >= 0; --e) {
+          w = fma(-lv[e], w, zv[e]);  // rows >= m: lv = zv = 0 keep w = 0
+          zv[e] = w;
+          nx = fma(w, w, nx);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (i0 + e < m) x[i0 + e] = zv[e];
+      }
       nx = 1.0 / sqrt(nx);
-      for (int i = 0; i < mm; ++i) x[i] *= nx;
+      for (int i0 = 0; i0 < m; i0 += 8) {
+        double xv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xv[e] = x[i0 + e] * nx;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (i0 + e < m) x[i0 + e] = xv[e];
+      }
     }
   }
-  return theta;
+  return theta_s * tn;
 }
 
 // Small matrices (n <= LANCZOS_M): the Krylov space is the whole space, so one Lanczos pass of
