@@ -283,7 +283,7 @@ __device__ __forceinline__ void pca_select_body(
 // Same selection for areas of at most 1024 * SEL_EPT spaxels (every 100 x 100 area), built for
 // the latency of a one-block kernel: thread t owns the SEL_EPT consecutive list entries
 // [t*E, (t+1)*E) in registers, so index order is (thread, local) order and each compaction is ONE
-// block scan of per-thread counts instead of one scan per 1024-entry chunk (3 scans + the 8
+// block scan of per-thread counts instead of one scan per 1024-entry chunk (3 scans + a few
 // radix passes instead of ~50 scans).  Results are identical to pca_select_kernel.
 constexpr int SEL_EPT = 12;
 
@@ -318,10 +318,10 @@ __device__ __forceinline__ void pca_select_fast_body(
     int *__restrict__ nbiter, int *__restrict__ nstop, int *__restrict__ mapO2,
     int *__restrict__ nuis, int *__restrict__ bg, int *__restrict__ nuis_pos,
     int *__restrict__ bg_pos, int *__restrict__ n_out, int *__restrict__ nb_out) {
-  __shared__ unsigned long long wsum[16];
+  __shared__ unsigned long long wsum[16], wmax[16];
   __shared__ int hist[256];
   __shared__ unsigned long long s_prefix;
-  __shared__ int s_remaining, s_it;
+  __shared__ int s_remaining, s_it, s_done;
   extern __shared__ int scache[];  // spaxel index of every list entry (for the filtered-index quirk)
   const int a = blockIdx.x;
   const int tid = threadIdx.x;
@@ -391,19 +391,50 @@ __device__ __forceinline__ void pca_select_fast_body(
   if (nb > ncand) nb = ncand;
 
   if (nb > 0) {
-    // ---- radix select of the nb-th smallest candidate (keys: bits of positive doubles)
-    if (tid == 0) s_prefix = 0ull, s_remaining = nb - 1;
-    unsigned long long maskbits = 0ull;
-    for (int pass = 7; pass >= 0; --pass) {
-      const int shift = pass * 8;
+    // ---- radix select of the nb-th smallest candidate (keys: bits of positive doubles).
+    // The O2 values of an area sit in a narrow range around 1, so the leading bytes of all
+    // keys coincide and a histogram over them is one LDS counter hit by every thread.  The
+    // digits are therefore taken from key - min(key), most significant bit of the RANGE first
+    // (8 bits per pass), and the passes stop as soon as the bucket holding the wanted rank has
+    // a single element -- typically after two or three passes instead of eight.
+    unsigned long long kmin = ~0ull, kmax = 0ull;
+#pragma unroll
+    for (int e = 0; e < SEL_EPT; ++e)
+      if (sp[e] >= 0 && tv[e] > 0.0 && tv[e] <= thr) {
+        const unsigned long long key = (unsigned long long)__double_as_longlong(tv[e]);
+        kmin = key < kmin ? key : kmin;
+        kmax = key > kmax ? key : kmax;
+      }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const unsigned long long o1 = __shfl_xor(kmin, off, 64), o2 = __shfl_xor(kmax, off, 64);
+      kmin = o1 < kmin ? o1 : kmin;
+      kmax = o2 > kmax ? o2 : kmax;
+    }
+    __syncthreads();  // previous users of wsum are done
+    if ((tid & 63) == 0) wsum[tid >> 6] = kmin, wmax[tid >> 6] = kmax;
+    if (tid == 0) s_prefix = 0ull, s_remaining = nb - 1, s_done = 0;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      kmin = wsum[w] < kmin ? wsum[w] : kmin;
+      kmax = wmax[w] > kmax ? wmax[w] : kmax;
+    }
+    const unsigned long long range = kmax - kmin;  // nb > 0: there is at least one candidate
+    int hi_bit = range ? 64 - __clzll((long long)range) : 0;  // digits below this bit
+    while (hi_bit > 0) {
+      const int lo_bit = hi_bit > 8 ? hi_bit - 8 : 0;
+      const unsigned long long above = hi_bit >= 64 ? 0ull : ~0ull << hi_bit;  // decided bits
+      const unsigned dmask = (1u << (hi_bit - lo_bit)) - 1u;
       if (tid < 256) hist[tid] = 0;
       __syncthreads();
       const unsigned long long prefix = s_prefix;
 #pragma unroll
       for (int e = 0; e < SEL_EPT; ++e)
         if (sp[e] >= 0 && tv[e] > 0.0 && tv[e] <= thr) {
-          const unsigned long long key = (unsigned long long)__double_as_longlong(tv[e]);
-          if ((key & maskbits) == prefix) atomicAdd(&hist[(int)((key >> shift) & 255ull)], 1);
+          const unsigned long long key =
+              (unsigned long long)__double_as_longlong(tv[e]) - kmin;
+          if ((key & above) == prefix) atomicAdd(&hist[(int)((unsigned)(key >> lo_bit) & dmask)], 1);
         }
       __syncthreads();
       if (tid < 64) {  // wave 0: bucket holding rank `remaining` via a 64-lane prefix scan
@@ -419,22 +450,36 @@ __device__ __forceinline__ void pca_select_fast_body(
         }
         const int excl = incl - mine;
         if (rem0 >= excl && rem0 < incl) {  // exactly one lane
-          int rem = rem0 - excl, b = 4 * tid;
+          int rem = rem0 - excl, b = 4 * tid, hb = h0;
           if (rem >= h0) {
-            rem -= h0, ++b;
+            rem -= h0, ++b, hb = h1;
             if (rem >= h1) {
-              rem -= h1, ++b;
-              if (rem >= h2) rem -= h2, ++b;
+              rem -= h1, ++b, hb = h2;
+              if (rem >= h2) rem -= h2, ++b, hb = h3;
             }
           }
           s_remaining = rem;
-          s_prefix = prefix | ((unsigned long long)b << shift);
+          s_prefix = prefix | ((unsigned long long)b << lo_bit);
+          s_done = hb == 1;  // the bucket's only element is the answer (then rem == 0)
         }
       }
-      maskbits |= 255ull << shift;
+      __syncthreads();
+      hi_bit = lo_bit;
+      if (s_done) break;
+    }
+    if (hi_bit > 0) {  // stopped early: the one candidate matching the decided bits
+      const unsigned long long above = ~0ull << hi_bit, prefix = s_prefix;
+      __syncthreads();  // everyone has read s_prefix
+#pragma unroll
+      for (int e = 0; e < SEL_EPT; ++e)
+        if (sp[e] >= 0 && tv[e] > 0.0 && tv[e] <= thr) {
+          const unsigned long long key =
+              (unsigned long long)__double_as_longlong(tv[e]) - kmin;
+          if ((key & above) == prefix) s_prefix = key;
+        }
       __syncthreads();
     }
-    const unsigned long long tau = s_prefix;
+    const unsigned long long tau = s_prefix + kmin;
     const int need_equal = s_remaining + 1;
     // ---- emit the background columns.  The reference indexes the *filtered* vector
     // test[test > 0] and uses those indices on the unfiltered columns (lib :908-917): the
