@@ -675,11 +675,26 @@ __global__ __launch_bounds__(1024) void gather_xp_kernel(
     }
     const double cprev = live ? C[(long)(T - 1) * ntot + pos] : 0.0;
     const double *Fo = Fold + fbold;
-    for (int z = z0 + w; z < z1; z += 16) {
-      double v = 0.0;
-      if (live) v = fma(-Ua[(long)z * PCA_CAP + (T - 1)], cprev, Fo[(long)z * ldold + io]);
-      if (inld) Fk[(long)z * ld + j] = v;
-      acc = fma(bk[z], v, acc);
+    // four channels per trip with their loads issued together (each is an L2 round trip)
+    for (int z = z0 + w; z < z1; z += 64) {
+      double fo[4], uu[4], bb[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int zz = z + 16 * s;
+        const long zc = zz < z1 ? zz : z0;
+        fo[s] = live ? Fo[zc * ldold + io] : 0.0;
+        uu[s] = Ua[zc * PCA_CAP + (T - 1)];
+        bb[s] = bk[zc];
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int zz = z + 16 * s;
+        if (zz < z1) {
+          const double v = live ? fma(-uu[s], cprev, fo[s]) : 0.0;
+          if (inld) Fk[(long)zz * ld + j] = v;
+          acc = fma(bb[s], v, acc);
+        }
+      }
     }
   } else {
     for (int q = w; q < T; q += 16) Cn[q][threadIdx.x] = live ? C[(long)q * ntot + pos] : 0.0;
@@ -718,9 +733,23 @@ __global__ __launch_bounds__(256) void project_xp_kernel(const double *__restric
   const double *bk = b + (long)k * Nz;
   const int z0 = blockIdx.x * 16, z1 = min(Nz, z0 + 16);
   for (int j = threadIdx.x; j < ld; j += 256) {
+    // all loads of the column first (independent), then the arithmetic
+    double cq[16], f[16], bz[16];  // nzb <= 16, 16 channels per block
+#pragma unroll
+    for (int q = 0; q < 16; ++q) cq[q] = q < nzb ? c[(long)q * ctot + j] : 0.0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int z = z0 + e < z1 ? z0 + e : z0;
+      f[e] = F[(long)z * ld + j];
+      bz[e] = bk[z];
+    }
     double cj = 0.0;  // c_j = b^T F_j, summed over the z slices of the gather in fixed order
-    for (int q = 0; q < nzb; ++q) cj += c[(long)q * ctot + j];
-    for (int z = z0; z < z1; ++z) X[(long)z * ld + j] = fma(-bk[z], cj, F[(long)z * ld + j]);
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      if (q < nzb) cj += cq[q];
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      if (z0 + e < z1) X[(long)(z0 + e) * ld + j] = fma(-bz[e], cj, f[e]);
   }
 }
 
@@ -755,18 +784,27 @@ __global__ __launch_bounds__(64) void gram_kernel(const double *__restrict__ Xp,
   const bool ia0 = i0 + r16 < ld, ia1 = i0 + 16 + r16 < ld;
   const bool jb0 = j0 + r16 < ld, jb1 = j0 + 16 + r16 < ld;
   double4_t acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc10 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
-  for (int z = z0; z < z1; z += 4) {
-    const int zz = z + kq;
-    const bool zin = zz < z1;
-    const double *row = X + (long)(zin ? zz : z0) * ld;
-    const double a0 = (zin && ia0) ? row[i0 + r16] : 0.0;
-    const double a1 = (zin && ia1) ? row[i0 + 16 + r16] : 0.0;
-    const double b0 = (zin && jb0) ? row[j0 + r16] : 0.0;
-    const double b1 = (zin && jb1) ? row[j0 + 16 + r16] : 0.0;
-    acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc00, 0, 0, 0);
-    acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc01, 0, 0, 0);
-    acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc10, 0, 0, 0);
-    acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc11, 0, 0, 0);
+  // eight k-steps (32 channels) per trip: the 32 loads are issued together -- a trip with one
+  // k-step waits a whole L2 round trip (~0.7 us) for four loads
+  for (int z = z0; z < z1; z += 32) {
+    double a0[8], a1[8], b0[8], b1[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int zz = z + 4 * s + kq;
+      const bool zin = zz < z1;
+      const double *row = X + (long)(zin ? zz : z0) * ld;
+      a0[s] = (zin && ia0) ? row[i0 + r16] : 0.0;
+      a1[s] = (zin && ia1) ? row[i0 + 16 + r16] : 0.0;
+      b0[s] = (zin && jb0) ? row[j0 + r16] : 0.0;
+      b1[s] = (zin && jb1) ? row[j0 + 16 + r16] : 0.0;
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[s], b0[s], acc00, 0, 0, 0);
+      acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[s], b1[s], acc01, 0, 0, 0);
+      acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[s], b0[s], acc10, 0, 0, 0);
+      acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[s], b1[s], acc11, 0, 0, 0);
+    }
   }
   double *G = slab + (long)ks * slab_stride + g_off[a];
 #pragma unroll
