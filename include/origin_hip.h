@@ -77,6 +77,29 @@ int origin_zmax_map(origin_ctx *ctx, const float *d_cube, const uint8_t *d_keep,
 int origin_count_above(origin_ctx *ctx, const float *d_cube, const uint8_t *d_keep, int Nz, long S,
                        int nthr, const double *h_thr, long *h_counts);
 
+/* ---- FITS data units ------------------------------------------------
+ * Step.dump / Step.load (steps.py:301-352) write and reload every cube / image of a step as a
+ * FITS image extension through mpdaf (Cube.write(convert_float32=False) -> float64; lazy
+ * reload in DataObj.__get__, steps.py:131-160).  A FITS data unit is the array in big-endian
+ * byte order, IEEE-754 for BITPIX < 0.  These two calls convert between a device array and
+ * the bytes of a data unit (widening / narrowing included), replacing the host-side dtype and
+ * byte-order pass of astropy.io.fits; origin_amd/fitsio.py writes the headers around them.
+ * element types: 0 = float32, 1 = uint8, 2 = int32, 3 = float64.
+ * bitpix: -64, -32, 8, 16, 32, 64.  d_dst of encode / d_src of decode: n * |bitpix| / 8 bytes,
+ * 8-byte aligned.  Asynchronous on the context's stream. */
+int origin_fits_encode(origin_ctx *ctx, const void *d_src, int src_type, long n, int bitpix,
+                       void *d_dst);
+int origin_fits_decode(origin_ctx *ctx, const void *d_src, int bitpix, long n, int dst_type,
+                       void *d_dst);
+/* The same conversions streamed to / from an open file descriptor at its current offset
+ * (sequential write() / read()): conversion, PCIe copy through two pinned buffers and file
+ * I/O overlap chunk by chunk.  The caller writes the header blocks and the padding of the
+ * data unit to a multiple of 2880 bytes.  Both return when the file / the device array is
+ * complete. */
+int origin_fits_write_data(origin_ctx *ctx, const void *d_src, int src_type, long n, int bitpix,
+                           int fd);
+int origin_fits_read_data(origin_ctx *ctx, int fd, int bitpix, long n, int dst_type, void *d_dst);
+
 /* ---- inter-GPU exchange (one process per GPU; RCCL over xGMI on the context's stream) ----
  * The reference has no multi-GPU path (its only parallelism is the joblib pool of
  * lib_origin.py:1150-1160); these serve the spatial tiling of origin_amd/multigpu.py.

@@ -255,3 +255,28 @@ if __name__ == "__main__":
     import sys
 
     dump_inputs(sys.argv[1])
+
+
+def g9_inputs():
+    """FITS dump / load: one array per file type the steps write, with the
+    special values a byte-level codec can get wrong, and the world-coordinate cards a MUSE
+    cube carries."""
+    rng = np.random.default_rng(99)
+    cube64 = rng.standard_normal((7, 5, 6)) * 1e3
+    cube64[0, 0, :6] = [np.nan, np.inf, -np.inf, -0.0, 5e-324, 1.7976931348623157e308]
+    cube64[1, 2, 3] = np.float64(np.float32(1.0) / np.float32(3.0))
+    cube32 = (rng.standard_normal((7, 5, 6)) * 50).astype(np.float32)
+    cube32[3, 1, :4] = [np.nan, np.inf, -0.0, 1e-45]
+    prof8 = rng.integers(0, 20, size=(7, 5, 6)).astype(np.uint8)
+    prof8[6, 4, 5] = 255
+    area64 = rng.integers(0, 37, size=(5, 6)).astype(np.int64)
+    area64[0, 0] = -3
+    img64 = rng.standard_normal((5, 6)) * 40
+    table = dict(Tval_r=np.linspace(3.0, 12.0, 9), Pval_r=np.linspace(0.2, 1.0, 9),
+                 Det_m=np.arange(9, dtype=np.int64) * 3, Det_M=np.arange(9, dtype=np.int64)[::-1] * 7 + 1)
+    wcs = dict(CRPIX1=3.5, CRPIX2=3.0, CRVAL1=53.16, CRVAL2=-27.78, CD1_1=-5.55555555555556e-05,
+               CD1_2=0.0, CD2_1=0.0, CD2_2=5.55555555555556e-05, CTYPE1='RA---TAN',
+               CTYPE2='DEC--TAN', CUNIT1='deg', CUNIT2='deg')
+    wave = dict(CRPIX3=1.0, CRVAL3=4750.0, CD3_3=1.25, CTYPE3='AWAV', CUNIT3='Angstrom')
+    return dict(cube64=cube64, cube32=cube32, prof8=prof8, area64=area64, img64=img64,
+                table=table, wcs=wcs, wave=wave)

@@ -18,6 +18,7 @@ copy is only made when somebody reads ``._data``.
 """
 import inspect
 import logging
+import os
 import time
 from collections import OrderedDict
 from datetime import datetime
@@ -27,7 +28,7 @@ import numpy as np
 from scipy import ndimage as ndi
 from scipy.signal import fftconvolve
 
-from . import kernels, pipeline
+from . import fitsio, kernels, pipeline
 from .device import DeviceArray, default_context
 from .thresholds import compute_thresh_gaussfit
 
@@ -65,7 +66,7 @@ class LazyCube:
 def _wrap(ctx, value, dtype=np.float32):
     """DeviceArray for anything cube-like a step may be handed (LazyCube, mpdaf object with
     ``_data``, ndarray)."""
-    if isinstance(value, LazyCube):
+    if isinstance(value, (LazyCube, fitsio.FitsCube)):
         return value.device(ctx, dtype)
     if isinstance(value, DeviceArray):
         return value
@@ -83,8 +84,10 @@ class Status(Enum):
 
 
 class DataObj:
-    """Descriptor naming a step output and its kind (reference steps.py:121-163); lazy
-    reload from disk is the reference's job and is not reproduced here."""
+    """Descriptor naming a step output and its kind, reloading it on demand once the step
+    has been dumped and the attribute holds the path of its file (reference
+    steps.py:121-163).  Cubes and images come back as ``fitsio.FitsCube`` (decoded by the
+    GPU when read), tables as a mapping of columns, arrays through ``np.loadtxt``."""
 
     def __init__(self, kind):
         self.kind = kind
@@ -92,7 +95,19 @@ class DataObj:
     def __get__(self, obj, owner=None):
         if obj is None:
             return
-        return obj.__dict__.get(self.label)
+        val = obj.__dict__.get(self.label)
+        if isinstance(val, str):
+            if os.path.isfile(val):
+                if self.kind in ('cube', 'image'):
+                    val = fitsio.FitsCube(val)
+                elif self.kind == 'table':
+                    val = fitsio.read_table(val)
+                elif self.kind == 'array':
+                    val = np.loadtxt(val, ndmin=1)
+                obj.__dict__[self.label] = val
+            else:
+                val = None
+        return val
 
     def __set__(self, obj, val):
         obj.__dict__[self.label] = val
@@ -181,6 +196,56 @@ class Step(metaclass=StepMeta):
 
     def store_image(self, name, data, **kwargs):
         setattr(self, name, data)
+
+    def dump(self, outpath):
+        """Save the outputs of a step that has been run and replace them by the paths of
+        their files (reference steps.py:301-340): ``<outpath>/<name>.fits`` for cubes, images
+        and tables, ``<name>.txt`` for arrays.  Cubes go from HBM to the file through the
+        device-side FITS encoder (fitsio.write_image), float64 on disk unless the reference
+        itself holds another type (``convert_float32=False``, steps.py:319)."""
+        if self.status is not Status.RUN:
+            return
+        ctx = getattr(self.orig, 'hip_ctx', None)
+        for name, kind in self._dataobjs:
+            obj = getattr(self, name)
+            if obj is None:
+                continue
+            ext = 'txt' if kind == 'array' else 'fits'
+            outf = f'{outpath}/{name}.{ext}'
+            self.logger.debug('   - %s [%s]', name, kind)
+            if kind in ('cube', 'image'):
+                fitsio.write_image(outf, obj, ctx=ctx, header=self._wcs_cards(kind))
+            elif kind == 'table':
+                if hasattr(obj, 'write'):  # astropy Table
+                    obj.write(outf, overwrite=True)
+                else:
+                    fitsio.write_table(outf, OrderedDict(
+                        (c, obj[c]) for c in getattr(obj, 'colnames', obj)))
+            elif kind == 'array':
+                np.savetxt(outf, obj)
+            # the attribute becomes the path of its file: the data (and its copy in HBM) is
+            # released and comes back from the file when the attribute is read again
+            setattr(self, name, outf)
+            _cache(self.orig).pop(name, None)
+        self.status = Status.DUMPED
+
+    def load(self, outpath):
+        """Point the outputs of a dumped step at their files; they are read when accessed
+        (reference steps.py:342-352)."""
+        if self.status is not Status.DUMPED:
+            return
+        for name, kind in self._dataobjs:
+            ext = 'txt' if kind == 'array' else 'fits'
+            setattr(self, name, f'{outpath}/{name}.{ext}')
+
+    def _wcs_cards(self, kind):
+        """World-coordinate cards of the session (``orig.wcs_header`` / ``orig.wave_header``:
+        plain mappings of FITS keywords when given), as mpdaf adds to the DATA extension."""
+        cards = OrderedDict()
+        cards.update(getattr(self.orig, 'wcs_header', None) or {})
+        if kind == 'cube':
+            cards.update(getattr(self.orig, 'wave_header', None) or {})
+        return cards
 
 
 # ----------------------------------------------------------------------------- helpers
