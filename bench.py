@@ -298,6 +298,23 @@ def main():
                         unit=unit, frac=round(ach / peak, 4), traffic=traffic,
                         avg_launch_ms=round(tot_ms / launches, 4), launches=launches, **extra)
 
+    # ---- whole path against the HBM roofline (the second half of BASELINE.json's metric):
+    # SURVEY 8(d) algorithmic bytes per voxel, A = 17 (DCT + standardise), C = 14 (GLR),
+    # B = 4 (n_iter + 2) for the voxels of an area that ran n_iter greedy-PCA iterations
+    path_hbm = None
+    it_mean = info.get("area_iters_mean")
+    if comm is not None:  # areas are spread over the ranks: mean over all of them
+        tot = comm.allreduce_sum(np.array([(it_mean or 0.0) * len(spx), float(len(spx))]))
+        it_mean = float(tot[0] / max(tot[1], 1.0))
+    if rank == 0 and it_mean is not None:
+        bpv = 17.0 + 14.0 + 4.0 * (it_mean + 2.0)
+        gbs = bpv * Nz * N * N / (ms_per_step * 1e-3) / 1e9
+        path_hbm = dict(bytes_per_voxel=round(bpv, 2), achieved=round(gbs, 1),
+                        peak=HBM_PEAK_GBS * world, unit="GB/s",
+                        frac=round(gbs / (HBM_PEAK_GBS * world), 4),
+                        note="algorithmic bytes of DCT+standardise, greedy PCA and GLR over the "
+                             "step time; the GLR stages are MFMA-bound (see roofline)")
+
     # ---- CPU baseline: the oracle on a centred crop, all host cores, rank 0, N == 1 ----
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -340,6 +357,7 @@ def main():
                        if comm is not None else None, "pca": info,
                        "gen_seconds": round(t_gen, 1)},
             "roofline": roofline,
+            "path_hbm": path_hbm,
             "cpu_baseline": cpu_baseline,
             "wall_ms_per_step_by_phase": {k: round(1e3 * v / max(1, args.steps), 2)
                                           for k, v in phase.items()},
