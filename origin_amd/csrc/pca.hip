@@ -1038,11 +1038,11 @@ __device__ void lanczos_small_wave(const double *__restrict__ Gk, int n, int ld,
                                    const double *__restrict__ slab = nullptr, long slab_stride = 0,
                                    int ksplit = 0) {
   // The caller has zeroed the whole work area: rows / columns beyond n are zeros, so every loop
-  // below runs in unrolled batches of 8 (4) with all LDS reads of a batch independent -- a loop
+  // below runs in unrolled batches of 16 with all LDS reads of a batch independent -- a loop
   // with a run-time trip count and one dependent read per iteration costs an LDS latency per
-  // element.  The extra terms are exact zeros (same sums, same order).
+  // element, and so does every batch.  The extra terms are exact zeros (same sums, same order).
   const bool own = lane < n;
-  const int nr = (n + 7) & ~7;
+  const int nr = (n + 15) & ~15;  // <= LANCZOS_M = 48
   if (!slab) {  // (with slabs the caller has filled sw.G: see lanczos_kernel)
     for (int c0 = 0; c0 < nr; c0 += 8) {
       double g[8];
@@ -1054,12 +1054,12 @@ __device__ void lanczos_small_wave(const double *__restrict__ Gk, int n, int ld,
   }
   // start vector G * ones
   double y = 0.0;
-  for (int c0 = 0; c0 < nr; c0 += 8) {
-    double g[8];
+  for (int c0 = 0; c0 < nr; c0 += 16) {
+    double g[16];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) g[e] = sw.G[c0 + e][lane];
+    for (int e = 0; e < 16; ++e) g[e] = sw.G[c0 + e][lane];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) y += g[e];
+    for (int e = 0; e < 16; ++e) y += g[e];
   }
   double nrm = sqrt(wave_sum_d(own ? y * y : 0.0));
   if (own) sw.Q[0][lane] = nrm > 0.0 ? y / nrm : (lane == 0 ? 1.0 : 0.0);
@@ -1067,36 +1067,36 @@ __device__ void lanczos_small_wave(const double *__restrict__ Gk, int n, int ld,
   double beta_last = 0.0;
   for (int j = 0; j < n; ++j) {
     double w = 0.0;  // w_l = sum_c G[c][l] q_j[c]   (G symmetric)
-    for (int c0 = 0; c0 < nr; c0 += 8) {
-      double g[8], q[8];
+    for (int c0 = 0; c0 < nr; c0 += 16) {
+      double g[16], q[16];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) g[e] = sw.G[c0 + e][lane], q[e] = sw.Q[j][c0 + e];
+      for (int e = 0; e < 16; ++e) g[e] = sw.G[c0 + e][lane], q[e] = sw.Q[j][c0 + e];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) w = fma(g[e], q[e], w);
+      for (int e = 0; e < 16; ++e) w = fma(g[e], q[e], w);
     }
     double aj = 0.0;
-    const int jr = (j + 4) & ~3;  // j + 1 rounded up to 4 (h[i] = 0 for i > j)
+    const int jr = (j + 16) & ~15;  // j + 1 rounded up to 16 (h[i] = 0, Q[i] = 0 for i > j)
     for (int pass = 0; pass < 2; ++pass) {
       if (own) sw.w[lane] = w;
       // lane i <= j: h_i = q_i . w
       double hi = 0.0;
       if (lane <= j) {
-        for (int e0 = 0; e0 < nr; e0 += 8) {
-          double a[8], b[8];
+        for (int e0 = 0; e0 < nr; e0 += 16) {
+          double a[16], b[16];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) a[e] = sw.Q[lane][e0 + e], b[e] = sw.w[e0 + e];
+          for (int e = 0; e < 16; ++e) a[e] = sw.Q[lane][e0 + e], b[e] = sw.w[e0 + e];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) hi = fma(a[e], b[e], hi);
+          for (int e = 0; e < 16; ++e) hi = fma(a[e], b[e], hi);
         }
         sw.h[lane] = hi;
       }
       aj += sw.h[j];
-      for (int i0 = 0; i0 < jr; i0 += 4) {
-        double a[4], b[4];
+      for (int i0 = 0; i0 < jr; i0 += 16) {
+        double a[16], b[16];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) a[e] = sw.h[i0 + e], b[e] = sw.Q[i0 + e][lane];
+        for (int e = 0; e < 16; ++e) a[e] = sw.h[i0 + e], b[e] = sw.Q[i0 + e][lane];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) w = fma(-a[e], b[e], w);
+        for (int e = 0; e < 16; ++e) w = fma(-a[e], b[e], w);
       }
     }
     const double bj = sqrt(wave_sum_d(own ? w * w : 0.0));

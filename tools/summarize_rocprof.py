@@ -23,11 +23,11 @@ def short(name):
 
 def main():
     kt, fetch, write, out = sys.argv[1:5]
-    stats = glob.glob(kt + "/*/*kernel_stats.csv")[0]
+    stats = (glob.glob(kt + "/*/*kernel_stats.csv") + glob.glob(kt + "/*kernel_stats.csv"))[0]
     shutil.copy(stats, out + "_kernel_stats.csv")
     res = {}
     for d in (fetch, write):
-        f = glob.glob(d + "/*/*counter_collection.csv")[0]
+        f = (glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"))[0]
         agg = collections.defaultdict(lambda: [0.0, 0])
         for r in csv.DictReader(open(f)):
             key = (short(r["Kernel_Name"]), r["Counter_Name"])
