@@ -74,6 +74,7 @@ enum {
   DF_FBOLD,  // offset of this area's nuisance block of the previous iteration (-1: none)
   DF_LDOLD,  // its row stride
   DF_NOLD,   // its number of columns
+  DF_SVALID,  // 1: the running column sum of the area's background set is usable (bmean_kernel)
   DF_COUNT
 };
 constexpr int PCA_CAP = 64;  // vectors kept per area before the cube is flushed (F = X - U C)
@@ -317,8 +318,10 @@ __device__ __forceinline__ void pca_select_fast_body(
     const double *__restrict__ thr_, double noise_pop, int itermax, int *__restrict__ active,
     int *__restrict__ nbiter, int *__restrict__ nstop, int *__restrict__ mapO2,
     int *__restrict__ nuis, int *__restrict__ bg, int *__restrict__ nuis_pos,
-    int *__restrict__ bg_pos, int *__restrict__ n_out, int *__restrict__ nb_out) {
+    int *__restrict__ bg_pos, int *__restrict__ n_out, int *__restrict__ nb_out,
+    uint8_t *__restrict__ inB, int *__restrict__ dlist, int *__restrict__ ndiff) {
   __shared__ unsigned long long wsum[16], wmax[16];
+  __shared__ unsigned bmap[1024 * SEL_EPT / 32];  // list positions emitted as background
   __shared__ int hist[256];
   __shared__ unsigned long long s_prefix;
   __shared__ int s_remaining, s_it, s_done;
@@ -344,6 +347,16 @@ __device__ __forceinline__ void pca_select_fast_body(
 #pragma unroll
   for (int e = 0; e < SEL_EPT; ++e)
     if (sp[e] >= 0) scache[i0 + e] = sp[e];
+  // membership of the previous iteration's background set (see the end of this function)
+  unsigned oldmask = 0;
+  if (inB) {
+    uint8_t ob[SEL_EPT];
+#pragma unroll
+    for (int e = 0; e < SEL_EPT; ++e) ob[e] = sp[e] >= 0 ? inB[o0 + i0 + e] : (uint8_t)0;
+#pragma unroll
+    for (int e = 0; e < SEL_EPT; ++e) oldmask |= (unsigned)(ob[e] != 0) << e;
+    for (int i = tid; i < 1024 * SEL_EPT / 32; i += 1024) bmap[i] = 0u;
+  }
 
   // ---- counts: nuisance (t > thr), candidates (0 < t <= thr), positive (t > 0)
   unsigned long long cnt = 0;  // [nuis | cand | pos] x 20 bits
@@ -507,12 +520,35 @@ __device__ __forceinline__ void pca_select_fast_body(
         if (emit) {
           bg[o0 + emit_before] = scache[rp];
           bg_pos[o0 + emit_before] = (int)(o0 + rp);
+          if (inB) atomicOr(&bmap[rp >> 5], 1u << (rp & 31));
           ++emit_before;
         }
         eq_before += eq;
       }
       ++rp;
     }
+  }
+  if (inB) {
+    // The background set changes by a few columns per iteration (the O2 tests move slowly), so
+    // its mean is updated from the columns that entered or left it instead of re-gathered
+    // (bmean_kernel).  Here: the changes of membership in list order -- +(spaxel+1) entered,
+    // -(spaxel+1) left -- and the new membership flags.
+    __syncthreads();  // bmap complete
+    unsigned newmask = 0;
+#pragma unroll
+    for (int e = 0; e < SEL_EPT; ++e)
+      if (sp[e] >= 0) newmask |= ((bmap[(i0 + e) >> 5] >> ((i0 + e) & 31)) & 1u) << e;
+    const unsigned diff = newmask ^ oldmask;
+    unsigned long long tot3;
+    int r = (int)block_scan_u64((unsigned long long)__popc(diff), wsum, tot3);
+#pragma unroll
+    for (int e = 0; e < SEL_EPT; ++e)
+      if ((diff >> e) & 1u) {
+        const bool in = (newmask >> e) & 1u;
+        dlist[o0 + r++] = in ? sp[e] + 1 : -(sp[e] + 1);
+        inB[o0 + i0 + e] = (uint8_t)in;
+      }
+    if (tid == 0) ndiff[a] = (int)tot3;
   }
   if (tid == 0) {
     nb_out[a] = nb;
@@ -560,9 +596,10 @@ __global__ __launch_bounds__(1024) void pca_select_fast_kernel(
     int *__restrict__ nbiter, int *__restrict__ nstop, int *__restrict__ mapO2,
     int *__restrict__ nuis, int *__restrict__ bg, int *__restrict__ nuis_pos,
     int *__restrict__ bg_pos, int *__restrict__ n_out, int *__restrict__ nb_out, int *host_out,
-    unsigned *counter, int gen) {
+    unsigned *counter, int gen, uint8_t *__restrict__ inB, int *__restrict__ dlist,
+    int *__restrict__ ndiff) {
   pca_select_fast_body(spx, spx_off, test, thr_, noise_pop, itermax, active, nbiter, nstop, mapO2,
-                       nuis, bg, nuis_pos, bg_pos, n_out, nb_out);
+                       nuis, bg, nuis_pos, bg_pos, n_out, nb_out, inB, dlist, ndiff);
   select_publish(blockIdx.x, gridDim.x, n_out, nb_out, host_out, counter, gen);
 }
 
@@ -600,27 +637,47 @@ __global__ __launch_bounds__(1024) void cbar_kernel(const double *__restrict__ C
 // ------------------------------------------------------------------------------------
 // b_k[z] = mean_{i in bg_k} F_t[z, bg_i] = mean_i X[z, bg_i] - sum_q U[z][q] cbar[q]
 // grid (ceil(Nz/4), nw), block (64,4).  U layout: [area][z][PCA_CAP].
+// A background column is a scattered gather (a 64-byte sector per sample), and the set moves by
+// a few columns per iteration: with Ssum (float64 [area][Nz], the sum over the set as the
+// previous iteration left it) and DF_SVALID the sum is updated from the columns that entered /
+// left (dlist, signed, in list order: a fixed summation order) instead of re-gathered.
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bmean_kernel(const float *__restrict__ X, int Nz, long S,
                                                     const int *__restrict__ bg,
                                                     const long *__restrict__ D, int nw,
                                                     const double *__restrict__ U,
                                                     const double *__restrict__ cbar,
-                                                    double *__restrict__ b) {
+                                                    double *__restrict__ b,
+                                                    const int *__restrict__ dlist,
+                                                    const int *__restrict__ ndiff,
+                                                    double *__restrict__ Ssum) {
   const int k = blockIdx.y;
   const int z = blockIdx.x * 4 + threadIdx.y;
   if (z >= Nz) return;
   const long o0 = DSC(DF_LIST0, k);
   const int nb = (int)DSC(DF_NB, k), T = (int)DSC(DF_T, k);
+  const int a = (int)DSC(DF_AREA, k);
   const float *row = X + (long)z * S;
+  double part = 0.0;
+  const bool delta = Ssum && DSC(DF_SVALID, k);
+  if (delta) {
+    const int nd = ndiff[a];
+    for (int i = threadIdx.x; i < nd; i += 64) {
+      const int e = dlist[o0 + i];
+      const double v = (double)row[(e > 0 ? e : -e) - 1];
+      part += e > 0 ? v : -v;
+    }
+  } else {
+    for (int i = threadIdx.x; i < nb; i += 64) part += (double)row[bg[o0 + i]];
+  }
+  double tot = wave_sum_d(part);
+  if (delta) tot += Ssum[(long)a * Nz + z];
+  if (Ssum && threadIdx.x == 0) Ssum[(long)a * Nz + z] = tot;
   double acc = 0.0;
-  for (int i = threadIdx.x; i < nb; i += 64) acc += (double)row[bg[o0 + i]];
-  acc /= (double)nb;
   if ((int)threadIdx.x < T)  // T <= PCA_CAP == 64 lanes
-    acc -= U[((long)DSC(DF_AREA, k) * Nz + z) * PCA_CAP + threadIdx.x] *
-           cbar[(long)k * PCA_CAP + threadIdx.x];
+    acc = U[((long)a * Nz + z) * PCA_CAP + threadIdx.x] * cbar[(long)k * PCA_CAP + threadIdx.x];
   acc = wave_sum_d(acc);
-  if (threadIdx.x == 0) b[(long)k * Nz + z] = acc;
+  if (threadIdx.x == 0) b[(long)k * Nz + z] = tot / (double)nb - acc;
 }
 
 // ------------------------------------------------------------------------------------
@@ -1566,7 +1623,7 @@ struct DevBuf {
 };
 
 struct PcaWorkspace {
-  DevBuf b[18];
+  DevBuf b[19];
 };
 
 // launches lanczos_kernel with the basis in LDS when the largest matrix allows it
@@ -1735,6 +1792,20 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
   int *d_npos[2] = {d_bg_pos + ntot, d_bg_pos + 2 * ntot};  // nuisance positions, ping-pong
   // nuisance block of each area as the previous iteration left it (host bookkeeping)
   std::vector<long> fb_off(na, -1), fb_ld(na, 0), fb_n(na, 0);
+  // running sum of the background columns of each area (bmean_kernel): float64 [na][Nz], then
+  // the signed list of columns that entered / left the set [ntot], their number per area [na]
+  // and the membership flag of every list position [ntot].  Only the register-resident
+  // selection kernel keeps them up to date.
+  const bool bg_delta = getenv("ORIGIN_PCA_FULL_BMEAN") == nullptr;
+  if ((rc = W.b[18].reserve(ctx, (size_t)na * Nz * sizeof(double) +
+                                     (size_t)(ntot + na) * sizeof(int) + (size_t)ntot)))
+    return rc;
+  double *d_ssum = (double *)W.b[18].p;
+  int *d_dlist = (int *)(d_ssum + (size_t)na * Nz);
+  int *d_ndiff = d_dlist + ntot;
+  uint8_t *d_inb = (uint8_t *)(d_ndiff + na);
+  ORIGIN_HIP(hipMemsetAsync(d_inb, 0, (size_t)ntot, st));
+  std::vector<char> s_valid(na, 0);
   if ((rc = b_test.reserve(ctx, (size_t)S * sizeof(double)))) return rc;
   double *d_test = (double *)b_test.p;
   ORIGIN_HIP(hipMemcpyAsync(d_test, d_test0, (size_t)S * sizeof(double), hipMemcpyDeviceToDevice,
@@ -1791,6 +1862,7 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
     }
     for (int a = 0; a < na; ++a) T[a] = 0;
     std::fill(fb_off.begin(), fb_off.end(), -1L);  // (blocks refer to columns of U)
+    std::fill(s_valid.begin(), s_valid.end(), (char)0);  // (sums refer to the cube read so far)
     src = d_F;
     return ORIGIN_OK;
   };
@@ -1820,6 +1892,7 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
   std::vector<long> D;
   int iters = 0;
   int gen = 1;  // selections launched so far + 1
+  const bool use_delta = bg_delta && nsmax_all <= 1024 * SEL_EPT;
   for (;;) {
     {
       ProfScope ps(ctx, K_PCA_SELECT, 2);
@@ -1827,7 +1900,8 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
         hipLaunchKernelGGL(pca_select_fast_kernel, dim3(na), dim3(1024),
                            (size_t)nsmax_all * sizeof(int), st, d_spx, d_spx_off, d_test, d_thr,
                            noise_pop, itermax, d_active, d_nbiter, d_nstop, d_mapO2, d_nuis, d_bg,
-                           d_npos[iters & 1], d_bg_pos, d_n, d_nb, d_hostout, d_selcnt, gen);
+                           d_npos[iters & 1], d_bg_pos, d_n, d_nb, d_hostout, d_selcnt, gen,
+                           use_delta ? d_inb : nullptr, d_dlist, d_ndiff);
       else
         hipLaunchKernelGGL(pca_select_kernel, dim3(na), dim3(1024), sel_lds, st, d_spx, d_spx_off,
                            d_test, d_thr, noise_pop, itermax, d_active, d_nbiter, d_nstop, d_mapO2,
@@ -1892,6 +1966,8 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
       D[(size_t)DF_FBOLD * nw + k] = have ? fb_off[a] : -1;
       D[(size_t)DF_LDOLD * nw + k] = fb_ld[a];
       D[(size_t)DF_NOLD * nw + k] = fb_n[a];
+      D[(size_t)DF_SVALID * nw + k] = use_delta && s_valid[a];
+      s_valid[a] = use_delta;  // this iteration's bmean_kernel leaves the sum behind
       xp += (long)Nz * ld;
       c += ld;
       g += (long)ld * ld;
@@ -1954,7 +2030,7 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
       hipLaunchKernelGGL(cbar_kernel, dim3(nw), dim3(1024), 0, st, d_C, ntot, d_bg_pos, dD, nw,
                          d_cbar);
       hipLaunchKernelGGL(bmean_kernel, dim3(cdiv(Nz, 4), nw), dim3(64, 4), 0, st, src, Nz, S, d_bg,
-                         dD, nw, d_U, d_cbar, d_b);
+                         dD, nw, d_U, d_cbar, d_b, d_dlist, d_ndiff, use_delta ? d_ssum : nullptr);
     }
     // z slices of the gather: enough blocks to fill the chip even when few areas iterate
     int nzb = (int)(((long)ctx->num_cu * 2 + (long)cdiv(ldmax, 64) * nw - 1) /
