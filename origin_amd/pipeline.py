@@ -73,6 +73,8 @@ def greedy_pca(ctx, cube_std, areamap, nbAreas, thresholds, testO2, Noise_popula
     # cube_faint = cube_std.copy() (:799): the copy is folded into the final F = X - U C pass
     F = cube_std if inplace else (out if out is not None else ctx.empty(cube_std.shape,
                                                                         np.float32))
+    if not inplace and sum(len(s) for s in spx) < Ny * Nx:
+        F.copy_from(cube_std)  # spaxels outside every area keep their cube_std values (:799)
     drv = driver or GreedyPCA(ctx)
     maps, nstop = drv.run(F, spx, testO2, [float(t) for t in thresholds], Noise_population,
                           itermax, test_map=o2_dev, src=None if inplace else cube_std)
