@@ -192,3 +192,22 @@ def test_local_max_small_and_ragged_shapes(hip, shape, size):
     got = hip.compute_local_max(correl, cmin, mask, size)
     ref = cpu_ref.compute_local_max(correl, cmin, mask, size)
     assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+
+
+def test_out_of_place_pca_keeps_unassigned_spaxels(ctx):
+    """cube_faint starts as a copy of cube_std (reference lib_origin.py:799): spaxels with
+    areamap == 0 must come out unchanged when the device path writes into a fresh buffer."""
+    from origin_amd import pipeline
+    rng = np.random.default_rng(12)
+    cube = rng.standard_normal((90, 10, 12)).astype(np.float32)
+    cube[:, 4, 4] *= 6
+    areamap = np.ones((10, 12), int)
+    areamap[:2, :] = 0
+    test = cpu_ref.O2test(cube.astype(float)[:, areamap == 1])
+    d = ctx.to_device(cube)
+    F, mapO2, nstop, _ = pipeline.greedy_pca(ctx, d, areamap, 1, [1.5], [test], 50, 100)
+    got = F.to_host()
+    assert np.array_equal(got[:, :2, :], cube[:, :2, :])
+    ref = cpu_ref.Compute_GreedyPCA_area(1, cube.astype(float), areamap, 50, [1.5], 100, [test],
+                                         svd="dense")
+    assert np.max(np.abs(got - ref[0])) <= 1e-4 and np.array_equal(mapO2, ref[1])
