@@ -137,6 +137,22 @@ class TileComm:
         torch, dist = self.torch, self.dist
         ident = torch.zeros(_capi.COMM_ID_BYTES + 1, dtype=torch.uint8)
         err = ""
+        # ncclCommInitRank is collective: a rank that cannot even load librccl would leave the
+        # others waiting inside it.  Every rank first proves it can reach the library (a
+        # throw-away unique id); only if all can is the communicator created.
+        probe = 1
+        try:
+            _capi.call("origin_comm_unique_id", C.create_string_buffer(_capi.COMM_ID_BYTES))
+        except Exception as exc:  # noqa: BLE001 -- reported through `note`
+            probe, err = 0, str(exc)
+        pflag = torch.tensor([probe], dtype=torch.int32)
+        dist.all_reduce(pflag, op=dist.ReduceOp.MIN)
+        if int(pflag[0]) != 1:
+            self._want_rccl = False
+            self.backend = "gloo"
+            self.note = "rccl unavailable (" + (err or "failed on another rank") + \
+                        "); host staging over gloo"
+            return
         if self.rank == 0:
             buf = C.create_string_buffer(_capi.COMM_ID_BYTES)
             try:
