@@ -328,8 +328,61 @@ def gen_g8():
     save("g8_purity", sha=np.array(gc.digest(inp["lmax"], inp["lmin"], inp["segmap"])), **out)
 
 
+def gen_g10():
+    """Area construction: the reference's functions chained exactly as CreateAreas.run does
+    (steps.py:530-563), with the stages kept so that a mismatch can be located."""
+    inp = INPUTS["g10"]
+    out = {}
+    for name, c in inp.items():
+        mask, segmap = np.asarray(c["mask"], dtype=bool), np.asarray(c["segmap"])
+        minsize = int(c["minsize"])
+        maxsize = None if c["maxsize"] is None else int(c["maxsize"])
+        Ny, Nx = segmap.shape
+        nexpmap = (np.sum(~mask, axis=0) > 0).astype(int)
+        NbSubcube = np.maximum(1, int(np.sqrt(np.sum(nexpmap) / (minsize ** 2))))
+        assert NbSubcube > 1
+        if maxsize is None:
+            maxsize = minsize * 2
+        MinSize, MaxSize = minsize ** 2, maxsize ** 2
+        sq = ref.area_segmentation_square_fusion(nexpmap, MinSize, MaxSize, NbSubcube, Ny, Nx)
+        sq_sizes = sq.sum(axis=(1, 2))
+        ws, src = ref.area_segmentation_sources_fusion(segmap, sq.copy(), float(c["pfa"]), Ny, Nx)
+        hull = ref.area_segmentation_convex_fusion(ws, src)
+        grown = ref.area_growing(hull, nexpmap)
+        # (area_segmentation_final merges in place: give it a copy, keep the grown planes)
+        areamap = ref.area_segmentation_final(grown.copy(), MinSize, MaxSize).astype(int)
+        labels = np.unique(areamap)
+        nb = len(labels) - (1 if 0 in labels else 0)
+        planes = lambda st: (np.arange(1, len(st) + 1)[:, None, None] * (st > 0)).sum(axis=0)
+        out.update({f"{name}_squares": planes(sq).astype(np.int16), f"{name}_square_sizes": sq_sizes,
+                    f"{name}_with_src": planes(ws).astype(np.int16), f"{name}_src": src,
+                    f"{name}_hulls": planes(hull).astype(np.int16),
+                    f"{name}_grown": planes(grown).astype(np.int16),
+                    f"{name}_areamap": areamap.astype(np.int16), f"{name}_nbareas": np.array(nb),
+                    f"{name}_nsub": np.array(NbSubcube)})
+        line = (f"G10        {name}: {NbSubcube}^2 squares -> {len(sq)} -> hulls {len(hull)} -> "
+                f"{nb} areas, sizes {sorted(int(x) for x in np.bincount(areamap.ravel())[1:])}")
+        print(line)
+        REPORT.append(line)
+    # isolated pieces: both merge criteria of fusion_areas, one hull
+    rng = np.random.default_rng(3)
+    lab = np.zeros((5, 40, 44))
+    lab[0, :12, :20] = 1
+    lab[1, :12, 20:] = 1
+    lab[2, 12:, :9] = 1
+    lab[3, 12:30, 9:] = 1
+    lab[4, 30:, 9:] = 1
+    out["fusion_min"] = ref.fusion_areas(lab.copy(), 300, 900).sum(axis=(1, 2))
+    out["fusion_var"] = ref.fusion_areas(lab.copy(), 300, 900, option='var').sum(axis=(1, 2))
+    pts = np.unique(rng.integers(0, 30, size=(25, 2)), axis=0)
+    pts = pts - pts.min(axis=0)
+    out["hull_points"] = pts
+    out["hull_filled"] = np.asarray(ref.Convexline(pts.copy(), 0, 0)).astype(np.uint8)
+    save("g10_areas", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["dico", "g1", "g3", "g4", "g5", "g7", "g8"]
+    which = sys.argv[1:] or ["dico", "g1", "g3", "g4", "g5", "g7", "g8", "g10"]
     if "dico" in which:
         check_dictionary()
     if "g1" in which:
@@ -344,6 +397,8 @@ if __name__ == "__main__":
         gen_g7()
     if "g8" in which:
         gen_g8()
+    if "g10" in which:
+        gen_g10()
     if not sys.argv[1:]:
         with open(os.path.join(HERE, "PINNING_REPORT.txt"), "w") as f:
             f.write("oracle/cpu_ref.py vs the reference's lib_origin.py (imported unmodified), "

@@ -200,6 +200,48 @@ def g8_inputs():
                 threshlist=np.array([9.5, 4.0, 6.25, 5.0, 7.75, 3.0, 12.0]))
 
 
+def g10_inputs():
+    """Area construction: exposure map with a ragged unexposed border and a hole,
+    merged segmentation map with compact sources (each with >= 3 non-collinear pixels, what
+    ConvexHull needs), sized so that the 3 x 3 grid of squares needs merging and growing.
+    Two cases: sources in most squares / few sources (areas without one are dropped and the
+    others grow over them)."""
+    rng = np.random.default_rng(1010)
+    Ny, Nx = 132, 150
+    yy, xx = np.mgrid[:Ny, :Nx]
+
+    def field(nsrc, seed):
+        r = np.random.default_rng(seed)
+        exp = np.ones((Ny, Nx), dtype=bool)
+        exp[:3 + (xx[0] % 7 == 0).astype(int).max(), :] = False
+        exp[:, :4] = False
+        exp[-5:, :] = False
+        exp[(yy > 118) & (xx > 120 + (yy - 118) * 2)] = False      # ragged corner
+        exp[(yy - 70) ** 2 + (xx - 95) ** 2 < 36] = False          # hole
+        seg = np.zeros((Ny, Nx), dtype=np.int32)
+        k = 0
+        while k < nsrc:
+            cy, cx = r.integers(8, Ny - 10), r.integers(8, Nx - 8)
+            ry, rx = r.integers(2, 6), r.integers(2, 7)
+            blob = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0
+            if (seg[blob] > 0).any() or not exp[blob].all() or blob.sum() < 6:
+                continue
+            k += 1
+            seg[blob] = k
+        return exp, seg
+
+    e1, s1 = field(14, 5)
+    e2, s2 = field(4, 6)
+    del rng
+    # cube masks (True = masked): a few channels, exposure = any unmasked channel
+    m1 = np.broadcast_to(~e1, (3, Ny, Nx)).copy()
+    m2 = np.broadcast_to(~e2, (3, Ny, Nx)).copy()
+    m1[1] = False                      # channel 1 fully valid except ...
+    m1[1][~e1] = True
+    return dict(many=dict(mask=m1, segmap=s1, minsize=40, maxsize=None, pfa=0.2),
+                few=dict(mask=m2, segmap=s2, minsize=45, maxsize=70, pfa=0.2))
+
+
 def _flatten(prefix, obj, out):
     if isinstance(obj, dict):
         for k, v in obj.items():
@@ -237,7 +279,7 @@ def _unflatten(flat):
 
 def all_inputs():
     return dict(g1=g1_inputs(), g3=g3_inputs(), g4=g4_inputs(), g5=g5_inputs(), g7=g7_inputs(),
-                g8=g8_inputs())
+                g8=g8_inputs(), g10=g10_inputs())
 
 
 def dump_inputs(path):

@@ -32,7 +32,7 @@ from . import fitsio, kernels, pipeline
 from .device import DeviceArray, default_context
 from .thresholds import compute_thresh_gaussfit
 
-__all__ = ('Preprocessing', 'ComputePCAThreshold', 'ComputeGreedyPCA', 'ComputeTGLR',
+__all__ = ('Preprocessing', 'CreateAreas', 'ComputePCAThreshold', 'ComputeGreedyPCA', 'ComputeTGLR',
            'Status', 'Step', 'DataObj', 'SimpleOrig', 'STEPS', 'register')
 
 
@@ -356,6 +356,34 @@ class _PreprocessingRun(_HipStepMixin):
         self.store_image('segmap_merged', segmap)
 
 
+class _CreateAreasRun:
+    """CreateAreas.run (reference steps.py:492-569): host geometry, origin_amd/areas.py."""
+    name = 'areas'
+    desc = 'Areas creation'
+
+    def run(self, orig, pfa=0.2, minsize=100, maxsize=None):
+        from .areas import create_areamap
+        mask = np.asarray(getattr(orig.mask, '_data', orig.mask), dtype=bool)
+        nexp = int(np.sum(mask.shape[0] - mask.sum(axis=0) > 0))
+        nsub = np.maximum(1, int(np.sqrt(nexp / (minsize ** 2))))
+        if nsub > 1:
+            self._loginfo('First segmentation of %d^2 square', nsub)
+        areamap, nbAreas = create_areamap(mask, _data(orig.segmap_merged), pfa, minsize, maxsize)
+        orig.param['nbareas'] = nbAreas
+        self.store_image('areamap', areamap)
+        self._loginfo('Save the map of areas in self.areamap')
+        self._loginfo('%d areas generated', nbAreas)
+
+    def set_areamap(self, areamap):
+        """Use an area map made elsewhere (a regular grid in the benchmarks, a map loaded from a
+        previous session) instead of running the step: same outputs and status as ``run``."""
+        areamap = np.asarray(getattr(areamap, '_data', areamap)).astype(int)
+        labels = np.unique(areamap)
+        self.orig.param['nbareas'] = len(labels) - (1 if 0 in labels else 0)
+        self.store_image('areamap', areamap)
+        self.status = Status.RUN
+
+
 class _ComputePCAThresholdRun(_HipStepMixin):
     name = 'compute_PCA_threshold'
     desc = 'PCA threshold computation'
@@ -484,21 +512,11 @@ class Preprocessing(_PreprocessingRun, Step):
     cube_std_local_max = DataObj('cube')
 
 
-class Areas(Step):
-    """Stand-in for ``CreateAreas`` (reference steps.py:492-569, out of scope): takes the
-    area map it is given."""
-    name = 'areas'
-    desc = 'Areas creation'
+class CreateAreas(_CreateAreasRun, Step):
     areamap = DataObj('image')
 
-    def run(self, orig, areamap=None, nbAreas=None):
-        if areamap is None:
-            areamap = (np.sum(~np.asarray(orig.mask, dtype=bool), axis=0) > 0).astype(int)
-        areamap = np.asarray(areamap).astype(int)
-        labels = np.unique(areamap)
-        nb = len(labels) - 1 if 0 in labels else len(labels)
-        orig.param['nbareas'] = nb if nbAreas is None else nbAreas
-        self.store_image('areamap', LazyCube(host=areamap, dtype=int))
+
+Areas = CreateAreas  # earlier name of the stand-alone step
 
 
 class ComputePCAThreshold(_ComputePCAThresholdRun, Step):
@@ -529,7 +547,7 @@ class ComputePurityThreshold(_ComputePurityThresholdRun, Step):
     segmap_purity = DataObj('image')
 
 
-STEPS = [Preprocessing, Areas, ComputePCAThreshold, ComputeGreedyPCA, ComputeTGLR,
+STEPS = [Preprocessing, CreateAreas, ComputePCAThreshold, ComputeGreedyPCA, ComputeTGLR,
          ComputePurityThreshold]
 
 
@@ -576,6 +594,7 @@ def register():
 
     replaced = []
     for mixin, refname in ((_PreprocessingRun, 'Preprocessing'),
+                           (_CreateAreasRun, 'CreateAreas'),
                            (_ComputePCAThresholdRun, 'ComputePCAThreshold'),
                            (_ComputeGreedyPCARun, 'ComputeGreedyPCA'),
                            (_ComputeTGLRRun, 'ComputeTGLR'),

@@ -256,7 +256,7 @@ def test_step_dump_load_and_resume(ctx, tmp_path):
         out = str(tmp_path / ("dumped" if dump else "plain"))
         os.makedirs(out, exist_ok=True)
         for call in (lambda: orig.step01_preprocessing(),
-                     lambda: orig.step02_areas(areamap=areamap),
+                     lambda: orig.step02_areas.set_areamap(areamap),
                      lambda: orig.step03_compute_PCA_threshold(),
                      lambda: orig.step04_compute_greedy_PCA(),
                      lambda: orig.step05_compute_TGLR(),

@@ -329,7 +329,7 @@ def test_step_chain_golden(ctx):
     with pytest.raises(RuntimeError):
         orig.step03_compute_PCA_threshold()          # require: preprocessing, areas
     orig.step01_preprocessing()
-    orig.step02_areas(areamap=inp["areamap"])
+    orig.step02_areas.set_areamap(inp["areamap"])
     orig.step03_compute_PCA_threshold()
     orig.step04_compute_greedy_PCA()
     orig.step05_compute_TGLR()
@@ -384,7 +384,7 @@ def test_purity_step_on_device_cubes(ctx):
                                          area_size=24)
     orig = SimpleOrig(raw, var, mask, f.PSF.astype(float), f.profiles)
     orig.step01_preprocessing()
-    orig.step02_areas(areamap=f.areamap)
+    orig.step02_areas.set_areamap(f.areamap)
     orig.step03_compute_PCA_threshold()
     orig.step04_compute_greedy_PCA()
     orig.step05_compute_TGLR()
