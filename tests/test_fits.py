@@ -292,3 +292,20 @@ def test_step_dump_load_and_resume(ctx, tmp_path):
     fresh = SimpleOrig(raw, var, mask, f.PSF, f.profiles, ctx=ctx)
     fresh.steps["preprocessing"].dump(out)
     assert fresh.steps["preprocessing"].status is Status.NOTRUN
+
+
+def test_scan_handles_headers_longer_than_one_block(tmp_path):
+    """mpdaf / MUSE headers run over several 2880-byte blocks (hundreds of ESO HIERARCH cards)."""
+    from origin_amd import fitsio
+    extra = {f"K{i:03d}": float(i) for i in range(90)}          # 90 + mandatory cards: 3 blocks
+    prim = fitsio.header_bytes(fitsio._image_cards((), 8, True, extra=extra))
+    ext = fitsio.header_bytes(fitsio._image_cards((2, 3), -32, False, "DATA", extra))
+    data = fits_ref.encode(np.arange(6, dtype=np.float32).reshape(2, 3), -32)
+    p = tmp_path / "long.fits"
+    p.write_bytes(prim + ext + data + b"\0" * (-len(data) % 2880))
+    assert len(prim) == len(ext) == 3 * 2880
+    hdus = fitsio.scan(str(p))
+    assert len(hdus) == 2 and hdus[1][1] == 6 * 2880 and hdus[1][2] == 24
+    assert hdus[1][0]["K089"] == 89.0 and hdus[1][0]["EXTNAME"] == "DATA"
+    assert [dict(h[0]) for h in hdus] == [dict(h[0]) for h in fits_ref.scan(str(p))]
+    assert fitsio.find_hdu(str(p))[1] == 6 * 2880
