@@ -193,4 +193,7 @@ def Compute_threshold_purity(purity, cube_local_max, cube_local_min, segmap=None
         detect = np.interp(threshold, res['Tval_r'], res['Det_M'])
         logger.info('Interpolated Threshold %.2f Detection %d for Purity %.2f', threshold,
                     detect, purity)
-    return float(threshold), res
+    try:  # the reference returns an astropy Table (what Step.dump writes, steps.py:321-322)
+        return float(threshold), res.as_table()
+    except ImportError:
+        return float(threshold), res

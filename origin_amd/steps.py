@@ -493,11 +493,9 @@ def _data(img):
 
 
 def _table(pval):
-    """astropy Table when astropy is there (the reference's DataObj('table')), else the dict."""
-    try:
-        return pval.as_table()
-    except ImportError:
-        return pval
+    """What Compute_threshold_purity returned: an astropy Table when astropy is there (the
+    reference's DataObj('table')), else the mapping of columns."""
+    return pval
 
 
 # ----------------------------------------------------------------------------- stand-alone
