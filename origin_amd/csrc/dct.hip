@@ -73,6 +73,12 @@ struct CtabGuard {  // the table is cached in the context; nothing to release pe
 
 // ------------------------------------------------------------------------------------
 // pass 1: moments + solve.  block = (64 lanes, ZS waves); wave w marches z = w, w+ZS, ...
+// The weighted fit needs the 2*ORDER+1 moments M_k and the ORDER+1 weighted projections Rw;
+// the unweighted projections R0 = D^T s are only used by spaxels that fall back to the plain
+// DCT (a masked voxel, lib :226/:237; singular weights; dct_approx): they are left to a second
+// march (dct_r0_kernel) over just the 64-spaxel groups that have such a spaxel -- none on a clean
+// field -- which takes a quarter of the float64 FMAs out of this kernel.
+// mom rows: [0, NK) M, [NK, NK+NA) Rw, NK+NA: any masked voxel.
 // ------------------------------------------------------------------------------------
 template <int ORDER>
 __global__ __launch_bounds__(512) void dct_moments_kernel(const float *__restrict__ raw,
@@ -83,7 +89,7 @@ __global__ __launch_bounds__(512) void dct_moments_kernel(const float *__restric
                                                           double *__restrict__ mom) {
   constexpr int NA = ORDER + 1;
   constexpr int NK = 2 * ORDER + 1;
-  constexpr int NACC = NK + 2 * NA;
+  constexpr int NACC = NK + NA;
   extern __shared__ double lds[];  // [ZS-1][NACC+1][64]
 
   const int lane = threadIdx.x;
@@ -93,11 +99,11 @@ __global__ __launch_bounds__(512) void dct_moments_kernel(const float *__restric
   const bool live = s < S;
   const long sc = live ? s : S - 1;  // clamp: dead lanes redo the last spaxel, never store
 
-  double M[NK], Rw[NA], R0[NA];
+  double M[NK], Rw[NA];
 #pragma unroll
   for (int k = 0; k < NK; ++k) M[k] = 0.0;
 #pragma unroll
-  for (int a = 0; a < NA; ++a) Rw[a] = R0[a] = 0.0;
+  for (int a = 0; a < NA; ++a) Rw[a] = 0.0;
   int anymask = 0;
 
 #pragma unroll 4
@@ -107,16 +113,14 @@ __global__ __launch_bounds__(512) void dct_moments_kernel(const float *__restric
     const float v = var[idx];
     anymask |= mask[idx];
     const double *ct = ctab + (long)z * NK;  // wave-uniform -> scalar loads
-    const double rd = (double)r;
-    const double wd = (double)(1.0f / v);  // var = inf (masked) -> weight 0
-    const double wr = wd * rd;
+    // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division: the weight is a float32
+    // quantity either way.  var = inf (masked) -> weight 0
+    const double wd = (double)__builtin_amdgcn_rcpf(v);
+    const double wr = wd * (double)r;
 #pragma unroll
     for (int k = 0; k < NK; ++k) M[k] = fma(wd, ct[k], M[k]);
 #pragma unroll
-    for (int a = 0; a < NA; ++a) {
-      Rw[a] = fma(wr, ct[a], Rw[a]);
-      R0[a] = fma(rd, ct[a], R0[a]);
-    }
+    for (int a = 0; a < NA; ++a) Rw[a] = fma(wr, ct[a], Rw[a]);
   }
 
   // cross-wave reduction (fixed order -> deterministic)
@@ -126,10 +130,7 @@ __global__ __launch_bounds__(512) void dct_moments_kernel(const float *__restric
 #pragma unroll
       for (int k = 0; k < NK; ++k) dst[k * 64] = M[k];
 #pragma unroll
-      for (int a = 0; a < NA; ++a) {
-        dst[(NK + a) * 64] = Rw[a];
-        dst[(NK + NA + a) * 64] = R0[a];
-      }
+      for (int a = 0; a < NA; ++a) dst[(NK + a) * 64] = Rw[a];
       dst[NACC * 64] = (double)anymask;
     }
     __syncthreads();
@@ -139,10 +140,7 @@ __global__ __launch_bounds__(512) void dct_moments_kernel(const float *__restric
 #pragma unroll
       for (int k = 0; k < NK; ++k) M[k] += src[k * 64];
 #pragma unroll
-      for (int a = 0; a < NA; ++a) {
-        Rw[a] += src[(NK + a) * 64];
-        R0[a] += src[(NK + NA + a) * 64];
-      }
+      for (int a = 0; a < NA; ++a) Rw[a] += src[(NK + a) * 64];
       anymask |= (int)src[NACC * 64];
     }
   }
@@ -153,36 +151,36 @@ __global__ __launch_bounds__(512) void dct_moments_kernel(const float *__restric
 #pragma unroll
     for (int k = 0; k < NK; ++k) mom[(long)k * S + s] = M[k];
 #pragma unroll
-    for (int a = 0; a < NA; ++a) {
-      mom[(long)(NK + a) * S + s] = Rw[a];
-      mom[(long)(NK + NA + a) * S + s] = R0[a];
-    }
+    for (int a = 0; a < NA; ++a) mom[(long)(NK + a) * S + s] = Rw[a];
     mom[(long)NACC * S + s] = (double)anymask;
   }
 }
 
-// per spaxel: H y = 2 Rw by Cholesky (valid spaxels) or the plain DCT coefficients
+// per spaxel: H y = 2 Rw by Cholesky (valid spaxels).  Spaxels that take the plain DCT
+// coefficients instead are flagged in need[] for dct_r0_kernel.  approx: every spaxel (mom is
+// not read).
 template <int ORDER>
 __global__ __launch_bounds__(256) void dct_solve_kernel(const double *__restrict__ mom, int Nz,
                                                         long S, int approx,
-                                                        double *__restrict__ coef) {
+                                                        double *__restrict__ coef,
+                                                        uint8_t *__restrict__ need) {
   constexpr int NA = ORDER + 1;
   constexpr int NK = 2 * ORDER + 1;
-  constexpr int NACC = NK + 2 * NA;
+  constexpr int NACC = NK + NA;
   const long s = (long)blockIdx.x * 256 + threadIdx.x;
   if (s >= S) return;
-  double M[NK], Rw[NA], R0[NA];
+  if (approx) {
+    need[s] = 1;
+    return;
+  }
+  double M[NK], Rw[NA];
 #pragma unroll
   for (int k = 0; k < NK; ++k) M[k] = mom[(long)k * S + s];
 #pragma unroll
-  for (int a = 0; a < NA; ++a) {
-    Rw[a] = mom[(long)(NK + a) * S + s];
-    R0[a] = mom[(long)(NK + NA + a) * S + s];
-  }
+  for (int a = 0; a < NA; ++a) Rw[a] = mom[(long)(NK + a) * S + s];
   const int anymask = mom[(long)NACC * S + s] != 0.0;
-  const bool live = true;
   double y[NA];
-  bool weighted = !approx && !anymask;  // valid = ~any(mask, axis=0)   (lib :226)
+  bool weighted = !anymask;  // valid = ~any(mask, axis=0)   (lib :226)
   if (weighted) {
     // H = L L^T, in place (lower triangle), fully unrolled -> registers
     double L[NA][NA];
@@ -224,15 +222,61 @@ __global__ __launch_bounds__(256) void dct_solve_kernel(const double *__restrict
     }
     weighted = ok;  // singular weights (reference: LinAlgError) -> unweighted fit
   }
-  if (!weighted) {
-    const double inl = 1.0 / (double)Nz;
-    y[0] = R0[0] * inl;
-#pragma unroll
-    for (int a = 1; a < NA; ++a) y[a] = 2.0 * R0[a] * inl;
-  }
-  if (live) {
+  need[s] = !weighted;
+  if (weighted) {
 #pragma unroll
     for (int a = 0; a < NA; ++a) coef[(long)a * S + s] = y[a];
+  }
+}
+
+// plain DCT coefficients y = D^T s (with the 1/Nz, 2/Nz scaling) of the flagged spaxels:
+// same block shape and z march as dct_moments_kernel; a block none of whose 64 spaxels is
+// flagged leaves at once.
+template <int ORDER>
+__global__ __launch_bounds__(512) void dct_r0_kernel(const float *__restrict__ raw,
+                                                     const uint8_t *__restrict__ need,
+                                                     const double *__restrict__ ctab, int Nz,
+                                                     long S, double *__restrict__ coef) {
+  constexpr int NA = ORDER + 1;
+  constexpr int NK = 2 * ORDER + 1;
+  extern __shared__ double lds[];  // [ZS-1][NA][64]
+  const int lane = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  const int ZS = blockDim.y;
+  const long s = (long)blockIdx.x * 64 + lane;
+  const bool live = s < S;
+  const long sc = live ? s : S - 1;
+  const bool flagged = live && need[sc];
+  if (!__any(flagged)) return;  // the same 64 spaxels in every wave of the block: uniform
+  double R0[NA];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) R0[a] = 0.0;
+#pragma unroll 4
+  for (int z = wave; z < Nz; z += ZS) {
+    const double rd = (double)raw[(long)z * S + sc];
+    const double *ct = ctab + (long)z * NK;
+#pragma unroll
+    for (int a = 0; a < NA; ++a) R0[a] = fma(rd, ct[a], R0[a]);
+  }
+  if (ZS > 1) {
+    if (wave > 0) {
+      double *dst = lds + (long)(wave - 1) * NA * 64 + lane;
+#pragma unroll
+      for (int a = 0; a < NA; ++a) dst[a * 64] = R0[a];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    for (int w = 1; w < ZS; ++w) {
+      const double *src = lds + (long)(w - 1) * NA * 64 + lane;
+#pragma unroll
+      for (int a = 0; a < NA; ++a) R0[a] += src[a * 64];
+    }
+  }
+  if (flagged) {
+    const double inl = 1.0 / (double)Nz;
+    coef[s] = R0[0] * inl;
+#pragma unroll
+    for (int a = 1; a < NA; ++a) coef[(long)a * S + s] = 2.0 * R0[a] * inl;
   }
 }
 
@@ -531,20 +575,25 @@ int origin_dct_fit(origin_ctx *ctx, const float *d_raw, const float *d_var,
   const long waves = (S + 63) / 64;
   int ZS = 1;
   while (ZS < 8 && waves * ZS < (long)ctx->num_cu * 16) ZS *= 2;
-  const int NACC = (2 * order + 1) + 2 * (order + 1);
+  const int NACC = (2 * order + 1) + (order + 1);
   while (ZS > 1 && (size_t)(ZS - 1) * (NACC + 1) * 64 * sizeof(double) > 64 * 1024) ZS /= 2;
   const size_t lds = (size_t)(ZS - 1) * (NACC + 1) * 64 * sizeof(double);
+  const size_t lds_r0 = (size_t)(ZS - 1) * (order + 1) * 64 * sizeof(double);
   dim3 grid((unsigned)waves), block(64, ZS);
   void *scr = nullptr;
-  rc = origin_scratch(ctx, (size_t)(NACC + 1) * S * sizeof(double), &scr);
+  rc = origin_scratch(ctx, (size_t)(NACC + 1) * S * sizeof(double) + (size_t)S, &scr);
   if (rc) return rc;
   double *mom = (double *)scr;
+  uint8_t *need = (uint8_t *)(mom + (size_t)(NACC + 1) * S);
   ProfScope ps(ctx, K_DCT_FIT);
 #define CALL(O)                                                                                 \
-  hipLaunchKernelGGL(dct_moments_kernel<O>, grid, block, lds, ctx->stream, d_raw, d_var, d_mask, \
-                     tab.p, Nz, S, mom);                                                        \
+  if (!approx)                                                                                  \
+    hipLaunchKernelGGL(dct_moments_kernel<O>, grid, block, lds, ctx->stream, d_raw, d_var,      \
+                       d_mask, tab.p, Nz, S, mom);                                              \
   hipLaunchKernelGGL(dct_solve_kernel<O>, dim3(cdiv(S, 256)), dim3(256), 0, ctx->stream, mom,   \
-                     Nz, S, approx, d_coef)
+                     Nz, S, approx, d_coef, need);                                              \
+  hipLaunchKernelGGL(dct_r0_kernel<O>, grid, block, lds_r0, ctx->stream, d_raw, need, tab.p,    \
+                     Nz, S, d_coef)
   DISPATCH_ORDER(order, CALL)
 #undef CALL
   ORIGIN_LAUNCH_CHECK();
