@@ -56,6 +56,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-crop", type=int, default=48)
     ap.add_argument("--local-max", action="store_true", help="also time compute_local_max")
+    ap.add_argument("--area-size", type=int, default=100,
+                    help="side of the square PCA areas (development: 128 makes area rows "
+                         "cache-line aligned)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -65,7 +68,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     Nz, N = args.nz, args.size
-    field_args = (Nz, N, N, None, 25, args.nprof)
+    field_args = (Nz, N, N, None, 25, args.nprof, 0, 1.0 / 400, 1.0 / 900, args.area_size)
     # worker pool for the synthetic cube: forked BEFORE this process touches the GPU
     nworkers = max(1, min(12, (os.cpu_count() or 8) // max(1, min(world, 8)) - 1))
     pool = mp.get_context("fork").Pool(nworkers)
@@ -84,7 +87,7 @@ def main():
     field = synth.SyntheticField(*field_args)
 
     if world > 1:
-        tiling = multigpu.Tiling(field.Ny, field.Nx, world, area_size=100, halo=12)
+        tiling = multigpu.Tiling(field.Ny, field.Nx, world, area_size=args.area_size, halo=12)
         tile = tiling.tile(rank)
         y0, y1, x0, x1 = tile.y0, tile.y1, tile.x0, tile.x1
     else:

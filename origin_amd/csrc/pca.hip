@@ -1501,6 +1501,50 @@ __global__ __launch_bounds__(256) void deflate_dot_kernel(const float *__restric
   if (live) cpart[(long)blockIdx.y * ntot + DSC(DF_CBASE, k) + li] = acc;
 }
 
+// The same dot products with the block -> memory mapping of the cube instead of the areas':
+// 256 consecutive spaxels of the flattened (Ny, Nx) plane per block, each lane looking up its
+// area (area_of), the area's slot in this iteration's work list (kidx, -1: not iterating) and
+// its list position (pos_of).  An area row of 100 float32 cuts the 128-byte lines at both ends,
+// and with one block set per area every cut line is fetched twice (measured: 4.7 TB/s of
+// algorithmic bytes with 100-wide areas against 6.3 TB/s with 128-wide ones); here every line
+// is fetched once, whole.  Same z slices and summation order as deflate_dot_kernel: identical partial sums.
+// Used while the iterating areas cover most of the field.  grid (ceil(S/256), ZS)
+__global__ __launch_bounds__(256) void deflate_dot_rows_kernel(
+    const float *__restrict__ F, int Nz, long S, const int *__restrict__ area_of,
+    const int *__restrict__ pos_of, const int *__restrict__ kidx, const long *__restrict__ D,
+    int nw, const double *__restrict__ u, int zper, double *__restrict__ cpart, long ntot) {
+  const long s = (long)blockIdx.x * 256 + threadIdx.x;
+  int k = -1;
+  if (s < S) {
+    const int a = area_of[s];
+    if (a >= 0) k = kidx[a];
+  }
+  if (!__any(k >= 0)) return;  // nothing of this wave's 64 spaxels iterates (no block barrier used)
+  const long sc = k >= 0 ? s : (long)blockIdx.x * 256;  // idle lanes re-read the block's first spaxel
+  const double *uk = u + (long)(k >= 0 ? k : 0) * Nz;  // per-lane load; lanes of one area share it
+  const int z0 = blockIdx.y * zper, z1 = min(Nz, z0 + zper);
+  double acc = 0.0;
+#pragma unroll 4
+  for (int z = z0; z < z1; ++z) acc = fma(uk[z], (double)F[(long)z * S + sc], acc);
+  if (k >= 0)
+    cpart[(long)blockIdx.y * ntot + DSC(DF_CBASE, k) + (pos_of[s] - DSC(DF_LIST0, k))] = acc;
+}
+
+// area_of[s] / pos_of[s]: the area (index) holding spaxel s and its position in the
+// concatenated lists; area_of is preset to -1.   grid (ceil(nsmax/256), na)
+__global__ __launch_bounds__(256) void invert_lists_kernel(const int *__restrict__ spx,
+                                                           const long *__restrict__ spx_off,
+                                                           int *__restrict__ area_of,
+                                                           int *__restrict__ pos_of) {
+  const int a = blockIdx.y;
+  const long o0 = spx_off[a];
+  const long i = o0 + (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= spx_off[a + 1]) return;
+  const int s = spx[i];
+  area_of[s] = a;
+  pos_of[s] = (int)i;
+}
+
 __global__ __launch_bounds__(256) void deflate_finish_kernel(const int *__restrict__ spx,
                                                              const long *__restrict__ D, int nw,
                                                              int nzs, int Nz, long cb_tot,
@@ -1623,7 +1667,7 @@ struct DevBuf {
 };
 
 struct PcaWorkspace {
-  DevBuf b[19];
+  DevBuf b[20];
 };
 
 // launches lanczos_kernel with the basis in LDS when the largest matrix allows it
@@ -1806,6 +1850,21 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
   uint8_t *d_inb = (uint8_t *)(d_ndiff + na);
   ORIGIN_HIP(hipMemsetAsync(d_inb, 0, (size_t)ntot, st));
   std::vector<char> s_valid(na, 0);
+  // spaxel -> (area, list position) for the kernels that walk the cube in memory order
+  // (deflate_dot_rows_kernel); the per-iteration area -> work-list slot table travels with the
+  // descriptors
+  const bool row_dot = getenv("ORIGIN_PCA_AREA_DOT") == nullptr;
+  if ((rc = W.b[19].reserve(ctx, (size_t)2 * S * sizeof(int)))) return rc;
+  int *d_area_of = (int *)W.b[19].p, *d_pos_of = d_area_of + S;
+  if (row_dot) {
+    int nsm = 0;
+    for (int a = 0; a < na; ++a) nsm = std::max(nsm, (int)(h_spx_off[a + 1] - h_spx_off[a]));
+    ORIGIN_HIP(hipMemsetAsync(d_area_of, 0xFF, (size_t)S * sizeof(int), st));
+    if (nsm > 0)
+      hipLaunchKernelGGL(invert_lists_kernel, dim3(cdiv(nsm, 256), na), dim3(256), 0, st, d_spx,
+                         d_spx_off, d_area_of, d_pos_of);
+  }
+  std::vector<int> kidx(na, -1);
   if ((rc = b_test.reserve(ctx, (size_t)S * sizeof(double)))) return rc;
   double *d_test = (double *)b_test.p;
   ORIGIN_HIP(hipMemcpyAsync(d_test, d_test0, (size_t)S * sizeof(double), hipMemcpyDeviceToDevice,
@@ -1989,13 +2048,14 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
     // descriptors and tile lists go up in ONE asynchronous copy from pinned staging (free
     // again: the selection that has just reported back is behind every earlier upload)
     const size_t dbytes = D.size() * sizeof(long), tbytes = (size_t)3 * ntiles * sizeof(int);
-    if ((rc = b_desc.reserve(ctx, dbytes + tbytes))) return rc;
+    const size_t kbytes = (size_t)na * sizeof(int);  // area -> slot of this iteration
+    if ((rc = b_desc.reserve(ctx, dbytes + tbytes + kbytes))) return rc;
     long *dD = (long *)b_desc.p;
     int *d_ti = (int *)((char *)b_desc.p + dbytes), *d_tj = d_ti + ntiles, *d_ta = d_tj + ntiles;
-    if (dbytes + tbytes > stage_cap) {
+    if (dbytes + tbytes + kbytes > stage_cap) {
       if (h_stage) (void)hipHostFree(h_stage);
       h_stage = nullptr;
-      stage_cap = (dbytes + tbytes) * 2;
+      stage_cap = (dbytes + tbytes + kbytes) * 2;
       ORIGIN_HIP(hipHostMalloc((void **)&h_stage, stage_cap, hipHostMallocDefault));
       pinned_stage.p = h_stage;
     }
@@ -2005,8 +2065,13 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
       memcpy(ht, ti.data(), (size_t)ntiles * sizeof(int));
       memcpy(ht + ntiles, tj.data(), (size_t)ntiles * sizeof(int));
       memcpy(ht + 2 * (size_t)ntiles, ta.data(), (size_t)ntiles * sizeof(int));
+      std::fill(kidx.begin(), kidx.end(), -1);
+      for (int w = 0; w < nw; ++w) kidx[(size_t)D[(size_t)DF_AREA * nw + w]] = w;
+      memcpy(ht + 3 * (size_t)ntiles, kidx.data(), kbytes);
     }
-    ORIGIN_HIP(hipMemcpyAsync(b_desc.p, h_stage, dbytes + tbytes, hipMemcpyHostToDevice, st));
+    const int *d_kidx_it = (const int *)((char *)b_desc.p + dbytes + tbytes);
+    ORIGIN_HIP(hipMemcpyAsync(b_desc.p, h_stage, dbytes + tbytes + kbytes, hipMemcpyHostToDevice,
+                              st));
     if ((rc = b_xp.reserve(ctx, (size_t)xp * sizeof(double)))) return rc;
     if ((rc = b_fb[iters & 1]->reserve(ctx, (size_t)xp * sizeof(double)))) return rc;
     double *d_Fb = (double *)b_fb[iters & 1]->p;
@@ -2113,8 +2178,12 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
     double *cpart = (double *)scr;
     {
       ProfScope ps(ctx, K_PCA_DEFLATE_DOT, 2);
-      hipLaunchKernelGGL(deflate_dot_kernel, dim3(cdiv(nsmax, 256), nzs, nw), dim3(256), 0, st, src,
-                         Nz, S, d_spx, dD, nw, d_u, zper, cpart, cb);
+      if (row_dot && 2 * cb >= S)  // the iterating areas cover at least half of the field
+        hipLaunchKernelGGL(deflate_dot_rows_kernel, dim3(cdiv(S, 256), nzs), dim3(256), 0, st, src,
+                           Nz, S, d_area_of, d_pos_of, d_kidx_it, dD, nw, d_u, zper, cpart, cb);
+      else
+        hipLaunchKernelGGL(deflate_dot_kernel, dim3(cdiv(nsmax, 256), nzs, nw), dim3(256), 0, st,
+                           src, Nz, S, d_spx, dD, nw, d_u, zper, cpart, cb);
     }
     {
       ProfScope ps(ctx, K_PCA_DEFLATE_UPDATE, 2);
