@@ -1078,101 +1078,112 @@ __device__ __forceinline__ double tridiag_top(const double *alpha, const double 
   return theta_s * tn;
 }
 
-// Small matrices (n <= LANCZOS_M): the Krylov space is the whole space, so one Lanczos pass of
-// n steps is exact.  It runs inside ONE wave without any workgroup barrier: lane l owns
-// element l of every vector, G and the basis sit in LDS, matrix-vector products and the
-// Gram-Schmidt coefficients are lane-local loops over broadcast LDS reads.
+// Work area of the small-matrix solver (n <= LANCZOS_M), in dynamic LDS, zeroed by the kernel.
 struct SmallWork {
-  double G[LANCZOS_M][LANCZOS_M + 1];
-  double Q[LANCZOS_M + 1][LANCZOS_M + 1];
-  double w[LANCZOS_M + 1], h[LANCZOS_M + 1];
-  double alpha[LANCZOS_M], beta[LANCZOS_M];
-  TriWork tri;
+  double G[LANCZOS_M][LANCZOS_M + 1];      // the matrix, zero beyond n
+  double Q[LANCZOS_M + 1][LANCZOS_M + 1];  // B_k, ping
+  double P[LANCZOS_M][LANCZOS_M + 1];      // B_k, pong
+  double w[LANCZOS_M + 1];
 };
 
-__device__ void lanczos_small_wave(const double *__restrict__ Gk, int n, int ld, int lane,
-                                   SmallWork &sw, double *__restrict__ v, double *info3,
-                                   const double *__restrict__ slab = nullptr, long slab_stride = 0,
-                                   int ksplit = 0) {
-  // The caller has zeroed the whole work area: rows / columns beyond n are zeros, so every loop
-  // below runs in unrolled batches of 16 with all LDS reads of a batch independent -- a loop
-  // with a run-time trip count and one dependent read per iteration costs an LDS latency per
-  // element, and so does every batch.  The extra terms are exact zeros (same sums, same order).
-  const bool own = lane < n;
-  const int nr = (n + 15) & ~15;  // <= LANCZOS_M = 48
-  if (!slab) {  // (with slabs the caller has filled sw.G: see lanczos_kernel)
-    for (int c0 = 0; c0 < nr; c0 += 8) {
-      double g[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) g[e] = (own && c0 + e < n) ? Gk[(long)(c0 + e) * ld + lane] : 0.0;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) sw.G[c0 + e][lane] = g[e];
-    }
+// Small matrices (n <= LANCZOS_M) by repeated squaring: B_0 = G / tr G, B_{k+1} = B_k^2 / tr B_k^2 tends to
+// v v^T for the leading eigenvector v, the weight of the second eigenvalue being squared at
+// every step (tr B_k^2 -> 1).  One squaring of a <= 48 x 48 matrix is at most nine 16 x 16
+// tiles of v_mfma_f64_16x16x4_f64, one wave each, operands straight from LDS -- about a dozen
+// block barriers in all (a whole-space Lanczos pass in one wave, n dependent steps and a
+// tridiagonal eigen-solve, took 50-70 us for n = 20 where this takes about 15).  All 1024 threads of the block take part; sw.G holds the matrix
+// (zero beyond n) and is kept for the residual.  B_k is symmetric by construction (both
+// operands are read as rows k of B_{k-1}: B^T B).
+__device__ void eig_small_power(int n, int ld, SmallWork &sw, double *__restrict__ v, double *info3) {
+  __shared__ double s_tr, s_part[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (wave == 0) {
+    const double d = lane < n ? sw.G[lane][lane] : 0.0;
+    const double tr = wave_sum_d(d);
+    if (lane == 0) s_tr = tr;
   }
-  // start vector G * ones
-  double y = 0.0;
-  for (int c0 = 0; c0 < nr; c0 += 16) {
-    double g[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) g[e] = sw.G[c0 + e][lane];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) y += g[e];
+  __syncthreads();
+  const double tr0 = s_tr;
+  if (!(tr0 > 0.0)) {  // G == 0: any unit vector
+    for (int e = tid; e < ld; e += 1024) v[e] = e == 0 ? 1.0 : 0.0;
+    if (tid == 0 && info3) info3[0] = 0.0, info3[1] = 0.0, info3[2] = 0.0;
+    return;
   }
-  double nrm = sqrt(wave_sum_d(own ? y * y : 0.0));
-  if (own) sw.Q[0][lane] = nrm > 0.0 ? y / nrm : (lane == 0 ? 1.0 : 0.0);
-  int m = 0;
-  double beta_last = 0.0;
-  for (int j = 0; j < n; ++j) {
-    double w = 0.0;  // w_l = sum_c G[c][l] q_j[c]   (G symmetric)
-    for (int c0 = 0; c0 < nr; c0 += 16) {
-      double g[16], q[16];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) g[e] = sw.G[c0 + e][lane], q[e] = sw.Q[j][c0 + e];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) w = fma(g[e], q[e], w);
-    }
-    double aj = 0.0;
-    const int jr = (j + 16) & ~15;  // j + 1 rounded up to 16 (h[i] = 0, Q[i] = 0 for i > j)
-    for (int pass = 0; pass < 2; ++pass) {
-      if (own) sw.w[lane] = w;
-      // lane i <= j: h_i = q_i . w
-      double hi = 0.0;
-      if (lane <= j) {
-        for (int e0 = 0; e0 < nr; e0 += 16) {
-          double a[16], b[16];
-#pragma unroll
-          for (int e = 0; e < 16; ++e) a[e] = sw.Q[lane][e0 + e], b[e] = sw.w[e0 + e];
-#pragma unroll
-          for (int e = 0; e < 16; ++e) hi = fma(a[e], b[e], hi);
-        }
-        sw.h[lane] = hi;
+  double (*cur)[LANCZOS_M + 1] = sw.Q, (*nxt)[LANCZOS_M + 1] = sw.P;
+  for (int i = tid; i < LANCZOS_M * (LANCZOS_M + 1); i += 1024) {
+    const int r = i / (LANCZOS_M + 1), c = i - r * (LANCZOS_M + 1);
+    cur[r][c] = sw.G[r][c] / tr0;
+  }
+  __syncthreads();
+  const int T = (n + 15) >> 4, ntile = T * T;
+  const int ti = wave / T, tj = wave - ti * T;
+  const int l16 = lane & 15, l4 = lane >> 4;
+  double t_prev = 0.0;
+  bool last = false;
+  int it = 0;
+  for (; it < 64; ++it) {
+    double4_t acc = {0, 0, 0, 0};
+    if (wave < ntile) {
+      for (int k0 = 0; k0 < 16 * T; k0 += 4) {
+        const double a = cur[k0 + l4][ti * 16 + l16];
+        const double b = cur[k0 + l4][tj * 16 + l16];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
       }
-      aj += sw.h[j];
-      for (int i0 = 0; i0 < jr; i0 += 16) {
-        double a[16], b[16];
+      if (ti == tj) {  // trace of the new matrix: D[row = l4 + 4r][col = l16]
+        double d = 0.0;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) a[e] = sw.h[i0 + e], b[e] = sw.Q[i0 + e][lane];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) w = fma(-a[e], b[e], w);
+        for (int r = 0; r < 4; ++r) d += (l16 == l4 + 4 * r) ? acc[r] : 0.0;
+        d = wave_sum_d(d);
+        if (lane == 0) s_part[ti] = d;
       }
     }
-    const double bj = sqrt(wave_sum_d(own ? w * w : 0.0));
-    if (lane == 0) sw.alpha[j] = aj, sw.beta[j] = bj;
-    m = j + 1;
-    beta_last = bj;
-    if (bj <= 1e-300 || bj <= 1e-15 * fabs(aj)) break;
-    if (j + 1 < n && own) sw.Q[j + 1][lane] = w / bj;
+    __syncthreads();
+    double t = 0.0;
+    for (int i = 0; i < T; ++i) t += s_part[i];
+    if (wave < ntile) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) nxt[ti * 16 + l4 + 4 * r][tj * 16 + l16] = acc[r] / t;
+    }
+    __syncthreads();
+    double (*sw_)[LANCZOS_M + 1] = cur;
+    cur = nxt;
+    nxt = sw_;
+    // 1 - t ~ twice the relative weight of the rest of the spectrum: once it is below 1e-8 one
+    // more squaring takes it below the rounding level; a stalled t means a repeated leading
+    // eigenvalue (any vector of its eigenspace will do)
+    if (last || fabs(t - t_prev) <= 2e-16 * t) {
+      ++it;
+      break;
+    }
+    last = 1.0 - t <= 1e-8;
+    t_prev = t;
   }
-  const double theta = tridiag_top(sw.alpha, sw.beta, m, lane, sw.tri);
-  double yl = 0.0;
-  for (int i = 0; i < m; ++i) yl = fma(sw.tri.x[i], own ? sw.Q[i][lane] : 0.0, yl);
-  nrm = sqrt(wave_sum_d(own ? yl * yl : 0.0));
-  if (own) v[lane] = nrm > 0.0 ? yl / nrm : 0.0;
-  for (int e = n + lane; e < ld; e += 64) v[e] = 0.0;
-  if (lane == 0 && info3) {
-    info3[0] = theta;
-    info3[1] = fabs(beta_last * sw.tri.x[m - 1]);
-    info3[2] = 0.0;
+  if (wave == 0) {
+    // B ~ v v^T: the column through the largest diagonal entry, normalised
+    const double d = lane < n ? cur[lane][lane] : -1.0;
+    double best = d;
+    int bj = lane;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const double od = __shfl_xor(best, off, 64);
+      const int oj = __shfl_xor(bj, off, 64);
+      if (od > best || (od == best && oj < bj)) best = od, bj = oj;
+    }
+    const double x = lane < n ? cur[lane][bj] : 0.0;
+    const double nrm = sqrt(wave_sum_d(x * x));
+    const double vi = nrm > 0.0 ? x / nrm : (lane == 0 ? 1.0 : 0.0);
+    if (lane < n) v[lane] = vi;
+    for (int e = n + lane; e < ld; e += 64) v[e] = 0.0;
+    if (info3) {  // Rayleigh quotient and residual against the original matrix
+      if (lane < LANCZOS_M) sw.w[lane] = lane < n ? vi : 0.0;
+      double y = 0.0;
+      if (lane < n)
+        for (int c = 0; c < n; ++c) y = fma(sw.G[lane][c], sw.w[c], y);
+      const double theta = wave_sum_d(lane < n ? y * vi : 0.0);
+      const double r = lane < n ? y - theta * vi : 0.0;
+      const double res = sqrt(wave_sum_d(r * r));
+      if (lane == 0) info3[0] = theta, info3[1] = res, info3[2] = 0.0;
+    }
   }
 }
 
@@ -1210,9 +1221,9 @@ __global__ __launch_bounds__(1024) void lanczos_kernel(const double *__restrict_
   double *y = Qk + (long)(LANCZOS_M + 1) * ld;
   double *v = vout + v_off[k];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (n <= LANCZOS_M) {  // whole-space Lanczos inside one wave, no barriers
+  if (n <= LANCZOS_M) {  // small matrix: repeated squaring on the matrix cores (eig_small_power)
     SmallWork &sw = *reinterpret_cast<SmallWork *>(lz_dyn);
-    {  // the one-wave solver relies on zeros beyond n (see lanczos_small_wave)
+    {  // the solver relies on zeros beyond n
       double *z8 = reinterpret_cast<double *>(&sw);
       for (int i = tid; i < (int)(sizeof(SmallWork) / sizeof(double)); i += 1024) z8[i] = 0.0;
       __syncthreads();
@@ -1239,9 +1250,12 @@ __global__ __launch_bounds__(1024) void lanczos_kernel(const double *__restrict_
       }
       __syncthreads();
     }
-    if (wave == 0)
-      lanczos_small_wave(Gk, n, ld, lane, sw, v, info ? info + 3 * k : nullptr,
-                         slab ? slab + g_off[k] : nullptr, slab_stride, ksplit);
+    else {
+      for (int c = wave; c < n; c += 16)
+        if (lane < n) sw.G[c][lane] = Gk[(long)c * ld + lane];
+      __syncthreads();
+    }
+    eig_small_power(n, ld, sw, v, info ? info + 3 * k : nullptr);
     return;
   }
   const int mfull = min(LANCZOS_M, n);
@@ -1714,7 +1728,7 @@ int gram_launch(origin_ctx *ctx, const double *d_Xp, const long *d_xp_off, const
                      d_ld, d_ti, d_tj, d_ta, Nz, ksplit, (double *)scr, d_g_off, g_total);
   if (slab_out) *slab_out = (const double *)scr;
   if (ksplit_out) *ksplit_out = ksplit;
-  // the one-wave eigen-solver sums the slabs itself when every matrix of the launch is small
+  // the small-matrix eigen-solver sums the slabs itself when every matrix of the launch is small
   if (!skip_reduce)
     hipLaunchKernelGGL(gram_reduce_kernel, dim3(ntiles), dim3(256), 0, ctx->stream,
                        (const double *)scr, g_total, ksplit, d_ld, d_ti, d_tj, d_ta, d_G, d_g_off);
