@@ -1187,6 +1187,122 @@ __device__ void eig_small_power(int n, int ld, SmallWork &sw, double *__restrict
   }
 }
 
+// The same iteration for LANCZOS_M < n <= PW_N with both buffers in the block's dynamic LDS
+// (2 x 96 x 97 float64 = 146 KB): up to 36 tiles, at most three per wave.  G is read from
+// global memory (these sizes never take the slab path).  Lanczos needs 24-48 dependent steps of
+// ~10 us for such a matrix; a squaring is ~6 us and a dozen of them suffice.
+constexpr int PW_N = 96, PW_LD = 97;
+constexpr size_t PW_BYTES = (size_t)2 * PW_N * PW_LD * sizeof(double);
+__device__ void eig_mid_power(const double *__restrict__ Gk, int n, int ld, double *lds,
+                              double *__restrict__ v, double *info3) {
+  __shared__ double s_tr, s_part[16], s_vec[PW_N];
+  double (*cur)[PW_LD] = reinterpret_cast<double (*)[PW_LD]>(lds);
+  double (*nxt)[PW_LD] = cur + PW_N;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (wave == 0) {
+    double d = lane < n ? Gk[(long)lane * ld + lane] : 0.0;
+    if (lane + 64 < n) d += Gk[(long)(lane + 64) * ld + lane + 64];
+    const double tr = wave_sum_d(d);
+    if (lane == 0) s_tr = tr;
+  }
+  __syncthreads();
+  const double tr0 = s_tr;
+  if (!(tr0 > 0.0)) {
+    for (int e = tid; e < ld; e += 1024) v[e] = e == 0 ? 1.0 : 0.0;
+    if (tid == 0 && info3) info3[0] = 0.0, info3[1] = 0.0, info3[2] = 0.0;
+    return;
+  }
+  for (int i = tid; i < PW_N * PW_LD; i += 1024) {
+    const int r = i / PW_LD, c = i - r * PW_LD;
+    cur[r][c] = (r < n && c < n) ? Gk[(long)r * ld + c] / tr0 : 0.0;
+  }
+  __syncthreads();
+  const int T = (n + 15) >> 4, ntile = T * T;
+  const int l16 = lane & 15, l4 = lane >> 4;
+  double t_prev = 0.0;
+  bool last = false;
+  int it = 0;
+  for (; it < 64; ++it) {
+    double4_t acc[3];
+    double dsum = 0.0;
+#pragma unroll
+    for (int sidx = 0; sidx < 3; ++sidx) {
+      acc[sidx] = double4_t{0, 0, 0, 0};
+      const int tile = wave + 16 * sidx;
+      if (tile < ntile) {
+        const int ti = tile / T, tj = tile - ti * T;
+        for (int k0 = 0; k0 < 16 * T; k0 += 4) {
+          const double a = cur[k0 + l4][ti * 16 + l16];
+          const double b = cur[k0 + l4][tj * 16 + l16];
+          acc[sidx] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[sidx], 0, 0, 0);
+        }
+        if (ti == tj) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dsum += (l16 == l4 + 4 * r) ? acc[sidx][r] : 0.0;
+        }
+      }
+    }
+    dsum = wave_sum_d(dsum);
+    if (lane == 0) s_part[wave] = dsum;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += s_part[w];
+#pragma unroll
+    for (int sidx = 0; sidx < 3; ++sidx) {
+      const int tile = wave + 16 * sidx;
+      if (tile < ntile) {
+        const int ti = tile / T, tj = tile - ti * T;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) nxt[ti * 16 + l4 + 4 * r][tj * 16 + l16] = acc[sidx][r] / t;
+      }
+    }
+    __syncthreads();
+    double (*sw_)[PW_LD] = cur;
+    cur = nxt;
+    nxt = sw_;
+    if (last || fabs(t - t_prev) <= 2e-16 * t) {
+      ++it;
+      break;
+    }
+    last = 1.0 - t <= 1e-8;
+    t_prev = t;
+  }
+  if (wave == 0) {
+    // column through the largest diagonal entry (two rows per lane), normalised
+    const double d0 = lane < n ? cur[lane][lane] : -1.0;
+    const double d1 = lane + 64 < n ? cur[lane + 64][lane + 64] : -1.0;
+    double best = d1 > d0 ? d1 : d0;
+    int bj = d1 > d0 ? lane + 64 : lane;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const double od = __shfl_xor(best, off, 64);
+      const int oj = __shfl_xor(bj, off, 64);
+      if (od > best || (od == best && oj < bj)) best = od, bj = oj;
+    }
+    const double x0 = lane < n ? cur[lane][bj] : 0.0;
+    const double x1 = lane + 64 < n ? cur[lane + 64][bj] : 0.0;
+    const double nrm = sqrt(wave_sum_d(x0 * x0 + x1 * x1));
+    const double v0 = nrm > 0.0 ? x0 / nrm : (lane == 0 ? 1.0 : 0.0), v1 = nrm > 0.0 ? x1 / nrm : 0.0;
+    if (lane < n) v[lane] = v0;
+    if (lane + 64 < n) v[lane + 64] = v1;
+    for (int e = n + lane; e < ld; e += 64) v[e] = 0.0;
+    if (info3) {
+      s_vec[lane] = v0;
+      if (lane < PW_N - 64) s_vec[lane + 64] = v1;
+      double y0 = 0.0, y1 = 0.0;
+      for (int c = 0; c < n; ++c) {
+        if (lane < n) y0 = fma(Gk[(long)lane * ld + c], s_vec[c], y0);
+        if (lane + 64 < n) y1 = fma(Gk[(long)(lane + 64) * ld + c], s_vec[c], y1);
+      }
+      const double theta = wave_sum_d(y0 * v0 + y1 * v1);
+      const double r0 = lane < n ? y0 - theta * v0 : 0.0, r1 = lane + 64 < n ? y1 - theta * v1 : 0.0;
+      const double res = sqrt(wave_sum_d(r0 * r0 + r1 * r1));
+      if (lane == 0) info3[0] = theta, info3[1] = res, info3[2] = 0.0;
+    }
+  }
+}
+
 // QLDS: the Krylov basis (LANCZOS_M + 2 rows of length ld) lives in dynamic LDS instead of global
 // memory -- the Gram-Schmidt passes of this one-block kernel are chains of dependent reads, and
 // an L2 round trip costs ~0.7 us against ~0.05 us for LDS.  The host picks it when the basis of
@@ -1204,7 +1320,8 @@ __global__ __launch_bounds__(1024) void lanczos_kernel(const double *__restrict_
                                                        int max_restart, double tol,
                                                        double *__restrict__ info,
                                                        const double *__restrict__ slab,
-                                                       long slab_stride, int ksplit) {
+                                                       long slab_stride, int ksplit,
+                                                       int power_nmax) {
   __shared__ double alpha[LANCZOS_M], beta[LANCZOS_M], h[LANCZOS_M + 1];
   __shared__ TriWork ws;
   __shared__ double red[16];
@@ -1256,6 +1373,10 @@ __global__ __launch_bounds__(1024) void lanczos_kernel(const double *__restrict_
       __syncthreads();
     }
     eig_small_power(n, ld, sw, v, info ? info + 3 * k : nullptr);
+    return;
+  }
+  if (n <= power_nmax) {  // mid-size matrix: repeated squaring with both buffers in LDS
+    eig_mid_power(Gk, n, ld, lz_dyn, v, info ? info + 3 * k : nullptr);
     return;
   }
   const int mfull = min(LANCZOS_M, n);
@@ -1691,21 +1812,29 @@ int eig_launch(origin_ctx *ctx, int nmat, long ldmax, const double *d_G, const l
                long slab_stride = 0, int ksplit = 0) {
   static bool attr_done = false;
   if (!attr_done) {
+    // dynamic + static LDS must stay within the 160 KB of a CU: ask for exactly what is used
+    const int dyn_max = (int)std::max(PW_BYTES, (size_t)(LANCZOS_M + 2) * LANCZOS_QLDS_LD * sizeof(double));
     ORIGIN_HIP(hipFuncSetAttribute((const void *)lanczos_kernel<true>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 148 * 1024));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, dyn_max));
+    ORIGIN_HIP(hipFuncSetAttribute((const void *)lanczos_kernel<false>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, dyn_max));
     attr_done = true;
   }
+  // matrices of up to PW_N columns are solved by repeated squaring in LDS (PW_BYTES of it)
+  const bool mid = ldmax > LANCZOS_M;
   const bool qlds = ldmax <= LANCZOS_QLDS_LD;
   if (qlds) {
-    const size_t lds = std::max(sizeof(SmallWork),
-                                (size_t)(LANCZOS_M + 2) * (size_t)ldmax * sizeof(double));
+    size_t lds = std::max(sizeof(SmallWork),
+                          (size_t)(LANCZOS_M + 2) * (size_t)ldmax * sizeof(double));
+    if (mid) lds = std::max(lds, PW_BYTES);
     hipLaunchKernelGGL(lanczos_kernel<true>, dim3(nmat), dim3(1024), lds, ctx->stream, d_G, d_g_off,
                        d_ld, d_n, d_q, d_q_off, d_v, d_v_off, 60, 1e-14, d_info, d_slab, slab_stride,
-                       ksplit);
+                       ksplit, mid ? PW_N : 0);
   } else {
-    hipLaunchKernelGGL(lanczos_kernel<false>, dim3(nmat), dim3(1024), sizeof(SmallWork), ctx->stream,
-                       d_G, d_g_off, d_ld, d_n, d_q, d_q_off, d_v, d_v_off, 60, 1e-14, d_info, d_slab,
-                       slab_stride, ksplit);
+    hipLaunchKernelGGL(lanczos_kernel<false>, dim3(nmat), dim3(1024),
+                       std::max(sizeof(SmallWork), PW_BYTES), ctx->stream, d_G, d_g_off, d_ld, d_n,
+                       d_q, d_q_off, d_v, d_v_off, 60, 1e-14, d_info, d_slab, slab_stride, ksplit,
+                       PW_N);
   }
   ORIGIN_LAUNCH_CHECK();
   return ORIGIN_OK;

@@ -120,10 +120,13 @@ def test_gram_mfma_matches_numpy(ctx):
     assert np.max(np.abs(got - ref)) <= 1e-12 * np.max(np.abs(ref))
 
 
-@pytest.mark.parametrize("n,spectrum", [(1, "flat"), (2, "gap"), (37, "gap"), (130, "close"),
+@pytest.mark.parametrize("n,spectrum", [(1, "flat"), (2, "gap"), (20, "flat"), (37, "gap"),
+                                        (48, "close"), (49, "gap"), (64, "close"), (90, "flat"),
+                                        (96, "gap"), (97, "close"), (130, "close"),
                                         (300, "flat"), (700, "close")])
 def test_lanczos_leading_eigenvector(ctx, n, spectrum):
-    """Device Lanczos vs LAPACK on PSD matrices with wide, close and flat spectra."""
+    """Device eigen-solvers vs LAPACK on PSD matrices with wide, close and flat spectra:
+    repeated squaring on the f64 matrix cores for n <= 48 and n <= 96, Lanczos above."""
     from origin_amd import _capi
     rng = np.random.default_rng(100 + n)
     Qm, _ = np.linalg.qr(rng.standard_normal((n, n)))
