@@ -182,8 +182,8 @@ int origin_o2(origin_ctx *ctx, const float *d_cube, int Nz, long S, double *d_ou
  * Per iteration (lib :899-949): nuisance/background selection (:889-917, including the
  * filtered-index quirk of :908-917), b = mean background (:917), Xp = X - b(b^T X)
  * (:920-923; the division by sum(b^2) at :924 only rescales Xp), G = Xp^T Xp with
- * v_mfma_f64_16x16x4_f64 and its leading eigenvector by restarted Lanczos in place of
- * svds(k=1) (:940), u = Xp v/|Xp v|, F -= u u^T F and the new O2 test (:943-946). */
+ * v_mfma_f64_16x16x4_f64 and its leading eigenvector (repeated squaring on the f64 matrix
+ * cores up to 96 columns, restarted Lanczos above) in place of svds(k=1) (:940), u = Xp v/|Xp v|, F -= u u^T F and the new O2 test (:943-946). */
 int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S, int na,
                    const int *d_spx,
                    const long *h_spx_off, const double *d_test0, const double *h_thr,

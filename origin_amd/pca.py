@@ -2,8 +2,8 @@
 muse_origin/lib_origin.py:769-954) over a cube that stays resident in HBM.
 
 The whole loop lives in liborigin_hip.so (``origin_pca_run``, csrc/pca.hip): all areas
-advance in lock step, nuisance / background selection, Gram matrix (float64 MFMA), Lanczos
-eigen-solve, deflation and the O2 test run on the device; this module only marshals the
+advance in lock step, nuisance / background selection, Gram matrix (float64 MFMA), leading
+eigenvector (repeated squaring / Lanczos), deflation and the O2 test run on the device; this module only marshals the
 area lists and thresholds.
 """
 import ctypes as C
