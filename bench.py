@@ -133,6 +133,7 @@ def main():
     correl = ctx.empty((Nz, ny, nx), np.float32)
     correl_min = ctx.empty((Nz, ny, nx), np.float32)
     profile = ctx.empty((Nz, ny, nx), np.uint8)
+    ima_dct = ctx.empty((ny, nx), np.float32)
     info = {}
 
     phase = {}
@@ -146,8 +147,11 @@ def main():
         if comm is not None:
             comm.allreduce_sum_device(ctx, [zsum, zcnt])
         pre = kernels.dct_standardize(ctx, raw, var, mask, coef, zsum, zcnt, cube_std=cube_std,
-                                      cont_dct=cont_dct)
+                                      want_cont=False)
         o2 = pre["o2"].to_host()
+        # the continuum cube is not needed by anything below: it runs while the host fits the
+        # thresholds (same step, same stream; the closing synchronisation waits for it)
+        kernels.dct_cont_std(ctx, var, coef, cont_dct=cont_dct, ima_dct=ima_dct)
         t1 = time.perf_counter()
         thr = pipeline.pca_threshold(o2, local_map, nb_local, 0.01, spx=spx)
         t2 = time.perf_counter()

@@ -161,6 +161,12 @@ int origin_dct_standardize(origin_ctx *ctx, const float *d_raw, const float *d_v
                            const double *d_zsum, const double *d_zcnt, int Nz, int Ny,
                            int Nx, int order, float *d_cube_std, float *d_cont_dct,
                            float *d_ima_std, float *d_ima_dct, double *d_o2);
+/* cont_dct (and ima_dct, may be NULL) alone, for callers that pass NULL for both above: nothing
+ * downstream of the O2 map waits for the continuum cube, so it can be enqueued after the O2
+ * map has been fetched and run while the host fits the thresholds (lib_origin.py:977-1024).
+ * Same values as origin_dct_standardize gives. */
+int origin_dct_cont_std(origin_ctx *ctx, const float *d_var, const double *d_coef, int Nz, int Ny,
+                        int Nx, int order, float *d_cont_dct, float *d_ima_dct);
 
 /* ---- B. O2 test and greedy PCA ---------------------------------------------------- */
 

@@ -463,6 +463,49 @@ __global__ __launch_bounds__(256) void dct_standardize_kernel(
   }
 }
 
+// cont_dct = cont / sqrt(var) alone (steps.py:440, :463) with the partial sums of its mean over
+// z: the half of dct_standardize_kernel nothing downstream of the O2 map waits for.  Run as a
+// pass of its own it overlaps the host's threshold fit (origin_dct_cont_std).  Same expressions
+// as the fused kernel: identical values.
+template <int ORDER>
+__global__ __launch_bounds__(256) void dct_cont_std_kernel(const float *__restrict__ var,
+                                                           const double *__restrict__ coef,
+                                                           const double *__restrict__ ctab, int Nz,
+                                                           long S, int zchunk,
+                                                           float *__restrict__ cont_dct,
+                                                           double *__restrict__ part /* [nzc][S] */) {
+  constexpr int NA = ORDER + 1;
+  constexpr int NK = 2 * ORDER + 1;
+  const long s = (long)blockIdx.x * 256 + threadIdx.x;
+  if (s >= S) return;
+  double c[NA];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) c[a] = coef[(long)a * S + s];
+  const int z0 = blockIdx.y * zchunk;
+  const int z1 = min(Nz, z0 + zchunk);
+  double a_dct = 0.0;
+#pragma unroll 2
+  for (int z = z0; z < z1; ++z) {
+    const long idx = (long)z * S + s;
+    const double cont = eval_cont<ORDER>(c, ctab + (long)z * NK);
+    const float rs = 1.0f / sqrtf(var[idx]);
+    const float cd = (float)cont * rs;
+    cont_dct[idx] = cd;
+    a_dct += (double)cd;
+  }
+  if (part) part[(long)blockIdx.y * S + s] = a_dct;
+}
+
+__global__ __launch_bounds__(256) void cont_image_final_kernel(const double *__restrict__ part,
+                                                               int nzc, long S, int Nz,
+                                                               float *__restrict__ ima_dct) {
+  const long s = (long)blockIdx.x * 256 + threadIdx.x;
+  if (s >= S) return;
+  double b = 0.0;
+  for (int k = 0; k < nzc; ++k) b += part[(long)k * S + s];
+  ima_dct[s] = (float)(b * (1.0 / (double)Nz));
+}
+
 // the per-channel mean is wave-uniform: divide once per channel, not once per voxel
 __global__ __launch_bounds__(256) void zmean_kernel(const double *__restrict__ zsum,
                                                     const double *__restrict__ zcnt, int Nz,
@@ -702,6 +745,42 @@ int origin_dct_standardize(origin_ctx *ctx, const float *d_raw, const float *d_v
   if (want) {
     hipLaunchKernelGGL(std_images_final_kernel, dim3(cdiv(S, 256)), dim3(256), 0, ctx->stream,
                        part, nzc, S, Nz, d_ima_std, d_ima_dct, d_o2);
+    ORIGIN_LAUNCH_CHECK();
+  }
+  return ORIGIN_OK;
+}
+
+int origin_dct_cont_std(origin_ctx *ctx, const float *d_var, const double *d_coef, int Nz, int Ny,
+                        int Nx, int order, float *d_cont_dct, float *d_ima_dct) {
+  ORIGIN_USE(ctx);
+  int rc = check_dims(Nz, Ny, Nx, order);
+  if (rc) return rc;
+  ORIGIN_CHECK_ARG(d_var && d_coef && d_cont_dct, "null pointer");
+  const long S = (long)Ny * Nx;
+  CtabGuard tab(ctx);
+  rc = make_ctab(ctx, Nz, order, &tab.p);
+  if (rc) return rc;
+  const int nzc0 = pick_zchunks(ctx, S, Nz);
+  const int zchunk = cdiv(Nz, nzc0);
+  const int nzc = cdiv(Nz, zchunk);
+  double *part = nullptr;
+  if (d_ima_dct) {
+    void *scr = nullptr;
+    rc = origin_scratch(ctx, (size_t)nzc * S * sizeof(double), &scr);
+    if (rc) return rc;
+    part = (double *)scr;
+  }
+  dim3 grid(cdiv(S, 256), nzc);
+  ProfScope ps(ctx, K_DCT_CONTINUUM);
+#define CALL(O)                                                                             \
+  hipLaunchKernelGGL(dct_cont_std_kernel<O>, grid, dim3(256), 0, ctx->stream, d_var, d_coef, \
+                     tab.p, Nz, S, zchunk, d_cont_dct, part)
+  DISPATCH_ORDER(order, CALL)
+#undef CALL
+  ORIGIN_LAUNCH_CHECK();
+  if (d_ima_dct) {
+    hipLaunchKernelGGL(cont_image_final_kernel, dim3(cdiv(S, 256)), dim3(256), 0, ctx->stream, part,
+                       nzc, S, Nz, d_ima_dct);
     ORIGIN_LAUNCH_CHECK();
   }
   return ORIGIN_OK;

@@ -340,7 +340,7 @@ class _PreprocessingRun(_HipStepMixin):
         self._loginfo('DCT continuum saved in self.cont_dct and self.ima_dct')
         self._put_cube(orig, 'cont_dct', out['cont_dct'], np.float32)
         self.store_image('ima_dct', out['ima_dct'].to_host())
-        o2 = out['o2'].to_host()
+        o2 = out['o2_host']
         _cache(orig)['o2_std'] = o2
 
         mean_fwhm = int(np.ceil(np.mean(orig.FWHM_PSF)))
