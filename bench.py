@@ -134,6 +134,10 @@ def main():
     correl_min = ctx.empty((Nz, ny, nx), np.float32)
     profile = ctx.empty((Nz, ny, nx), np.uint8)
     ima_dct = ctx.empty((ny, nx), np.float32)
+    # work buffers of the DCT stage, allocated once (an allocation made while the GPU is busy
+    # waits for it)
+    coef_buf = ctx.empty((11, ny, nx), np.float64)
+    zsum_buf, zcnt_buf = ctx.empty((Nz,), np.float64), ctx.empty((Nz,), np.float64)
     info = {}
 
     phase = {}
@@ -142,8 +146,8 @@ def main():
 
     def one_step():
         t0 = time.perf_counter()
-        coef = kernels.dct_fit(ctx, raw, var, mask, 10, False)
-        zsum, zcnt = kernels.dct_resid_sums(ctx, raw, mask, coef)
+        coef = kernels.dct_fit(ctx, raw, var, mask, 10, False, coef=coef_buf)
+        zsum, zcnt = kernels.dct_resid_sums(ctx, raw, mask, coef, zsum=zsum_buf, zcnt=zcnt_buf)
         if comm is not None:
             comm.allreduce_sum_device(ctx, [zsum, zcnt])
         pre = kernels.dct_standardize(ctx, raw, var, mask, coef, zsum, zcnt, cube_std=cube_std,
