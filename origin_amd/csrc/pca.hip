@@ -1801,8 +1801,31 @@ struct DevBuf {
   ~DevBuf() { release(); }
 };
 
+// pinned host memory that lives as long as the workspace (hipHostMalloc / hipHostFree cost
+// hundreds of microseconds and the free waits for the device)
+struct HostBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  unsigned flags = 0;
+  int reserve(size_t want, unsigned fl) {
+    if (want <= bytes && fl == flags) return ORIGIN_OK;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    bytes = 0;
+    const size_t n = want + want / 2 + 256;
+    ORIGIN_HIP(hipHostMalloc(&p, n, fl));
+    bytes = n;
+    flags = fl;
+    return ORIGIN_OK;
+  }
+  ~HostBuf() {
+    if (p) (void)hipHostFree(p);
+  }
+};
+
 struct PcaWorkspace {
   DevBuf b[20];
+  HostBuf h_nnb, h_stage;
 };
 
 // launches lanczos_kernel with the basis in LDS when the largest matrix allows it
@@ -2020,16 +2043,13 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
 
   // read-back buffer [2*na] + [1] generation flag: mapped, coherent host memory the selection
   // kernel writes into directly
-  int *h_nnb = nullptr;
-  ORIGIN_HIP(hipHostMalloc((void **)&h_nnb, (size_t)(2 * na + 1) * sizeof(int),
-                           hipHostMallocMapped | hipHostMallocCoherent));
+  if ((rc = W.h_nnb.reserve((size_t)(2 * na + 1) * sizeof(int),
+                            hipHostMallocMapped | hipHostMallocCoherent)))
+    return rc;
+  int *h_nnb = (int *)W.h_nnb.p;
   memset(h_nnb, 0, (size_t)(2 * na + 1) * sizeof(int));
   int *d_hostout = nullptr;
   ORIGIN_HIP(hipHostGetDevicePointer((void **)&d_hostout, h_nnb, 0));
-  struct Pinned {
-    int *p;
-    ~Pinned() { (void)hipHostFree(p); }
-  } pinned{h_nnb};
 
   // F = X - U C for every area that holds vectors (every area at all when the output is a
   // different buffer and has not been written yet); afterwards T = 0 and the cube is read
@@ -2082,14 +2102,7 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
     sel_lds = 0;
   }
 
-  char *h_stage = nullptr;  // pinned staging of descriptors + Gram tile lists (grown on demand)
-  size_t stage_cap = 0;
-  struct PinnedC {
-    char *p;
-    ~PinnedC() {
-      if (p) (void)hipHostFree(p);
-    }
-  } pinned_stage{nullptr};
+  char *h_stage = (char *)W.h_stage.p;  // pinned staging of descriptors + Gram tile lists
 
   std::vector<long> D;
   int iters = 0;
@@ -2195,12 +2208,10 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
     if ((rc = b_desc.reserve(ctx, dbytes + tbytes + kbytes))) return rc;
     long *dD = (long *)b_desc.p;
     int *d_ti = (int *)((char *)b_desc.p + dbytes), *d_tj = d_ti + ntiles, *d_ta = d_tj + ntiles;
-    if (dbytes + tbytes + kbytes > stage_cap) {
-      if (h_stage) (void)hipHostFree(h_stage);
-      h_stage = nullptr;
-      stage_cap = (dbytes + tbytes + kbytes) * 2;
-      ORIGIN_HIP(hipHostMalloc((void **)&h_stage, stage_cap, hipHostMallocDefault));
-      pinned_stage.p = h_stage;
+    if (dbytes + tbytes + kbytes > W.h_stage.bytes) {
+      // (free again: the selection that has just reported back is behind every earlier upload)
+      if ((rc = W.h_stage.reserve((dbytes + tbytes + kbytes) * 2, hipHostMallocDefault))) return rc;
+      h_stage = (char *)W.h_stage.p;
     }
     memcpy(h_stage, D.data(), dbytes);
     {

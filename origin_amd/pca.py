@@ -44,7 +44,8 @@ class GreedyPCA:
         tests: per area float64 O2 values in the same order (``testO2``); alternatively
         ``test_map``: a float64 DeviceArray [Ny*Nx] holding the O2 test of every spaxel (what
         dct_standardize produces), which avoids a host round trip.
-        Returns (mapO2 per area as float64 arrays, nstop)."""
+        Returns (mapO2 per area as float64 arrays, nstop); ``want_map="full"``: the int32 map
+        over all S spaxels instead of the per-area arrays."""
         ctx = self.ctx
         Nz = F.shape[0]
         S = F.size // Nz
@@ -81,4 +82,6 @@ class GreedyPCA:
         if not want_map:
             return None, nstop.value
         hmap = d_map.to_host()
+        if want_map == "full":  # the map over all spaxels (zero outside the areas), no regrouping
+            return hmap, nstop.value
         return [hmap[np.asarray(s)].astype(np.float64) for s in area_spx], nstop.value

@@ -82,12 +82,11 @@ def greedy_pca(ctx, cube_std, areamap, nbAreas, thresholds, testO2, Noise_popula
     if not inplace and sum(len(s) for s in spx) < Ny * Nx:
         F.copy_from(cube_std)  # spaxels outside every area keep their cube_std values (:799)
     drv = driver or GreedyPCA(ctx)
-    maps, nstop = drv.run(F, spx, testO2, [float(t) for t in thresholds], Noise_population,
-                          itermax, test_map=o2_dev, src=None if inplace else cube_std)
-    mapO2 = np.zeros(Ny * Nx)
-    for s, m in zip(spx, maps):
-        mapO2[s] = m
-    return F, mapO2.reshape(Ny, Nx), nstop, drv
+    hmap, nstop = drv.run(F, spx, testO2, [float(t) for t in thresholds], Noise_population,
+                          itermax, test_map=o2_dev, src=None if inplace else cube_std,
+                          want_map="full")
+    # (the device map is zero outside the areas: the same array as scattering the per-area maps)
+    return F, hmap.astype(np.float64).reshape(Ny, Nx), nstop, drv
 
 
 def tglr(ctx, plan, cube_faint, mask, size=3, want_local=True):
