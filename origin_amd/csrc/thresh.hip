@@ -12,6 +12,9 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -160,28 +163,85 @@ extern "C" int origin_o2_histogram(const double *h_data, long n, double sigclip,
 
 // The same for `na` areas at once on a few host threads (no GIL involved): area a reads
 // h_data[off[a] .. off[a+1]) and writes hist / edges at a * (cap_bins + 1).
+namespace {
+
+// Worker threads that outlive the calls: creating 16-36 threads costs more (~20 us each) than
+// the histograms of a 600 x 600 field take.  One batch at a time (the callers are serial); the
+// calling thread works too.  Threads are detached and sleep on the condition variable between
+// batches.
+class HistPool {
+ public:
+  static HistPool &get() {
+    static HistPool *pool = new HistPool();  // never destroyed: workers may be asleep at exit
+    return *pool;
+  }
+  // runs task(i) for i in [0, n) on the pool and the caller; returns when all are done
+  void run(int n, const std::function<void(int)> &task) {
+    std::unique_lock<std::mutex> batch(batch_mutex_);  // one batch at a time
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      task_ = &task;
+      n_ = n;
+      next_.store(0);
+      pending_ = n;
+      ++generation_;
+    }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [&] { return pending_ == 0; });
+    task_ = nullptr;
+  }
+
+ private:
+  HistPool() {
+    const int hw = (int)std::thread::hardware_concurrency();
+    const int nt = std::max(0, std::min(47, hw - 1));
+    for (int t = 0; t < nt; ++t) std::thread([this] { loop(); }).detach();
+  }
+  void work() {
+    for (;;) {
+      const int i = next_.fetch_add(1);
+      if (i >= n_) break;
+      (*task_)(i);
+      std::lock_guard<std::mutex> lk(m_);
+      if (--pending_ == 0) done_.notify_all();
+    }
+  }
+  void loop() {
+    unsigned long seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return generation_ != seen; });
+        seen = generation_;
+      }
+      work();
+    }
+  }
+  std::mutex m_, batch_mutex_;
+  std::condition_variable cv_, done_;
+  const std::function<void(int)> *task_ = nullptr;
+  int n_ = 0, pending_ = 0;
+  std::atomic<int> next_{0};
+  unsigned long generation_ = 0;
+};
+
+}  // namespace
+
 extern "C" int origin_o2_histogram_batch(const double *h_data, const long *h_off, int na,
                                          double sigclip, int maxiters, double *h_hist,
                                          double *h_edges, long cap_bins, long *h_nbins) {
   ORIGIN_CHECK_ARG(h_data && h_off && h_hist && h_edges && h_nbins && na >= 0, "bad arguments");
-  std::atomic<int> next(0), failed(0);
-  auto worker = [&]() {
-    for (;;) {
-      const int a = next.fetch_add(1);
-      if (a >= na) break;
-      long nk = 0;
-      const int rc = origin_o2_histogram(h_data + h_off[a], h_off[a + 1] - h_off[a], sigclip,
-                                         maxiters, h_hist + (size_t)a * (cap_bins + 1),
-                                         h_edges + (size_t)a * (cap_bins + 1), cap_bins,
-                                         h_nbins + a, &nk);
-      if (rc != ORIGIN_OK) failed.store(rc);
-    }
-  };
-  const int nt = std::max(1, std::min({na, 16, (int)std::thread::hardware_concurrency()}));
-  std::vector<std::thread> pool;
-  for (int t = 1; t < nt; ++t) pool.emplace_back(worker);
-  worker();
-  for (auto &t : pool) t.join();
+  std::atomic<int> failed(0);
+  HistPool::get().run(na, [&](int a) {
+    long nk = 0;
+    const int rc = origin_o2_histogram(h_data + h_off[a], h_off[a + 1] - h_off[a], sigclip,
+                                       maxiters, h_hist + (size_t)a * (cap_bins + 1),
+                                       h_edges + (size_t)a * (cap_bins + 1), cap_bins,
+                                       h_nbins + a, &nk);
+    if (rc != ORIGIN_OK) failed.store(rc);
+  });
   if (failed.load() != 0) {
     origin_set_error("origin_o2_histogram failed for at least one area (empty or too many bins)");
     return failed.load();
