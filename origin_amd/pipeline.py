@@ -42,6 +42,9 @@ def preprocess(ctx, raw, var, mask, dct_order=10, dct_approx=False, allreduce=No
     return out
 
 
+_CAT = {}  # concatenated area lists of the last pca_threshold call (keyed by the list object)
+
+
 def area_lists(areamap, nbAreas):
     """Flat spaxel indices of each area, in the column order of ``cube[:, areamap == i]``."""
     flat = np.asarray(areamap).reshape(-1)
@@ -57,10 +60,20 @@ def pca_threshold(o2_map, areamap, nbAreas, pfa_test=0.01, spx=None):
     spx = area_lists(areamap, nbAreas) if spx is None else spx
     flat = np.asarray(o2_map, dtype=np.float64).reshape(-1)
 
-    tests = [flat[s] for s in spx]
+    # one gather through the concatenated lists (kept per list object), per-area views into it
+    cat = _CAT.get(id(spx))
+    if cat is None or cat[0] is not spx:
+        off = np.zeros(len(spx) + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(s) for s in spx])
+        idx = np.concatenate(spx) if len(spx) else np.zeros(0, np.int64)
+        _CAT.clear()
+        cat = _CAT[id(spx)] = (spx, idx, off)
+    _, idx, off = cat
+    data = flat[idx]
+    tests = [data[off[a]:off[a + 1]] for a in range(len(spx))]
     # clip + histogram of all areas in one native multi-threaded call, then the (SciPy /
     # MINPACK) Gaussian fit per area
-    hists = clipped_histograms(tests) if tests else []
+    hists = clipped_histograms(tests, _cat=(data, off)) if tests else []
     results = [(t,) + tuple(compute_thresh_gaussfit(t, pfa_test, _hist=h))
                for t, h in zip(tests, hists)]
     testO2, histO2, binO2, thresO2, meaO2, stdO2 = zip(*results)

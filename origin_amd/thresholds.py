@@ -73,15 +73,20 @@ def clipped_histogram(data, bins='fd', sigclip=10):
     return clipped_histogram_numpy(data, bins, sigclip)
 
 
-def clipped_histograms(tests, sigclip=10):
+def clipped_histograms(tests, sigclip=10, _cat=None):
     """``clipped_histogram`` for a list of per-area O2 vectors in one native call that spreads
-    the areas over host threads."""
+    the areas over host threads.  ``_cat``: (data, offsets) when the vectors already sit one
+    after the other in one float64 array (then ``tests`` is only counted)."""
     from . import _capi
-    lens = np.array([len(t) for t in tests], dtype=np.int64)
-    off = np.zeros(len(tests) + 1, dtype=np.int64)
-    off[1:] = np.cumsum(lens)
-    data = np.ascontiguousarray(np.concatenate([np.asarray(t, dtype=np.float64).ravel()
-                                                for t in tests]))
+    if _cat is not None:
+        data, off = _cat
+        lens = np.diff(off)
+    else:
+        lens = np.array([len(t) for t in tests], dtype=np.int64)
+        off = np.zeros(len(tests) + 1, dtype=np.int64)
+        off[1:] = np.cumsum(lens)
+        data = np.ascontiguousarray(np.concatenate([np.asarray(t, dtype=np.float64).ravel()
+                                                    for t in tests]))
     cap = int(max(4096, lens.max()))
     hist = np.empty((len(tests), cap + 1))
     edges = np.empty((len(tests), cap + 1))
