@@ -211,3 +211,25 @@ def test_out_of_place_pca_keeps_unassigned_spaxels(ctx):
     ref = cpu_ref.Compute_GreedyPCA_area(1, cube.astype(float), areamap, 50, [1.5], 100, [test],
                                          svd="dense")
     assert np.max(np.abs(got - ref[0])) <= 1e-4 and np.array_equal(mapO2, ref[1])
+
+
+def test_pca_more_iterations_than_vector_slots(hip):
+    """An area that needs more iterations than the 64 removed vectors the device keeps per area:
+    the cube is flushed (F = X - U C) in the middle of the run and the loop goes on from the
+    flushed cube -- nuisance-block reuse, running background sums and the memory-order dot
+    products all restart from it.  ~80 independent strong nuisance spaxels, one removed per
+    iteration."""
+    rng = np.random.default_rng(31)
+    Nz, S = 240, 500
+    cube = rng.standard_normal((Nz, S)).astype(np.float32).astype(float)
+    for j in range(80):
+        cube[:, 5 * j] += (6.0 + 0.05 * j) * rng.standard_normal(Nz).astype(np.float32)
+    cube = cube.astype(np.float32).astype(float)
+    test = cpu_ref.O2test(cube)
+    thr = float(np.percentile(test, 83.5))
+    ref = cpu_ref.Compute_GreedyPCA(cube, test, thr, 50, 300, svd="dense")
+    got = hip.Compute_GreedyPCA(cube, test, thr, 50, 300)
+    assert ref[1].max() > 64                      # the case does cross the flush
+    assert got[2] == ref[2] == 0
+    assert np.array_equal(got[1], ref[1])
+    assert np.max(np.abs(got[0] - ref[0])) <= 1e-4
