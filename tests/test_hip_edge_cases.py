@@ -233,3 +233,23 @@ def test_pca_more_iterations_than_vector_slots(hip):
     assert got[2] == ref[2] == 0
     assert np.array_equal(got[1], ref[1])
     assert np.max(np.abs(got[0] - ref[0])) <= 1e-4
+
+
+def test_pca_area_larger_than_the_register_resident_selection(hip):
+    """An area of more than 1024 x 12 spaxels takes the general selection kernel (O2 values
+    streamed instead of held in registers / LDS), the re-gathered background mean and the
+    per-area deflation kernels."""
+    rng = np.random.default_rng(47)
+    Nz, S = 64, 13000
+    cube = rng.standard_normal((Nz, S)).astype(np.float32).astype(float)
+    for j in range(12):
+        cube[:, 1000 * j + 7] += (5.0 + 0.3 * j) * rng.standard_normal(Nz).astype(np.float32)
+    cube[:, 4321] = 0.0      # a spaxel with O2 == 0: the filtered-index quirk (lib :908-917)
+    cube = cube.astype(np.float32).astype(float)
+    test = cpu_ref.O2test(cube)
+    thr = float(np.sort(test)[-13])
+    ref = cpu_ref.Compute_GreedyPCA(cube, test, thr, 50, 100, svd="dense")
+    got = hip.Compute_GreedyPCA(cube, test, thr, 50, 100)
+    assert ref[1].max() >= 5
+    assert got[2] == ref[2] and np.array_equal(got[1], ref[1])
+    assert np.max(np.abs(got[0] - ref[0])) <= 1e-4
