@@ -406,3 +406,35 @@ def test_graft_entry_smoke():
     """The driver's smoke(): small Step chain on the GPU against the oracle."""
     import __graft_entry__
     __graft_entry__.smoke()
+
+
+def test_greedy_pca_full_depth_properties(ctx):
+    """BASELINE config 1 size (3681 x 200 x 200, four 100 x 100 areas), too big for the oracle:
+    size-independent properties of the greedy PCA.  (a) At the end at most ONE spaxel per area
+    has an O2 test above the area's threshold (a single remaining nuisance spaxel ends the loop
+    untouched, lib_origin.py:927-928) -- recomputed from the float32 cube_faint, not from the
+    running values the loop keeps.  (b) Idempotence: a second run on cube_faint with the same
+    thresholds only counts those leftovers once more in mapO2 and leaves the cube bit for bit."""
+    from origin_amd import kernels, pipeline, synth
+    f = synth.SyntheticField(3681, 200, 200)
+    raw, var, mask = f.arrays()
+    d_raw, d_var, d_mask = ctx.to_device(raw), ctx.to_device(var), ctx.to_device(mask.astype(np.uint8))
+    del raw, var
+    pre = pipeline.preprocess(ctx, d_raw, d_var, d_mask, want_cont=False)
+    thr = pipeline.pca_threshold(pre["o2_host"], f.areamap, f.nbAreas, 0.01)
+    F, mapO2, nstop, drv = pipeline.greedy_pca(ctx, pre["cube_std"], f.areamap, f.nbAreas,
+                                               thr["thresO2"], thr["testO2"], 50, 100,
+                                               o2_dev=pre["o2"])
+    assert nstop == 0 and mapO2.max() >= 3
+    o2 = kernels.o2test(ctx, F).to_host()
+    leftovers = 0
+    for a in range(f.nbAreas):
+        above = o2[f.areamap == a + 1] > thr["thresO2"][a] * (1 + 2e-6)
+        assert above.sum() <= 1, a
+        leftovers += int(above.sum())
+    before = F.to_host()
+    test2 = [o2.reshape(-1)[s] for s in pipeline.area_lists(f.areamap, f.nbAreas)]
+    F2, map2, nstop2, _ = pipeline.greedy_pca(ctx, F, f.areamap, f.nbAreas, thr["thresO2"], test2,
+                                              50, 100, inplace=True)
+    assert nstop2 == 0 and map2.sum() == leftovers and map2.max() <= 1
+    assert np.array_equal(F2.to_host(), before)
