@@ -1725,25 +1725,38 @@ __global__ __launch_bounds__(256) void deflate_finish_kernel(const int *__restri
 
 // ------------------------------------------------------------------------------------
 // flush: F[z, s] = X[z, s] - sum_{q < T_a} U[z][q] C[q][i]  (X may alias F; one float32 rounding)
-// grid (ceil(nsmax/256), ceil(Nz/32), na_flush); thread = one spaxel x 32 channels, U rows in LDS
+// 1-D grid over (spaxel chunk, channel block, area), see the decoding below; thread = one spaxel x
+// 32 channels, U rows in LDS
 // ------------------------------------------------------------------------------------
 constexpr int FLUSH_ZB = 32;  // channels per block
 __global__ __launch_bounds__(256) void flush_kernel(const float *X, float *F, int Nz, long S,
                                                     const int *__restrict__ spx,
                                                     const long *__restrict__ FD, int nf,
                                                     const double *__restrict__ U,
-                                                    const double *__restrict__ C, long ntot) {
+                                                    const double *__restrict__ C, long ntot,
+                                                    int nxb, int nzb) {
   // FD: [4][nf] = area, list0, ns, T
   __shared__ double Us[FLUSH_ZB][PCA_CAP];  // this block's rows of U (zero beyond T / Nz)
-  const int k = blockIdx.z;
+  // 1-D grid decoded so that the blocks of neighbouring areas for the same rows and channels
+  // are 8 workgroup ids apart: same XCD (id mod 8), a few dispatches apart in time.  An area
+  // row of 100 float32 cuts the 128-byte lines at both ends; when the two halves of a cut line
+  // are written while the line is still in that XCD's L2 it goes to memory once, whole,
+  // instead of as two partial writes (a read-modify-write each).
+  const long id = blockIdx.x;
+  const int low = (int)(id & 7);
+  const long rest = id >> 3;
+  const int k = (int)(rest % nf);
+  const long cz = (rest / nf) * 8 + low;  // index over (spaxel chunk, channel block)
+  if (cz >= (long)nxb * nzb) return;
+  const int bx = (int)(cz % nxb), by = (int)(cz / nxb);
   const int ns = (int)FD[(long)2 * nf + k], T = (int)FD[(long)3 * nf + k];
-  const int li = blockIdx.x * 256 + threadIdx.x;
-  if (blockIdx.x * 256 >= ns) return;
+  const int li = bx * 256 + threadIdx.x;
+  if (bx * 256 >= ns) return;
   const bool live = li < ns;
   const long pos = FD[(long)1 * nf + k] + (live ? li : ns - 1);
   const long col = spx[pos];
   const double *Ua = U + FD[k] * (long)Nz * PCA_CAP;
-  const int z0 = blockIdx.y * FLUSH_ZB;
+  const int z0 = by * FLUSH_ZB;
   for (int i = threadIdx.x; i < FLUSH_ZB * PCA_CAP; i += 256) {
     const int r = i / PCA_CAP, q = i - r * PCA_CAP;
     Us[r][q] = (z0 + r < Nz && q < T) ? Ua[(long)(z0 + r) * PCA_CAP + q] : 0.0;
@@ -2078,8 +2091,10 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
                                 st));
       ORIGIN_HIP(hipStreamSynchronize(st));
       ProfScope ps(ctx, K_PCA_FLUSH, 2);
-      hipLaunchKernelGGL(flush_kernel, dim3(cdiv(nsmax, 256), cdiv(Nz, FLUSH_ZB), nf), dim3(256), 0, st,
-                         src, d_F, Nz, S, d_spx, (const long *)b_fd.p, nf, d_U, d_C, ntot);
+      const int nxb = cdiv(nsmax, 256), nzb = cdiv(Nz, FLUSH_ZB);
+      const long ngroups = ((long)nxb * nzb + 7) / 8;  // groups of 8 (spaxel chunk, channel block)
+      hipLaunchKernelGGL(flush_kernel, dim3((unsigned)(ngroups * nf * 8)), dim3(256), 0, st, src, d_F,
+                         Nz, S, d_spx, (const long *)b_fd.p, nf, d_U, d_C, ntot, nxb, nzb);
       ORIGIN_LAUNCH_CHECK();
     }
     for (int a = 0; a < na; ++a) T[a] = 0;
