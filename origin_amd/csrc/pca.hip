@@ -1729,7 +1729,7 @@ __global__ __launch_bounds__(256) void deflate_finish_kernel(const int *__restri
 // 32 channels, U rows in LDS
 // ------------------------------------------------------------------------------------
 constexpr int FLUSH_ZB = 32;  // channels per block
-__global__ __launch_bounds__(256) void flush_kernel(const float *X, float *F, int Nz, long S,
+__global__ __launch_bounds__(256, 4) void flush_kernel(const float *X, float *F, int Nz, long S,
                                                     const int *__restrict__ spx,
                                                     const long *__restrict__ FD, int nf,
                                                     const double *__restrict__ U,
@@ -1761,11 +1761,11 @@ __global__ __launch_bounds__(256) void flush_kernel(const float *X, float *F, in
     const int r = i / PCA_CAP, q = i - r * PCA_CAP;
     Us[r][q] = (z0 + r < Nz && q < T) ? Ua[(long)(z0 + r) * PCA_CAP + q] : 0.0;
   }
-  // the X values of this thread's column: requested before the coefficient loop
-  float xv[FLUSH_ZB];
-#pragma unroll
-  for (int r = 0; r < FLUSH_ZB; ++r) xv[r] = X[(long)min(z0 + r, Nz - 1) * S + col];
   __syncthreads();
+  // Register budget: 4 waves per SIMD (128 VGPRs) keep enough loads in flight for this pass to
+  // stream; left alone the compiler hoists all 128 LDS reads of a coefficient batch (250 VGPRs,
+  // 2 waves per SIMD, 2.9 TB/s).  Hence two rows of U per scheduling group, and the X column
+  // loaded after the coefficient loop.
   double acc[FLUSH_ZB];
 #pragma unroll
   for (int r = 0; r < FLUSH_ZB; ++r) acc[r] = 0.0;
@@ -1774,10 +1774,18 @@ __global__ __launch_bounds__(256) void flush_kernel(const float *X, float *F, in
 #pragma unroll
     for (int e = 0; e < 8; ++e) c[e] = q0 + e < T ? C[(long)(q0 + e) * ntot + pos] : 0.0;
 #pragma unroll
-    for (int e = 0; e < 8; ++e)
+    for (int r = 0; r < FLUSH_ZB; r += 2) {
 #pragma unroll
-      for (int r = 0; r < FLUSH_ZB; ++r) acc[r] = fma(Us[r][q0 + e], c[e], acc[r]);
+      for (int e = 0; e < 8; ++e) {
+        acc[r] = fma(Us[r][q0 + e], c[e], acc[r]);
+        acc[r + 1] = fma(Us[r + 1][q0 + e], c[e], acc[r + 1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
+  float xv[FLUSH_ZB];
+#pragma unroll
+  for (int r = 0; r < FLUSH_ZB; ++r) xv[r] = X[(long)min(z0 + r, Nz - 1) * S + col];
   if (live) {
 #pragma unroll
     for (int r = 0; r < FLUSH_ZB; ++r) {
