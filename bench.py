@@ -27,6 +27,7 @@ from origin_amd import synth  # noqa: E402
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
 F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA (no sparsity)
+PMC_PROFILE = "r02_pmc_fetch_write.json"   # rocprofv3 --pmc summary the traffic figure is read from
 
 
 def _gen_chunk(args):
@@ -54,7 +55,17 @@ def main():
     ap.add_argument("--nz", type=int, default=3681)
     ap.add_argument("--nprof", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-crop", type=int, default=48)
+    ap.add_argument("--cpu-crop", type=int, default=100,
+                    help="side of the centred crop the CPU oracle is timed on (SURVEY 8d: one "
+                         "100x100 area)")
+    ap.add_argument("--check", choices=("off", "light", "full"), default="light",
+                    help="oracle check of the arrays the timed steps produced (N=1 only): light = "
+                         "one haloed GLR window + one PCA area, full = three windows + two areas "
+                         "+ a DCT window (oracle/window_check.py)")
+    ap.add_argument("--e2e-size", type=int, default=200,
+                    help="side of the sub-field for the PCIe-inclusive pass (host arrays in, host "
+                         "arrays out through the Step seam); 0 = skip")
+    ap.add_argument("--glr-precision", choices=("f16x2", "f32", "bf16"), default="f16x2")
     ap.add_argument("--local-max", action="store_true", help="also time compute_local_max")
     ap.add_argument("--area-size", type=int, default=100,
                     help="side of the square PCA areas (development: 128 makes area rows "
@@ -87,7 +98,8 @@ def main():
     field = synth.SyntheticField(*field_args)
 
     if world > 1:
-        tiling = multigpu.Tiling(field.Ny, field.Nx, world, area_size=args.area_size, halo=12)
+        tiling = multigpu.Tiling(field.Ny, field.Nx, world, area_size=args.area_size,
+                                 halo=field.PSF.shape[-1] // 2)
         tile = tiling.tile(rank)
         y0, y1, x0, x1 = tile.y0, tile.y1, tile.x0, tile.x1
     else:
@@ -123,7 +135,8 @@ def main():
                                 field.profiles, pcut=1e-8)
     else:
         plan = kernels.GLRPlan(ctx, (Nz, ny, nx), field.PSF.astype(np.float64), None,
-                               field.profiles, pcut=1e-8, pmeansub=True)
+                               field.profiles, pcut=1e-8, pmeansub=True,
+                               precision=args.glr_precision)
     if comm is not None:
         comm.attach(ctx)  # RCCL communicator on this context (collective)
 
@@ -134,11 +147,14 @@ def main():
     correl_min = ctx.empty((Nz, ny, nx), np.float32)
     profile = ctx.empty((Nz, ny, nx), np.uint8)
     ima_dct = ctx.empty((ny, nx), np.float32)
+    ima_std = ctx.empty((ny, nx), np.float32)
+    o2_buf = ctx.empty((ny, nx), np.float64)
     # work buffers of the DCT stage, allocated once (an allocation made while the GPU is busy
     # waits for it)
     coef_buf = ctx.empty((11, ny, nx), np.float64)
     zsum_buf, zcnt_buf = ctx.empty((Nz,), np.float64), ctx.empty((Nz,), np.float64)
     info = {}
+    last = {}
 
     phase = {}
     from origin_amd.pca import GreedyPCA
@@ -151,7 +167,7 @@ def main():
         if comm is not None:
             comm.allreduce_sum_device(ctx, [zsum, zcnt])
         pre = kernels.dct_standardize(ctx, raw, var, mask, coef, zsum, zcnt, cube_std=cube_std,
-                                      want_cont=False)
+                                      want_cont=False, o2=o2_buf, ima_std=ima_std)
         o2 = pre["o2"].to_host()
         # the continuum cube is not needed by anything below: it runs while the host fits the
         # thresholds (same step, same stream; the closing synchronisation waits for it)
@@ -181,6 +197,7 @@ def main():
         info["nstop"] = nstop
         info["maxmap_max"] = float(out["maxmap"].to_host().max())
         info["area_iters_mean"] = float(np.mean([mapO2.reshape(-1)[s].max() for s in spx]))
+        last.update(thr=thr, mapO2=mapO2, out=out)
         return out
 
     def barrier():
@@ -282,10 +299,11 @@ def main():
         # of this very command (profiles/, tools/summarize_rocprof.py) when the workload is the
         # default one; null otherwise
         traffic = None
+        extra["traffic_measured_in_this_run"] = False
         try:
             if world == 1 and (Nz, N, args.nprof) == (3681, 600, 20):
                 pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)),
-                                                  "profiles", "r01_pmc_fetch_write.json")))
+                                                  "profiles", PMC_PROFILE)))
                 kmap = {"glr_spectral": ["spectral_mfma_kernel", "spectral3_kernel"],
                         "glr_spatial": ["spatial_mfma_kernel", "spatial4x4_kernel"],
                         "dct_fit": ["dct_moments_kernel"], "dct_plane_sums": ["dct_plane_sums_kernel"],
@@ -299,9 +317,11 @@ def main():
                         fx = 1.0 if kn == "spectral_mfma_kernel" else 2.0
                         traffic = round((fx * e.get("FETCH_SIZE_GB_per_launch", 0.0) +
                                          e.get("WRITE_SIZE_GB_per_launch", 0.0)) * 1e9)
-                        extra["traffic_source"] = ("profiles/r01_pmc_fetch_write.json: rocprofv3 --pmc "
-                                                   "FETCH_SIZE / WRITE_SIZE passes of this command, "
-                                                   f"kernel {kn}, bytes per launch")
+                        extra["traffic_source"] = (
+                            f"profiles/{PMC_PROFILE} (commit {pmc.get('_commit', '?')}): rocprofv3 "
+                            "--pmc FETCH_SIZE / WRITE_SIZE passes of this command, kernel "
+                            f"{kn}, bytes per launch; a counter pass cannot run inside bench.py, "
+                            "so the figure is the committed profile's, not this run's")
                         break
         except (OSError, ValueError):
             traffic = None
@@ -347,6 +367,70 @@ def main():
                                    f"GLR joblib ncpu={cores}",
                             seconds={k: round(v, 2) for k, v in tm.items()})
 
+    # ---- oracle check of the arrays the timed steps left in HBM (rank 0, N == 1) ----------
+    check = None
+    if rank == 0 and world == 1 and args.check != "off":
+        from oracle import window_check as wc
+        t = time.perf_counter()
+        full = args.check == "full"
+        psf64 = field.PSF.astype(np.float64)
+        ncpu = min(32, os.cpu_count() or 1)
+        out = last["out"]
+        wins = wc.glr_windows(ny, nx) if full else \
+            wc.glr_windows(ny, nx, out=32, halo=24, which=("interior",))
+        glr_res = [wc.check_glr_window(cube_faint, out, mask, psf64, field.profiles, w,
+                                       nthreads=ncpu) for w in wins]
+        # PCA: the area that iterated longest and (full) the one with the median count
+        iters = np.array([last["mapO2"].reshape(-1)[s_].max() for s_ in spx])
+        order_a = np.argsort(-iters, kind="stable")
+        areas = [int(order_a[0])] + ([int(order_a[len(order_a) // 2])] if full and nb_local > 1
+                                     else [])
+        if not full:   # light: the median area (the longest can take minutes on the CPU)
+            areas = [int(order_a[len(order_a) // 2])]
+        pca_res = [wc.check_pca_area(cube_std, cube_faint, last["mapO2"], spx[a],
+                                     last["thr"]["thresO2"][a], a) for a in areas]
+        dct_res = []
+        if full:
+            w = ("dct", ny // 2 - 8, ny // 2 + 8, nx // 3, nx // 3 + 24)
+            r_ = wc.check_dct_window(raw, var, mask, cube_std, cont_dct, w)
+            r_.pop("_zmean")
+            dct_res.append(r_)
+        check = dict(level=args.check, glr=glr_res, pca=pca_res, dct=dct_res,
+                     ok=bool(all(r_["ok"] for r_ in glr_res + pca_res + dct_res)),
+                     tolerances="GLR |dT|<=1e-4, argmax mismatch<=1e-4; PCA rel-Frobenius<=2e-6, "
+                                "max-abs<=1e-4, mapO2 identical; DCT 1e-5*max(1,|x|)",
+                     oracle="oracle.cpu_ref (float64) on haloed windows / whole areas of the "
+                            "device arrays of the last step",
+                     seconds=round(time.perf_counter() - t, 1))
+
+    # ---- PCIe-inclusive pass: host arrays in, host arrays out, through the Step seam ---------
+    e2e = None
+    if rank == 0 and world == 1 and args.e2e_size > 0:
+        from origin_amd.steps import SimpleOrig
+        n_e = min(args.e2e_size, N)
+        fe = synth.SyntheticField(Nz, n_e, n_e, None, 25, args.nprof, 0, 1.0 / 400, 1.0 / 900,
+                                  args.area_size)
+        eraw, evar, emask = fe.arrays()
+        best = None
+        for _ in range(2):   # second pass: allocator and plan caches warm, as in a session
+            t = time.perf_counter()
+            o = SimpleOrig(eraw, evar, emask, fe.PSF.astype(np.float64), fe.profiles, ctx=ctx)
+            o.step01_preprocessing()
+            o.step02_areas.set_areamap(fe.areamap)
+            o.step03_compute_PCA_threshold()
+            o.step04_compute_greedy_PCA()
+            o.step05_compute_TGLR()
+            outs = [o.cube_std._data, o.cube_faint._data, o.cube_correl._data, o.maxmap]
+            dt = time.perf_counter() - t
+            best = dt if best is None else min(best, dt)
+            del o, outs
+        e2e = dict(value=round(Nz * n_e * n_e / best, 1), unit="voxels/s", seconds=round(best, 3),
+                   sample=f"{Nz}x{n_e}x{n_e} sub-field: float32 host arrays in (raw, var, mask), "
+                          "steps 1,3,4,5 of the Step seam (incl. their host-side segmentation "
+                          "maps and local maxima), float64 host arrays out (cube_std, "
+                          "cube_faint, cube_correl, maxmap); H2D + D2H + float64 widening "
+                          "included; never `value`")
+
     if rank == 0:
         line = {
             "metric": "voxels/s through DCT+PCA+GLR (ORIGIN hot path)",
@@ -359,17 +443,24 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if glr_precision == "f32" else f"f32+{glr_precision}",
             "data": "synthetic",
             "config": {"workload": f"synthetic {Nz}x{N}x{N} cube, Dico_FWHM_2_12 "
                                    f"({args.nprof} profiles), PSF 25x25, 100x100 areas, "
                                    "dct_order 10, pfa 0.01, Noise_population 50, itermax 100",
+                       "arithmetic": "DCT/PCA: f32 storage, f64 reductions and eigen-solve; GLR: "
+                                     + {"f16x2": "two-term f16 split on the matrix cores, fp32 "
+                                                 "accumulate (fp32-class: 22 significant bits)",
+                                        "bf16": "single bf16 MFMA per product, fp32 accumulate",
+                                        "f32": "fp32 FMA"}.get(glr_precision, glr_precision),
                        "glr_spectral_arithmetic": glr_precision, "tiles": world, "comm": (comm.backend + (" " + comm.note if comm.note else ""))
                        if comm is not None else None, "pca": info,
                        "gen_seconds": round(t_gen, 1)},
             "roofline": roofline,
             "path_hbm": path_hbm,
             "cpu_baseline": cpu_baseline,
+            "check": check,
+            "e2e": e2e,
             "wall_ms_per_step_by_phase": {k: round(1e3 * v / max(1, args.steps), 2)
                                           for k, v in phase.items()},
             "kernels_ms_per_step": {k: round(v[0] / max(1, args.steps), 3)

@@ -1207,21 +1207,24 @@ int origin_glr_plan_create(origin_ctx *ctx, int Nz, int Ny, int Nx, int nfields,
     for (size_t i = 0; i < w.size(); ++i) w[i] = (float)h_weights[i];
     TRY(upload(ctx, w, &pl->d_w, &pl->bytes));
   }
-  // profiles: even lengths get a trailing zero tap so that every length is 2*lw+1 with the
-  // reference's centring  startind = (L-1)//2                              (lib :1179-1181)
+  // profiles: every kernel centres a profile of length 2*lw+1 on tap lw.  The reference centres
+  // on startind = (L-1)//2 (lib :1179-1181), which for an even L is L/2 - 1: an even profile
+  // therefore gets a LEADING zero tap, p' = [0, p_0 .. p_{L-1}], lw' = L/2, so that
+  // sum_j p'[j] x[z + lw' - j] = sum_j p[j] x[z + L/2 - 1 - j]  (a trailing zero would shift the
+  // output by one channel)
   std::vector<float> taps, taps2;
   std::vector<int> off(K + 1, 0);
   int lwmax = 0;
   for (int kk = 0; kk < K; ++kk) {
     const int L = h_tap_off[kk + 1] - h_tap_off[kk];
+    if (!(L & 1)) {
+      taps.push_back(0.f);
+      taps2.push_back(0.f);
+    }
     for (int j = 0; j < L; ++j) {
       const double v = h_taps[h_tap_off[kk] + j];
       taps.push_back((float)v);
       taps2.push_back((float)(v * v));
-    }
-    if (!(L & 1)) {
-      taps.push_back(0.f);
-      taps2.push_back(0.f);
     }
     off[kk + 1] = (int)taps.size();
     lwmax = std::max(lwmax, (off[kk + 1] - off[kk] - 1) / 2);

@@ -165,6 +165,21 @@ class DeviceArray:
                    self.nbytes)
         return out
 
+    def window(self, y0, y1, x0, x1, z0=0, z1=None):
+        """Host copy of the box [z0:z1, y0:y1, x0:x1] of a (Nz, Ny, Nx) array (one strided
+        device->host copy: nothing but the box crosses PCIe)."""
+        Nz, Ny, Nx = self.shape
+        z1 = Nz if z1 is None else z1
+        if not (0 <= z0 < z1 <= Nz and 0 <= y0 < y1 <= Ny and 0 <= x0 < x1 <= Nx):
+            raise ValueError(f"box [{z0}:{z1}, {y0}:{y1}, {x0}:{x1}] outside {self.shape}")
+        nz, ny, nx = z1 - z0, y1 - y0, x1 - x0
+        out = np.empty((nz, ny, nx), dtype=self.dtype)
+        es = self.dtype.itemsize
+        src = self.ptr + ((z0 * Ny + y0) * Nx + x0) * es
+        _capi.call("origin_copy_box", self.ctx.handle, 1, out.ctypes.data_as(C.c_void_p), nx,
+                   ny * nx, C.c_void_p(src), Nx, Ny * Nx, nz, ny, nx, es)
+        return out
+
     def copy_from(self, other):
         assert other.nbytes == self.nbytes
         _capi.call("origin_d2d", self.ctx.handle, self.p, other.p, self.nbytes)

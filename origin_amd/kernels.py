@@ -43,14 +43,16 @@ def dct_resid_sums(ctx, raw, mask, coef, zsum=None, zcnt=None):
 
 
 def dct_standardize(ctx, raw, var, mask, coef, zsum, zcnt, cube_std=None, cont_dct=None,
-                    want_cont=True, want_images=True):
+                    want_cont=True, want_images=True, o2=None, ima_std=None):
     Nz, Ny, Nx = raw.shape
     cube_std = ctx.empty((Nz, Ny, Nx), np.float32) if cube_std is None else cube_std
     if cont_dct is None and want_cont:
         cont_dct = ctx.empty((Nz, Ny, Nx), np.float32)
-    ima_std = ctx.empty((Ny, Nx), np.float32) if want_images else None
+    if ima_std is None and want_images:
+        ima_std = ctx.empty((Ny, Nx), np.float32)
     ima_dct = ctx.empty((Ny, Nx), np.float32) if (want_images and cont_dct is not None) else None
-    o2 = ctx.empty((Ny, Nx), np.float64) if want_images else None
+    if o2 is None and want_images:
+        o2 = ctx.empty((Ny, Nx), np.float64)
     _capi.call("origin_dct_standardize", ctx.handle, raw.p, var.p, mask.p, coef.p, zsum.p,
                zcnt.p, Nz, Ny, Nx, coef.shape[0] - 1, cube_std.p, _p(cont_dct), _p(ima_std),
                _p(ima_dct), _p(o2))

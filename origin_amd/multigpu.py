@@ -249,7 +249,6 @@ class TileComm:
             buf.upload(t.numpy())
 
 
-TorchComm = TileComm  # earlier name
 
 
 def init_comm(rank, world, local_rank, backend=None):
@@ -357,6 +356,17 @@ class TiledGLR:
 
     def __init__(self, ctx, comm, tiling, rank, Nz, PSF, profiles, pcut=1e-8, pmeansub=True):
         self.ctx, self.comm, self.tiling, self.rank, self.Nz = ctx, comm, tiling, rank, Nz
+        # a kept spaxel must see real neighbour data over the whole PSF footprint, and a strip
+        # must come from ONE neighbour: halo >= P//2 and every tile at least a halo wide
+        psf0 = PSF[0] if isinstance(PSF, (list, tuple)) else PSF
+        need = int(np.asarray(psf0).shape[-1]) // 2
+        if tiling.halo < need:
+            raise ValueError(f"tiling halo {tiling.halo} is smaller than the PSF half width {need}")
+        for r in range(tiling.world):
+            t_ = tiling.tile(r)
+            if min(t_.y1 - t_.y0, t_.x1 - t_.x0) < tiling.halo:
+                raise ValueError(f"tile {r} ({t_.y1 - t_.y0}x{t_.x1 - t_.x0}) is narrower than "
+                                 f"the halo {tiling.halo}")
         (y0, y1, x0, x1), self.halos = tiling.extended(rank)
         self.eshape = (Nz, y1 - y0, x1 - x0)
         self.plan = kernels.GLRPlan(ctx, self.eshape, PSF, None, profiles, pcut, pmeansub)
@@ -367,6 +377,8 @@ class TiledGLR:
         self.out = dict(correl=ctx.empty(self.eshape, np.float32),
                         correl_min=ctx.empty(self.eshape, np.float32),
                         profile=ctx.empty(self.eshape, np.uint8))
+        self.maps = dict(maxmap=ctx.empty(self.shape[1:], np.float32),
+                         minmap=ctx.empty(self.shape[1:], np.float32))
         self._mask_set = False
         self._strips = {}
 
@@ -385,20 +397,10 @@ class TiledGLR:
         for name, dst in (("correl", correl), ("correl_min", correl_min), ("profile", profile)):
             _copy_box(ctx, dst, dst.shape, (0, 0, 0), o[name], self.eshape, (0, top, left),
                       (Nz, ny, nx))
+        # the maps of the kept spaxels, cropped on the device (no host round trip per step)
         e_ny, e_nx = self.eshape[1:]
-        maps = {}
         for name in ("maxmap", "minmap"):
-            full = o[name].to_host().reshape(e_ny, e_nx)
-            maps[name] = full[top: top + ny, left: left + nx].copy()
+            _copy_box(ctx, self.maps[name], (1, ny, nx), (0, 0, 0), o[name], (1, e_ny, e_nx),
+                      (0, top, left), (1, ny, nx))
         return dict(correl=correl, profile=profile, correl_min=correl_min,
-                    maxmap=_HostMap(maps["maxmap"]), minmap=_HostMap(maps["minmap"]))
-
-
-class _HostMap:
-    """Tiny adaptor so tiled and single-GPU results expose ``to_host()`` alike."""
-
-    def __init__(self, arr):
-        self.arr = arr
-
-    def to_host(self):
-        return self.arr
+                    maxmap=self.maps["maxmap"], minmap=self.maps["minmap"])

@@ -33,7 +33,7 @@ from .device import DeviceArray, default_context
 from .thresholds import compute_thresh_gaussfit
 
 __all__ = ('Preprocessing', 'CreateAreas', 'ComputePCAThreshold', 'ComputeGreedyPCA', 'ComputeTGLR',
-           'Status', 'Step', 'DataObj', 'SimpleOrig', 'STEPS', 'register')
+           'Status', 'Step', 'DataObj', 'SimpleOrig', 'STEPS', 'register', 'unregister')
 
 
 # ----------------------------------------------------------------------------- containers
@@ -75,79 +75,95 @@ def _wrap(ctx, value, dtype=np.float32):
 
 
 # ----------------------------------------------------------------------------- framework
+# Stand-alone harness for sessions without muse_origin/mpdaf.  It honours the same contract as
+# the reference's Step machinery (steps.py:112-299) -- the persisted keys of ``param[name]``
+# ('stepidx', 'params', 'status', 'runtime', 'execution_date'), the ``stepNN_<name>`` method
+# names, the ``require`` check and its error text, FAILED on exceptions -- but is built
+# differently: descriptors name themselves (``__set_name__``), classes collect their outputs
+# along the MRO in ``__init_subclass__`` (so a mixin + base combination keeps them, which the
+# reference's metaclass does not: see register()), and reload goes through a reader table.
 class Status(Enum):
-    """Step processing status (reference steps.py:112-118)."""
+    """Values are what the reference persists in the session's yaml (steps.py:112-118)."""
     NOTRUN = 'not run yet'
     RUN = 'run'
     DUMPED = 'dumped outputs'
     FAILED = 'failed'
 
 
+_DONE = (Status.RUN, Status.DUMPED)
+
+_READERS = {
+    'cube': lambda path: fitsio.FitsCube(path),
+    'image': lambda path: fitsio.FitsCube(path),
+    'table': lambda path: fitsio.read_table(path),
+    'array': lambda path: np.loadtxt(path, ndmin=1),
+}
+
+
 class DataObj:
-    """Descriptor naming a step output and its kind, reloading it on demand once the step
-    has been dumped and the attribute holds the path of its file (reference
-    steps.py:121-163).  Cubes and images come back as ``fitsio.FitsCube`` (decoded by the
-    GPU when read), tables as a mapping of columns, arrays through ``np.loadtxt``."""
+    """A named output of a step.  Holds the value, or -- once the step has been dumped -- the
+    path of its file, in which case the first read brings it back through ``_READERS`` (cubes
+    and images as ``fitsio.FitsCube``, decoded by the GPU when used).  A path whose file is
+    gone reads as None, an output never produced too (reference behaviour, steps.py:121-163)."""
 
     def __init__(self, kind):
         self.kind = kind
+        self.label = None
+
+    def __set_name__(self, owner, name):
+        self.label = name
 
     def __get__(self, obj, owner=None):
         if obj is None:
-            return
-        val = obj.__dict__.get(self.label)
-        if isinstance(val, str):
-            if os.path.isfile(val):
-                if self.kind in ('cube', 'image'):
-                    val = fitsio.FitsCube(val)
-                elif self.kind == 'table':
-                    val = fitsio.read_table(val)
-                elif self.kind == 'array':
-                    val = np.loadtxt(val, ndmin=1)
-                obj.__dict__[self.label] = val
-            else:
-                val = None
+            return None
+        slot = vars(obj)
+        val = slot.get(self.label)
+        if not isinstance(val, str):
+            return val
+        if not os.path.isfile(val):
+            return None
+        slot[self.label] = val = _READERS[self.kind](val)
         return val
 
     def __set__(self, obj, val):
-        obj.__dict__[self.label] = val
+        vars(obj)[self.label] = val
 
 
-class StepMeta(type):
-    """Sets DataObj labels and collects them in ``_dataobjs`` (reference steps.py:166-185)."""
-
-    def __new__(cls, name, bases, attrs):
-        descr = []
-        for base in bases:
-            descr.extend(getattr(base, '_dataobjs', []))
-        for n, inst in attrs.items():
-            if isinstance(inst, DataObj):
-                inst.label = n
-                descr.append((n, inst.kind))
-        attrs['_dataobjs'] = descr
-        return super().__new__(cls, name, bases, attrs)
+def _outputs_of(cls):
+    """(label, kind) of every DataObj visible on ``cls``, base classes first."""
+    seen = OrderedDict()
+    for klass in reversed(cls.__mro__):
+        for label, attr in vars(klass).items():
+            if isinstance(attr, DataObj):
+                seen[label] = attr.kind
+    return list(seen.items())
 
 
-class Step(metaclass=StepMeta):
-    """Processing step (reference steps.py:188-299): ``__call__`` records the parameters,
-    checks ``require``, runs, sets the status and the runtime."""
+class Step:
+    """One processing step of a session: ``step(**kw)`` records the keyword values, refuses to
+    run before the steps named in ``require``, runs, and leaves status / runtime / date in
+    ``orig.param[name]``."""
 
     name = None
     desc = None
     require = None
+    _dataobjs = []
+
+    def __init_subclass__(cls, **kw):
+        super().__init_subclass__(**kw)
+        cls._dataobjs = _outputs_of(cls)
 
     def __init__(self, orig, idx, param):
         self.logger = logging.getLogger(__name__)
-        self.orig = orig
-        self.idx = idx
-        self.method_name = 'step%02d_%s' % (idx, self.name)
+        self.orig, self.idx = orig, idx
+        self.method_name = f'step{idx:02d}_{self.name}'
+        # a reloaded session brings its own record: keep what is there
         self.meta = param.setdefault(self.name, {})
         self.meta.setdefault('stepidx', idx)
         self.param = self.meta.setdefault('params', {})
 
     def __repr__(self):
-        return 'Step {:02d}: <{}(status: {})>'.format(self.idx, self.__class__.__name__,
-                                                      self.status.name)
+        return f'Step {self.idx:02d}: <{type(self).__name__}(status: {self.status.name})>'
 
     def _loginfo(self, *args):
         self.logger.info(*args)
@@ -158,37 +174,30 @@ class Step(metaclass=StepMeta):
     def _logwarning(self, *args):
         self.logger.warning(*args)
 
-    @property
-    def status(self):
-        return self.meta.get('status', Status.NOTRUN)
+    status = property(lambda self: self.meta.get('status', Status.NOTRUN),
+                      lambda self, val: self.meta.__setitem__('status', val))
 
-    @status.setter
-    def status(self, val):
-        self.meta['status'] = val
+    def _record_keywords(self, kwargs):
+        for key, par in inspect.signature(self.run).parameters.items():
+            if key != 'orig':
+                self.param[key] = kwargs.get(key, par.default)
+
+    def _check_required(self):
+        for other in (self.orig.steps[r] for r in self.require or ()):
+            if other.status not in _DONE:
+                raise RuntimeError(f'step {other.idx:02d} must be run before')
 
     def __call__(self, *args, **kwargs):
-        t0 = time.time()
+        start = time.time()
         self._loginfo('Step %02d - %s', self.idx, self.desc)
-        sig = inspect.signature(self.run)
-        for name, p in sig.parameters.items():
-            if name == 'orig':
-                continue
-            self.param[name] = kwargs.get(name, p.default)
-        if self.require is not None:
-            for req in self.require:
-                step = self.orig.steps[req]
-                if step.status not in (Status.RUN, Status.DUMPED):
-                    raise RuntimeError(f'step {step.idx:02d} must be run before')
-        try:
-            self.run(self.orig, *args, **kwargs)
-        except Exception:
-            self.status = Status.FAILED
-            raise
-        else:
-            self.status = Status.RUN
-        self.meta['runtime'] = tot = time.time() - t0
+        self._record_keywords(kwargs)
+        self._check_required()
+        self.status = Status.FAILED          # stays if run() raises
+        self.run(self.orig, *args, **kwargs)
+        self.status = Status.RUN
+        self.meta['runtime'] = time.time() - start
         self.meta['execution_date'] = datetime.now().isoformat()
-        self._loginfo('%02d Done - %.2f sec.', self.idx, tot)
+        self._loginfo('%02d Done - %.2f sec.', self.idx, self.meta['runtime'])
 
     # without mpdaf the outputs stay LazyCube / ndarray
     def store_cube(self, name, data, **kwargs):
@@ -360,6 +369,7 @@ class _CreateAreasRun:
     """CreateAreas.run (reference steps.py:492-569): host geometry, origin_amd/areas.py."""
     name = 'areas'
     desc = 'Areas creation'
+    _Status = Status     # register() points this at the reference's own enum
 
     def run(self, orig, pfa=0.2, minsize=100, maxsize=None):
         from .areas import create_areamap
@@ -381,7 +391,7 @@ class _CreateAreasRun:
         labels = np.unique(areamap)
         self.orig.param['nbareas'] = len(labels) - (1 if 0 in labels else 0)
         self.store_image('areamap', areamap)
-        self.status = Status.RUN
+        self.status = self._Status.RUN
 
 
 class _ComputePCAThresholdRun(_HipStepMixin):
@@ -474,7 +484,7 @@ class _ComputePurityThresholdRun(_HipStepMixin):
         threshold, pval = Compute_threshold_purity(
             purity, self._get_cube(orig, ctx, 'cube_local_max'),
             self._get_cube(orig, ctx, 'cube_local_min'), segmap, threshlist=threshlist)
-        self.Pval = _table(pval)
+        self.Pval = pval
         orig.param['threshold'] = threshold
         self._loginfo('Threshold: %.2f ', threshold)
 
@@ -482,7 +492,7 @@ class _ComputePurityThresholdRun(_HipStepMixin):
         threshold_std, pval = Compute_threshold_purity(
             purity_std, self._get_cube(orig, ctx, 'cube_std_local_max'),
             self._get_cube(orig, ctx, 'cube_std_local_min'), threshlist=threshlist)
-        self.Pval_comp = _table(pval)
+        self.Pval_comp = pval
         orig.param['threshold_std'] = threshold_std
         self._loginfo('Threshold: %.2f ', threshold_std)
 
@@ -490,12 +500,6 @@ class _ComputePurityThresholdRun(_HipStepMixin):
 def _data(img):
     """ndarray of an image attribute (mpdaf Image under the reference, ndarray here)."""
     return np.asarray(getattr(img, '_data', img))
-
-
-def _table(pval):
-    """What Compute_threshold_purity returned: an astropy Table when astropy is there (the
-    reference's DataObj('table')), else the mapping of columns."""
-    return pval
 
 
 # ----------------------------------------------------------------------------- stand-alone
@@ -513,8 +517,6 @@ class Preprocessing(_PreprocessingRun, Step):
 class CreateAreas(_CreateAreasRun, Step):
     areamap = DataObj('image')
 
-
-Areas = CreateAreas  # earlier name of the stand-alone step
 
 
 class ComputePCAThreshold(_ComputePCAThresholdRun, Step):
@@ -586,8 +588,15 @@ class SimpleOrig:
 
 # ----------------------------------------------------------------------------- register
 def register():
-    """Swap GPU versions of the four hot steps into ``muse_origin.steps.STEPS``.  Call
-    before constructing ``ORIGIN``.  Returns the list of replaced class names."""
+    """Swap GPU versions of the six steps built here into ``muse_origin.steps.STEPS``.  Call
+    before constructing ``ORIGIN`` (origin.py:193 reads the list then).  Returns the list of
+    replaced class names.
+
+    Each replacement is ``class <Name>(<run mixin>, <reference class>)`` made with the
+    reference's own metaclass.  That metaclass rebuilds ``_dataobjs`` from the attributes of
+    the class body alone (steps.py:176-185), which is empty here -- the DataObj descriptors
+    are inherited -- so the list is copied over from the reference class afterwards;
+    ``ORIGIN.__init__`` (origin.py:206-207), ``Step.dump`` and ``Step.load`` all walk it."""
     import muse_origin.steps as ref  # noqa: raises ImportError when the reference is absent
 
     replaced = []
@@ -598,8 +607,25 @@ def register():
                            (_ComputeTGLRRun, 'ComputeTGLR'),
                            (_ComputePurityThresholdRun, 'ComputePurityThreshold')):
         base = getattr(ref, refname)
-        new = type(base)(refname, (mixin, base), {'__doc__': base.__doc__})
+        if getattr(base, '_origin_amd_base', None) is not None:   # already registered
+            replaced.append(refname)
+            continue
+        new = type(base)(refname, (mixin, base), {'__doc__': base.__doc__,
+                                                  '__module__': base.__module__})
+        new._dataobjs = list(base._dataobjs)
+        new._Status = ref.Status
+        new._origin_amd_base = base
         ref.STEPS[ref.STEPS.index(base)] = new
         setattr(ref, refname, new)
         replaced.append(refname)
     return replaced
+
+
+def unregister():
+    """Put the reference's own classes back (tests; A/B runs of one session)."""
+    import muse_origin.steps as ref
+    for i, cls in enumerate(list(ref.STEPS)):
+        base = getattr(cls, '_origin_amd_base', None)
+        if base is not None:
+            ref.STEPS[i] = base
+            setattr(ref, base.__name__, base)

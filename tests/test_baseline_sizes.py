@@ -1,0 +1,142 @@
+"""GPU parity at the sizes BASELINE.json names (configs 1-3), against the float64 oracle.
+
+config 1  3681 x 200 x 200, DCT + greedy PCA: the whole HIP run against the oracle run from the
+          same raw inputs -- cube_std over the full field, cube_faint / mapO2 / iteration counts
+          on two whole 100 x 100 areas (reference lib_origin.py:150-240, steps.py:431-450,
+          lib_origin.py:824-954).
+config 2  3681 x 300 x 300, 20 profiles: the HIP chain on the full field, the oracle GLR on
+          haloed (48+24)^2 windows of the device's own cube_faint at a corner, an edge and in the
+          interior (lib_origin.py:1070-1217, steps.py:781-793).
+config 3  the 3681 x 600 x 600 headline workload: ``bench.py --check full`` (same windows + two
+          PCA areas + a DCT window), so that the number the driver records carries the same
+          correctness bit.
+
+Tolerances: cube_std |d| <= 1e-5 max(1,|x|); cube_faint rel-Frobenius <= 2e-6 and
+max-abs <= 1e-4, mapO2 / nstop identical; GLR |dT| <= 1e-4, argmax mismatches <= 0.01 %.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import cpu_ref, window_check
+from origin_amd import kernels, pipeline, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from origin_amd.device import default_context
+    return default_context(0)
+
+
+def _hip_chain(ctx, f, raw, var, mask, upto="pca"):
+    d_raw, d_var = ctx.to_device(raw), ctx.to_device(var)
+    d_mask = ctx.to_device(mask.astype(np.uint8))
+    pre = pipeline.preprocess(ctx, d_raw, d_var, d_mask)
+    thr = pipeline.pca_threshold(pre["o2_host"], f.areamap, f.nbAreas, 0.01)
+    spx = pipeline.area_lists(f.areamap, f.nbAreas)
+    F, mapO2, nstop, drv = pipeline.greedy_pca(ctx, pre["cube_std"], f.areamap, f.nbAreas,
+                                               thr["thresO2"], thr["testO2"], 50, 100, spx=spx,
+                                               o2_dev=pre["o2"])
+    return dict(raw=d_raw, var=d_var, mask=d_mask, pre=pre, thr=thr, spx=spx, faint=F,
+                mapO2=mapO2, nstop=nstop, iterations=drv.iterations)
+
+
+def test_config1_dct_pca_3681x200x200_against_numpy(ctx):
+    Nz, N = 3681, 200
+    f = synth.SyntheticField(Nz, N, N)
+    raw, var, mask = f.arrays()
+    hip = _hip_chain(ctx, f, raw, var, mask)
+    assert hip["nstop"] == 0
+
+    # ---- oracle preprocessing of the whole field, one area (100 x 100 x 3681 float64) at a
+    # time: dct_residual is per spaxel, the glue of steps.py:434-446 needs the per-channel mean
+    # over ALL unmasked spaxels, accumulated here as sum / count
+    spx = hip["spx"]
+    zsum, zcnt = np.zeros(Nz), np.zeros(Nz)
+    data_std = {}
+    for a, s in enumerate(spx):
+        ys, xs = np.unravel_index(s, (N, N))
+        y0, y1, x0, x1 = ys.min(), ys.max() + 1, xs.min(), xs.max() + 1
+        r = raw[:, y0:y1, x0:x1].astype(np.float64)
+        v = var[:, y0:y1, x0:x1].astype(np.float64)
+        m = mask[:, y0:y1, x0:x1]
+        cont = cpu_ref.dct_residual(r, 10, v, False, m)
+        data = r - cont                                            # steps.py:434
+        data[m] = np.nan                                           # :435
+        zsum += np.nansum(data, axis=(1, 2))
+        zcnt += np.sum(~m, axis=(1, 2))
+        data_std[a] = (data, np.sqrt(v), m, (y0, y1, x0, x1))      # :439
+    mean = zsum / zcnt                                             # :442
+    cube_std = np.empty((Nz, N, N))
+    for a, (data, std, m, (y0, y1, x0, x1)) in data_std.items():
+        data -= mean[:, None, None]                                # :444
+        data /= std                                                # :445
+        data[m] = 0                                                # :446
+        cube_std[:, y0:y1, x0:x1] = data
+    del data_std
+    got = hip["pre"]["cube_std"].to_host()
+    err = np.abs(got - cube_std) / np.maximum(1.0, np.abs(cube_std))
+    assert err.max() <= 1e-5, err.max()
+
+    # ---- thresholds and greedy PCA of two whole areas, oracle end to end from its own cube_std
+    for a in (0, f.nbAreas - 1):
+        X = cube_std.reshape(Nz, -1)[:, spx[a]]
+        test = cpu_ref.O2test(X)
+        _, _, thr, mea, sd = cpu_ref.compute_thresh_gaussfit(test, 0.01)
+        assert abs(hip["thr"]["thresO2"][a] - thr) <= 1e-5 * thr
+        trace = []
+        faint, m2, nstop = cpu_ref.Compute_GreedyPCA(X, test, thr, 50, 100, trace=trace)
+        assert nstop == 0 and len(trace) >= 3
+        gF = hip["faint"].to_host().reshape(Nz, -1)[:, spx[a]]
+        d = gF - faint
+        assert np.linalg.norm(d) <= 2e-6 * np.linalg.norm(faint)
+        assert np.max(np.abs(d)) <= 1e-4
+        assert np.array_equal(hip["mapO2"].reshape(-1)[spx[a]], m2), a
+        assert int(m2.max()) == len(trace)
+
+
+def test_config2_glr_3681x300x300_oracle_windows(ctx):
+    Nz, N = 3681, 300
+    f = synth.SyntheticField(Nz, N, N)
+    raw, var, mask = f.arrays()
+    hip = _hip_chain(ctx, f, raw, var, mask)
+    del raw, var
+    psf = f.PSF.astype(np.float64)
+    plan = kernels.GLRPlan(ctx, (Nz, N, N), psf, None, f.profiles, 1e-8, True)
+    assert plan.precision == "f16x2" and plan.spatial_on_matrix_cores
+    out = pipeline.tglr(ctx, plan, hip["faint"], hip["mask"], want_local=False)
+    ctx.sync()
+    ncpu = min(32, os.cpu_count() or 1)
+    for w in window_check.glr_windows(N, N):
+        res = window_check.check_glr_window(hip["faint"], out, hip["mask"], psf, f.profiles, w,
+                                            nthreads=ncpu)
+        assert res["ok"], res
+        assert res["T_range"][1] > 5.0          # the window saw real signal, not zeros
+    # the stage before it, on two areas of this field too (one has the brightest blob)
+    for a in (0, 4):
+        res = window_check.check_pca_area(hip["pre"]["cube_std"], hip["faint"], hip["mapO2"],
+                                          hip["spx"][a], hip["thr"]["thresO2"][a], a)
+        assert res["ok"], res
+    plan.close()
+
+
+def test_config3_headline_600_bench_check():
+    """bench.py on the headline workload with --check full: three GLR windows, two PCA areas
+    and a DCT window of the very arrays the timed steps produced."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1",
+           "--check", "full", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500,
+                       cwd=ROOT)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    chk = line["check"]
+    assert chk["level"] == "full" and len(chk["glr"]) == 3 and len(chk["pca"]) == 2
+    assert chk["ok"], chk
+    assert line["config"]["workload"].startswith("synthetic 3681x600x600")

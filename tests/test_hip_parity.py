@@ -300,6 +300,32 @@ def test_glr_wide_profiles_fallback(hip):
     assert np.max(np.abs(correl_min - r[2])) <= 1e-4
 
 
+@pytest.mark.parametrize("lengths", [(8, 12, 30, 11), (64, 9), (140, 20)])
+def test_glr_even_length_profiles_keep_the_reference_centre(ctx, lengths):
+    """pcut=None hands the dictionary entries over untrimmed; an even-length entry is centred
+    on startind = (L-1)//2 = L/2 - 1 (reference lib_origin.py:1179-1181).  Asymmetric profiles
+    (a shift by one channel cannot hide), every spectral kernel family: matrix-core / packed
+    fp32 (lw <= 32) and the generic wide-window kernel (140 taps)."""
+    from origin_amd import kernels
+    rng = np.random.default_rng(sum(lengths))
+    Nz, Ny, Nx = 200, 28, 32
+    cube = rng.standard_normal((Nz, Ny, Nx)).astype(np.float32)
+    cube[100, 14, 16] += 60.0
+    psf = synth.moffat_psf(Nz, 25).astype(np.float64)
+    prof = [np.exp(-0.5 * ((np.arange(L) - 0.37 * L) / (0.18 * L)) ** 2) * (1 + 0.2 * rng.random(L))
+            for L in lengths]
+    ref = cpu_ref.Correlation_GLR_test(cube.astype(np.float64), psf, None, prof, nthreads=1,
+                                       pcut=None, pmeansub=True)
+    for prec in ("f16x2", "f32"):
+        plan = kernels.GLRPlan(ctx, cube.shape, psf, None, prof, None, True,
+                               precision=prec if max(lengths) <= 65 else None)
+        out = plan.run(ctx.to_device(cube), mask=None, want_maps=False)
+        assert np.max(np.abs(out["correl"].to_host() - ref[0])) <= 1e-4
+        assert np.max(np.abs(out["correl_min"].to_host() - ref[2])) <= 1e-4
+        assert np.mean(out["profile"].to_host() != ref[1]) <= 1e-4
+        plan.close()
+
+
 def test_glr_linearity_property(hip):
     """T(a * cube) = a * T(cube) for a > 0 (size-independent property)."""
     c = gc.g5_inputs()["e"]
