@@ -223,6 +223,20 @@ int origin_o2_histogram_batch(const double *h_data, const long *h_off, int na, d
                               int maxiters, double *h_hist, double *h_edges, long cap_bins,
                               long *h_nbins);
 
+/* Gaussian fit of one histogram half (lib_origin.py:1014-1018: astropy LevMarLSQFitter on
+ * Gaussian1D = MINPACK lmder, analytic Jacobian, xtol 1e-7, maxfev 100): h_p[3] = (amplitude,
+ * mean, stddev), start values in, solution out; *info = MINPACK's termination code. */
+int origin_gauss_fit(const double *h_x, const double *h_y, long m, double *h_p, int *info,
+                     int *nfev);
+
+/* Threshold of every area from the histograms origin_o2_histogram_batch left (same layout):
+ * mode, half-maximum width, bin centres left of mode + fwhm/2, Gaussian fit, thresO2 = mean -
+ * stddev * coef with coef = norm.ppf(pfa) (lib_origin.py:1004-1022).  h_res[a] = (thresO2,
+ * mean, stddev); h_status[a] = 0 ok, 1 = histogram maximum in the first bin (the reference's
+ * argmin over an empty slice raises), 2 = fewer than three bins to fit.  Host threads only. */
+int origin_o2_threshold_batch(const double *h_hist, const double *h_edges, const long *h_nbins,
+                              int na, long cap_bins, double coef, double *h_res, int *h_status);
+
 /* ---- C. GLR correlation ------------------------------------------------------------
  * Replaces Correlation_GLR_test (lib_origin.py:1070-1217) and the dense lines of
  * ComputeTGLR.run (steps.py:781-793).

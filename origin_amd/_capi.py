@@ -66,6 +66,8 @@ SIGNATURES = {
     "origin_pca_eig_qrows": [],
     "origin_o2_histogram": [vp, i64, C.c_double, i32, vp, vp, i64, PP(i64), PP(i64)],
     "origin_o2_histogram_batch": [vp, vp, i32, C.c_double, i32, vp, vp, i64, vp],
+    "origin_gauss_fit": [vp, vp, i64, vp, PP(i32), PP(i32)],
+    "origin_o2_threshold_batch": [vp, vp, vp, i32, i64, C.c_double, vp, vp],
     "origin_glr_plan_create": [vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, PP(vp)],
     "origin_glr_plan_destroy": [vp],
     "origin_glr_plan_set_precision": [vp, i32],

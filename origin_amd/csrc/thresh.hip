@@ -3,8 +3,7 @@
 // centre, population std, at most 5 iterations), Freedman-Diaconis histogram with
 // density=True.  ~1e4 numbers per area, scalar work: it stays on the host by design, but as
 // native code -- the NumPy version cost 0.55 ms per area (20 ms per 600x600 cube), more than
-// the GPU spends on the DCT.  The Levenberg-Marquardt fit that follows stays in SciPy
-// (MINPACK, the reference's own solver) so that thresholds agree to the last bit.
+// the GPU spends on the DCT.  The Levenberg-Marquardt fit that follows is lmfit.hip.
 //
 // The arithmetic follows NumPy operation by operation (percentile 'linear' interpolation,
 // linspace edges, the uniform-bin index formula of np.histogram with its edge corrections),
@@ -228,6 +227,11 @@ class HistPool {
 };
 
 }  // namespace
+
+// the pool is shared with the Gaussian fits of lmfit.hip
+void origin_host_pool_run(int n, const std::function<void(int)> &task) {
+  HistPool::get().run(n, task);
+}
 
 extern "C" int origin_o2_histogram_batch(const double *h_data, const long *h_off, int na,
                                          double sigclip, int maxiters, double *h_hist,

@@ -170,6 +170,7 @@ class DeviceArray:
         device->host copy: nothing but the box crosses PCIe)."""
         Nz, Ny, Nx = self.shape
         z1 = Nz if z1 is None else z1
+        y0, y1, x0, x1, z0, z1 = (int(v) for v in (y0, y1, x0, x1, z0, z1))
         if not (0 <= z0 < z1 <= Nz and 0 <= y0 < y1 <= Ny and 0 <= x0 < x1 <= Nx):
             raise ValueError(f"box [{z0}:{z1}, {y0}:{y1}, {x0}:{x1}] outside {self.shape}")
         nz, ny, nx = z1 - z0, y1 - y0, x1 - x0

@@ -11,7 +11,7 @@ import numpy as np
 
 from . import kernels
 from .pca import GreedyPCA
-from .thresholds import clipped_histograms, compute_thresh_gaussfit
+from .thresholds import thresholds_batch
 
 
 def preprocess(ctx, raw, var, mask, dct_order=10, dct_approx=False, allreduce=None,
@@ -71,11 +71,10 @@ def pca_threshold(o2_map, areamap, nbAreas, pfa_test=0.01, spx=None):
     _, idx, off = cat
     data = flat[idx]
     tests = [data[off[a]:off[a + 1]] for a in range(len(spx))]
-    # clip + histogram of all areas in one native multi-threaded call, then the (SciPy /
-    # MINPACK) Gaussian fit per area
-    hists = clipped_histograms(tests, _cat=(data, off)) if tests else []
-    results = [(t,) + tuple(compute_thresh_gaussfit(t, pfa_test, _hist=h))
-               for t, h in zip(tests, hists)]
+    # clip + histogram + Gaussian fit + threshold of all areas: two native calls spread over
+    # the host worker pool (csrc/thresh.hip, csrc/lmfit.hip)
+    fits = thresholds_batch(tests, pfa_test, _cat=(data, off)) if tests else []
+    results = [(t,) + f for t, f in zip(tests, fits)]
     testO2, histO2, binO2, thresO2, meaO2, stdO2 = zip(*results)
     return dict(testO2=testO2, histO2=histO2, binO2=binO2, thresO2=thresO2, meaO2=meaO2,
                 stdO2=stdO2)

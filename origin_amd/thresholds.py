@@ -10,7 +10,6 @@ muse_origin/lib_origin.py:977-1024, with astropy's ``sigma_clip`` / ``LevMarLSQF
 import ctypes as C
 
 import numpy as np
-from scipy import optimize
 from scipy.special import ndtri
 
 _SIGMA_TO_FWHM = 2.0 * np.sqrt(2.0 * np.log(2.0))
@@ -35,7 +34,22 @@ def sigma_clip_compressed(data, sigma, maxiters=5):
 
 def fit_gauss1d(x, y, amplitude, mean, stddev):
     """Levenberg-Marquardt fit of amplitude*exp(-(x-mean)^2/(2 stddev^2)) with the analytic
-    Jacobian (what LevMarLSQFitter does with Gaussian1D.fit_deriv, lib_origin.py:1014-1018)."""
+    Jacobian (what LevMarLSQFitter does with Gaussian1D.fit_deriv, lib_origin.py:1014-1018):
+    MINPACK's lmder algorithm as native host code (csrc/lmfit.hip), no Python callbacks."""
+    from . import _capi
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    p = np.array([amplitude, mean, stddev], dtype=np.float64)
+    info, nfev = C.c_int(0), C.c_int(0)
+    _capi.call("origin_gauss_fit", x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p),
+               x.size, p.ctypes.data_as(C.c_void_p), C.byref(info), C.byref(nfev))
+    return p[0], p[1], max(p[2], float(np.finfo(np.float32).tiny))
+
+
+def fit_gauss1d_scipy(x, y, amplitude, mean, stddev):
+    """The same fit through scipy.optimize.leastsq (the reference's own route); kept as the
+    cross-check of the native solver in tests/test_host_logic.py."""
+    from scipy import optimize
     tiny = float(np.finfo(np.float32).tiny)
 
     def unpack(p):
@@ -98,6 +112,44 @@ def clipped_histograms(tests, sigclip=10, _cat=None):
     return [(hist[a, :nb[a]].copy(), edges[a, :nb[a] + 1].copy()) for a in range(len(tests))]
 
 
+def thresholds_batch(tests, pfa, sigclip=10, _cat=None):
+    """``compute_thresh_gaussfit`` for a list of per-area O2 vectors, everything (clip,
+    histogram, fit, threshold) in two native calls on the host worker pool.  Returns one
+    (histO2, frecO2, thresO2, mea, std) per area.  Raises ValueError where the reference would
+    (histogram maximum in the first bin: ``argmin`` of an empty slice, lib_origin.py:1006)."""
+    from . import _capi
+    na = len(tests)
+    if _cat is not None:
+        data, off = _cat
+        lens = np.diff(off)
+    else:
+        lens = np.array([len(t) for t in tests], dtype=np.int64)
+        off = np.zeros(na + 1, dtype=np.int64)
+        off[1:] = np.cumsum(lens)
+        data = np.ascontiguousarray(np.concatenate([np.asarray(t, dtype=np.float64).ravel()
+                                                    for t in tests]))
+    cap = int(max(4096, lens.max()))
+    hist = np.empty((na, cap + 1))
+    edges = np.empty((na, cap + 1))
+    nb = np.zeros(na, dtype=np.int64)
+    _capi.call("origin_o2_histogram_batch", data.ctypes.data_as(C.c_void_p),
+               off.ctypes.data_as(C.c_void_p), na, float(sigclip), 5,
+               hist.ctypes.data_as(C.c_void_p), edges.ctypes.data_as(C.c_void_p), cap,
+               nb.ctypes.data_as(C.c_void_p))
+    res = np.empty((na, 3))
+    status = np.zeros(na, dtype=np.int32)
+    _capi.call("origin_o2_threshold_batch", hist.ctypes.data_as(C.c_void_p),
+               edges.ctypes.data_as(C.c_void_p), nb.ctypes.data_as(C.c_void_p), na, cap,
+               float(ndtri(pfa)), res.ctypes.data_as(C.c_void_p),
+               status.ctypes.data_as(C.c_void_p))
+    if np.any(status == 1):
+        raise ValueError("attempt to get argmin of an empty sequence")   # np.argmin's message
+    if np.any(status == 2):
+        raise ValueError("fewer than three histogram bins left of the mode: no Gaussian fit")
+    return [(hist[a, :nb[a]].copy(), edges[a, :nb[a] + 1].copy(), float(res[a, 0]),
+             res[a, 1], res[a, 2]) for a in range(na)]
+
+
 def clipped_histogram_numpy(data, bins='fd', sigclip=10):
     data = np.asarray(data, dtype=float)
     data = data[data > 0]
@@ -105,7 +157,7 @@ def clipped_histogram_numpy(data, bins='fd', sigclip=10):
     return np.histogram(data, bins=bins, density=True)
 
 
-def compute_thresh_gaussfit(data, pfa, bins='fd', sigclip=10, _hist=None):
+def compute_thresh_gaussfit(data, pfa, bins='fd', sigclip=10, _hist=None, _fit=None):
     """Same signature and return tuple as the reference (lib_origin.py:977-1024):
     histO2, frecO2, thresO2 (python float), mea, std."""
     histO2, frecO2 = _hist if _hist is not None else clipped_histogram(data, bins, sigclip)
@@ -118,6 +170,6 @@ def compute_thresh_gaussfit(data, pfa, bins='fd', sigclip=10, _hist=None):
     x = (frecO2[1:] + frecO2[:-1]) / 2
     xcut = mod + _SIGMA_TO_FWHM * sigma / 2
     ksel = x < xcut
-    _, mea, std = fit_gauss1d(x[ksel], histO2[ksel], histO2.max(), mod, sigma)
+    _, mea, std = (_fit or fit_gauss1d)(x[ksel], histO2[ksel], histO2.max(), mod, sigma)
     thresO2 = float(mea - std * coef)
     return histO2, frecO2, thresO2, mea, std

@@ -22,6 +22,39 @@ def test_threshold_fit_matches_reference_goldens():
             assert isinstance(thr, float)
 
 
+def test_native_lm_fit_equals_scipy_leastsq():
+    """csrc/lmfit.hip (MINPACK's lmder algorithm, native) against scipy.optimize.leastsq, the
+    reference's own solver behind astropy's LevMarLSQFitter (lib_origin.py:1014-1018): same
+    stopping point, parameters equal to a few ulp (libm exp vs NumPy's vector exp)."""
+    g = np.load(os.path.join(gc.GOLDEN_DIR, "g3_thresh.npz"))
+    cases = [g["in_" + n] for n in "abc"]
+    rng = np.random.default_rng(5)
+    cases += [(rng.standard_normal((200, n)) ** 2).mean(0) * s for n, s in
+              ((900, 1.0), (5000, 3.0), (20000, 0.2))]
+    for t in cases:
+        for pfa in (0.01, 0.2):
+            a = thresholds.compute_thresh_gaussfit(t, pfa)
+            b = thresholds.compute_thresh_gaussfit(t, pfa, _fit=thresholds.fit_gauss1d_scipy)
+            np.testing.assert_allclose(a[2:], b[2:], rtol=1e-13)
+    # the batch call (histogram + fit + threshold natively, all areas at once) is the same
+    res = thresholds.thresholds_batch(cases, 0.01)
+    for t, r in zip(cases, res):
+        one = thresholds.compute_thresh_gaussfit(t, 0.01)
+        assert r[2] == one[2] and r[3] == one[3] and r[4] == one[4]
+        np.testing.assert_array_equal(r[0], one[0])
+        np.testing.assert_array_equal(r[1], one[1])
+
+
+def test_threshold_batch_raises_where_the_reference_does():
+    import pytest
+    # histogram maximum in the first bin: np.argmin of an empty slice (lib_origin.py:1006)
+    t = np.concatenate([np.full(500, 1.0), np.linspace(1.0, 3.0, 40)])
+    with pytest.raises(ValueError):
+        cpu_ref.compute_thresh_gaussfit(t, 0.01)
+    with pytest.raises(ValueError):
+        thresholds.thresholds_batch([t], 0.01)
+
+
 def test_prepare_profiles_matches_oracle():
     for pcut, sub in ((1e-8, True), (None, True), (1e-3, False)):
         a = kernels.prepare_profiles(synth.dico_fwhm(20), pcut, sub)
