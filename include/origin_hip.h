@@ -253,10 +253,12 @@ int origin_glr_plan_create(origin_ctx *ctx, int Nz, int Ny, int Nx, int nfields,
                            origin_glr_plan **out);
 int origin_glr_plan_destroy(origin_glr_plan *plan);
 /* bytes of device memory the plan holds */
-/* Arithmetic of the spectral stage when the plan is eligible for both (weights == NULL, one
- * field, profile half widths <= 32, K <= 34): 1 (default) = matrix cores on a two-term f16
- * split of data and taps with fp32 accumulation (~3e-7 of sum |p x| from float64), 0 = fp32 FMA
- * chain (~1e-7).  Plans that are not eligible always run 0; get returns what will run. */
+/* Arithmetic of the GLR stages when the plan is eligible for the matrix cores (weights == NULL,
+ * one field, profile half widths <= 32, K <= 26): 1 (default) = two-term f16 split of data and
+ * taps, three MFMAs per product, fp32 accumulation (~3e-7 of sum |p x| from float64: fp32 class);
+ * 2 = bf16 operands, one MFMA per product in the spectral stage (BASELINE config 4 "bf16 GLR";
+ * |dT| ~1e-2); 0 = fp32 FMA chain (~1e-7).  Plans that are not eligible always run 0; get
+ * returns what will run. */
 int origin_glr_plan_set_precision(origin_glr_plan *plan, int precision);
 int origin_glr_plan_get_precision(origin_glr_plan *plan, int *precision);
 int origin_glr_plan_bytes(origin_glr_plan *plan, size_t *bytes);

@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "common.h"
+#include "glr_tables.h"
 
 struct origin_glr_plan {
   origin_ctx *ctx;
@@ -50,9 +51,13 @@ struct origin_glr_plan {
   int nborder;
   int lwt;         // template half width chosen for d_rows (8, 16, 24, 29 or 32; 0 = none)
   int NzP;
-  uint4 *d_atab;   // spectral_mfma_kernel: shifted hi/lo f16 tap copies [K][2][8][MF_GROUPS][8]
-  int *d_pwide;    // [K] 1 = half width > 16 (all 6 window blocks), 0 = blocks 1..4
-  int precision;   // 0 = fp32 FMA kernels, 1 = split-f16 MFMA spectral stage (when eligible)
+  uint4 *d_atab;   // matrix-core spectral stage: shifted hi/lo f16 tap copies (glr_tables.h)
+  uint4 *d_atab_bf16;  // the same with bf16 taps (precision 2)
+  int *d_pwide;    // [K] processing order, narrow first: original index | (half width > 16) << 8
+  int n_narrow;    // number of narrow profiles (the first n_narrow slots)
+  float *d_rdi_s;  // interior-class 1/sqrt(den) in processing order [slot][NzP]
+  std::vector<int> *h_order;  // processing order on the host (plan creation only)
+  int precision;   // 0 = fp32 FMA kernels, 1 = split-f16 MFMA stages, 2 = bf16 MFMA stages
   size_t bytes;
 };
 
@@ -656,7 +661,7 @@ __global__ __launch_bounds__(256) void spectral3_kernel(
 }
 
 // ------------------------------------------------------------------------------------
-// spectral stage on the matrix cores.
+// spectral stage on the matrix cores: operand layout (the kernel is glr_spectral_mfma.hip).
 //
 // num_k[z] = sum_j p_k[j] x[z + lw_k - j] is a banded Toeplitz product: for a tile of 32 output
 // channels z0..z0+31 and the 96-channel window x[z0-32 .. z0+63],
@@ -680,312 +685,9 @@ __global__ __launch_bounds__(256) void spectral3_kernel(
 // copies: conflict-free for the lane groups of ds_read_b128) so that every fragment is ONE
 // aligned ds_read_b128 at a per-lane base plus an immediate offset.  Profiles whose half width
 // is <= 16 only touch window blocks 1..4 (4 of the 6 k-steps).
-// Measured (tools/mfma_rate.hip): the MFMA issues every 32 cycles from 1, 2 or 4 accumulator
-// chains alike, but VALU work does not hide behind it -- neither from the same wave nor from a
-// second wave on the SIMD: each VALU instruction adds ~2 cycles.  The epilogue (scale, first
-// arg-max, min: 4.5 VALU per output and profile) is therefore the second cost centre.
 // Normalisation: 1/sqrt(den) of the lane's border class, exact for every spaxel (no fix-up
 // pass behind this kernel).
 // ------------------------------------------------------------------------------------
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
-
-constexpr int MF_TAP_SCALE_LOG2 = 12;                 // taps are stored times 2^12
-constexpr int MF_GROUPS = 20;                         // 16-byte groups per shifted copy (15 used)
-constexpr int MF_COPY_BYTES = MF_GROUPS * 16;         // 320 = 256 + 64: conflict-free ds_read_b128
-constexpr int MF_PROF_BYTES = 2 * 8 * MF_COPY_BYTES;  // hi copies, then lo copies
-constexpr int MF_RD_BYTES = 32 * 4;                   // per wave and profile: 32 channels of 1/sqrt(den)
-constexpr int MF_WAVES = 8;                           // waves per block (two per SIMD)
-constexpr int MF_MAX_K = 26;                          // 26 * (5120 + 8 * 128) B = 156 KiB of LDS
-constexpr int MF_BREG = 80;                           // B fragments live in a[80:127]
-
-template <int I, int N, typename F>
-__device__ __forceinline__ void mf_for(F &&f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    mf_for<I + 1, N>(f);
-  }
-}
-
-// Register plan.  A wave owns 32 consecutive spaxels (one 32-column B tile) and marches z in
-// tiles of 32 channels.  The data window (B fragments: 6 blocks x hi/lo x 4 dwords = 48
-// registers, constant over all K profiles) is parked in the accumulator file a[80:127] by hand
-// and named literally in the MFMA instructions; results accumulate in VGPRs where the VALU
-// epilogue reads them directly.  (Left to itself hipcc keeps the results in AGPRs and moves
-// everything through v_accvgpr_read/mov, which issue in order with the MFMAs.)  The kernel
-// stays far below its VGPR budget, so the compiler allocates no AGPR of its own (audit the .s
-// for v_accvgpr outside ASMSTART/ASMEND after every change; tests compare with the fp32
-// kernel).  With 128 + 128 registers per wave two waves share a SIMD: while one wave is in
-// its VALU epilogue, loads or stores, another one feeds the matrix pipe.
-// Wait states the compiler cannot see (cdna_hip_programming.md 5.7): v_accvgpr_write -> MFMA
-// operand (s_nop 1 in the first MFMA of every profile) and MFMA result -> VALU reader
-// (s_nop after the last MFMA of a profile).
-template <int R>
-__device__ __forceinline__ void mf_put(const f16x8 &v) {
-  const u32x4v u = __builtin_bit_cast(u32x4v, v);
-  asm volatile("v_accvgpr_write_b32 a[%c4], %0\n\tv_accvgpr_write_b32 a[%c5], %1\n\t"
-               "v_accvgpr_write_b32 a[%c6], %2\n\tv_accvgpr_write_b32 a[%c7], %3"
-               :
-               : "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]), "n"(R), "n"(R + 1), "n"(R + 2),
-                 "n"(R + 3));
-}
-// fragment (block ks, hi/lo) -> first register
-__host__ __device__ constexpr int mf_breg(int ks, int lo) { return MF_BREG + 4 * (ks * 2 + lo); }
-
-template <int R, bool FIRST>
-__device__ __forceinline__ void mf_mma(f32x16 &acc, const f16x8 &a) {
-  if constexpr (FIRST)
-    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, a[%c2:%c3], 0"
-                 : "=&v"(acc)
-                 : "v"(a), "n"(R), "n"(R + 3));
-  else
-    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[%c2:%c3], %0"
-                 : "+v"(acc)
-                 : "v"(a), "n"(R), "n"(R + 3));
-}
-
-__device__ __forceinline__ float mf_min(float a, float b) {
-  float r;  // plain v_min_f32: fminf() adds a canonicalising v_max per operand
-  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-
-// the 12 (narrow: window blocks 1..4) or 18 (wide: 0..5) MFMAs of one profile:
-// acc = Ah Bh + Ah Bl + Al Bh over the blocks; A fragments are requested a block ahead.  One
-// accumulator chain is enough: tools/mfma_rate.hip measures the same 32-cycle issue for 1, 2
-// and 4 chains.
-template <bool WIDE>
-__device__ __forceinline__ void mf_profile(const char *__restrict__ ak,
-                                           const char *__restrict__ a_next, f16x8 &ah, f16x8 &al,
-                                           f32x16 &acc) {
-  // (ah, al) arrive holding the fragments of this profile's first block and leave holding those
-  // of the next profile's first block (a_next): no LDS latency is exposed between profiles
-  constexpr int KS0 = WIDE ? 0 : 1, NKS = WIDE ? 6 : 4;
-  constexpr int LO = 8 * MF_COPY_BYTES;
-  mf_for<0, NKS>([&](auto ic) {
-    constexpr int g = decltype(ic)::value, ks = KS0 + g;
-    const char *src = g + 1 < NKS ? ak + (ks + 1) * 32 : a_next;
-    const f16x8 nh = *reinterpret_cast<const f16x8 *>(src);
-    const f16x8 nl = *reinterpret_cast<const f16x8 *>(src + LO);
-    mf_mma<mf_breg(ks, 0), g == 0>(acc, ah);
-    mf_mma<mf_breg(ks, 1), false>(acc, ah);
-    mf_mma<mf_breg(ks, 0), false>(acc, al);
-    ah = nh, al = nl;
-  });
-  asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc));  // MFMA result -> VALU reader
-}
-
-// running first-maximum / argmax / minimum over the profiles.  Accumulator register i of lane
-// (r, h) is channel z0 + (i&3) + 8 (i>>2) + 4 h; f[g] holds 1/sqrt(den) (times the unscaling
-// factor) of profile k for the lane's channels of group g.
-__device__ __forceinline__ void mf_epilogue(const f32x16 &acc, const f32x4v (&f)[4], int k,
-                                            f32x16 &best, int (&bk)[16], f32x16 &worst) {
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-#pragma unroll
-    for (int q = 0; q < 4; q += 2) {
-      const int i = 4 * g + q;
-      const f32x2 T2 = (f32x2){acc[i], acc[i + 1]} * (f32x2){f[g][q], f[g][q + 1]};  // v_pk_mul_f32
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const float T = e ? T2.y : T2.x;
-        const bool gt = T > best[i + e];  // strict '>' : the first maximum wins   (lib :1210)
-        best[i + e] = gt ? T : best[i + e];
-        bk[i + e] = gt ? k : bk[i + e];
-        worst[i + e] = mf_min(worst[i + e], T);
-      }
-    }
-  }
-}
-
-__global__ __launch_bounds__(64 * MF_WAVES, 1) void spectral_mfma_kernel(
-    const float *__restrict__ fsf, const float *__restrict__ rden, int NzP,
-    const uint4 *__restrict__ atab, const int *__restrict__ pwide, int K, int Nz, int Ny, int Nx,
-    int P, int zchunk, const uint8_t *__restrict__ mask, float *__restrict__ correl,
-    uint8_t *__restrict__ profile, float *__restrict__ correl_min, float *__restrict__ part_max,
-    float *__restrict__ part_min) {
-  extern __shared__ __align__(16) char mf_lds[];
-  // a[80:127] belong to the B fragments (the clobber makes the descriptor allocate 128 AGPRs;
-  // with inline-asm AGPR use hipcc splits the 256 registers of a wave 128 / 128 and parks its
-  // own long-lived scalars in the lowest AGPRs -- a[0:15] here, audited, far below)
-  asm volatile("" ::: "a80", "a127");
-  {
-    const int nvec = K * (MF_PROF_BYTES / 16);
-    for (int i = threadIdx.x; i < nvec; i += 64 * MF_WAVES)
-      reinterpret_cast<uint4 *>(mf_lds)[i] = atab[i];
-  }
-  __syncthreads();
-  const long S = (long)Ny * Nx;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int r = lane & 31, h = lane >> 5;
-  const long s_base = ((long)blockIdx.x * MF_WAVES + wv) * 32;
-  if (s_base >= S) return;  // whole wave; no barrier follows
-  const int zc0 = blockIdx.y * zchunk, zc1 = min(Nz, zc0 + zchunk);
-  const int E0 = 8 * h - r + 31;
-  const char *a_lane = mf_lds + (E0 & 7) * MF_COPY_BYTES + (E0 >> 3) * 16;
-  // this wave's [K][32] table of 1/sqrt(den) for the current tile (behind the tap copies)
-  char *rd_wave = mf_lds + K * MF_PROF_BYTES + wv * K * MF_RD_BYTES;
-  const char *rd_lane = rd_wave + 16 * h;  // channels 4h..4h+3 of each group of 8
-  const bool sv = s_base + r < S;
-  const long sc = sv ? s_base + r : S - 1;
-  float vmax = -INFINITY, vmin = INFINITY;
-  // Normalisation class of this lane's spaxel (how the field border clips the PSF window).
-  // Waves whose 32 spaxels are all interior read the interior table through LDS; a wave
-  // that touches the border fetches each lane's own class from the [cls][k][z] table (one
-  // 16-byte load per accumulator group, requested before the profile's MFMAs).
-  const int ccls = (P / 2) * P + P / 2;
-  int cls;
-  {
-    const int y = (int)(sc / Nx), xx = (int)(sc - (long)y * Nx);
-    cls = border_class(y, Ny, P) * P + border_class(xx, Nx, P);
-  }
-  const bool bwave = __any(cls != ccls);
-  const float *rdi = rden + (long)ccls * K * NzP;
-  const float *rdb = rden + (long)cls * K * NzP + 4 * h;
-
-  for (int z0 = zc0; z0 < zc1; z0 += 32) {
-    // ---- 1/sqrt(den)[k][z0 .. z0+31]: requested now, written to LDS (times the unscaling
-    // factor) once the tile's scale is known
-    float rv[MF_MAX_K / 2];
-#pragma unroll
-    for (int q = 0; q < MF_MAX_K / 2; ++q) {
-      const int i = lane + 64 * q;
-      rv[q] = i < K * 32 ? rdi[(long)(i >> 5) * NzP + z0 + (i & 31)] : 0.0f;
-    }
-    // ---- window X[z0-32 .. z0+63] in B-fragment order: lane (r, h) holds rows 16 ks + 8 h + j
-    float x[6][8];
-    const int zb = z0 - 32 + 8 * h;
-    if (z0 - 32 >= 0 && z0 + 64 <= Nz) {
-      const float *p = fsf + (long)zb * S + sc;
-#pragma unroll
-      for (int ks = 0; ks < 6; ++ks)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) x[ks][j] = p[(long)(16 * ks + j) * S];
-    } else {
-#pragma unroll
-      for (int ks = 0; ks < 6; ++ks)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int zz = zb + 16 * ks + j;
-          const bool in = zz >= 0 && zz < Nz;
-          const float v = fsf[(long)(in ? zz : 0) * S + sc];
-          x[ks][j] = in ? v : 0.0f;
-        }
-    }
-    // ---- power-of-two scale of this tile: max |y| in [2^14, 2^15)
-    float m = 0.0f;
-#pragma unroll
-    for (int ks = 0; ks < 6; ++ks)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(sv ? x[ks][j] : 0.0f));
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    const int ex = (int)((__float_as_uint(m) >> 23) & 0xffu);
-    const bool tiny = ex < 40 || ex == 255;  // zero / denormal-small / non-finite: no scaling
-    const float scale = __uint_as_float((unsigned)(tiny ? 127 : 268 - ex) << 23);
-    // 2^-(e + MF_TAP_SCALE_LOG2): undoes both scalings, exactly
-    const float inv = __uint_as_float((unsigned)(tiny ? 127 - MF_TAP_SCALE_LOG2
-                                                      : ex - 14 - MF_TAP_SCALE_LOG2) << 23);
-    // (this wave's readers of the previous tile's table are done: same wave, in order)
-#pragma unroll
-    for (int q = 0; q < MF_MAX_K / 2; ++q) {
-      const int i = lane + 64 * q;
-      if (i < K * 32) reinterpret_cast<float *>(rd_wave)[i] = rv[q] * inv;
-    }
-    // ---- split into f16 hi + lo and park the fragments in a[80:127]
-    mf_for<0, 6>([&](auto ic) {
-      constexpr int ks = decltype(ic)::value;
-      f16x8 yh8, yl8;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float y = x[ks][j] * scale;
-        const _Float16 yh = (_Float16)y;
-        yh8[j] = yh;
-        yl8[j] = (_Float16)(y - (float)yh);
-      }
-      mf_put<mf_breg(ks, 0)>(yh8);
-      mf_put<mf_breg(ks, 1)>(yl8);
-    });
-
-    // accumulator register i of lane (r, h) is channel z0 + (i&3) + 8 (i>>2) + 4 h
-    f32x16 best, worst;
-    int bk[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) best[i] = -INFINITY, worst[i] = INFINITY, bk[i] = 0;
-    auto first_block = [&](int k) -> const char * {  // A fragments of profile k's first block
-      const int kk = k < K ? k : 0;
-      return a_lane + kk * MF_PROF_BYTES + (pwide[kk] ? 0 : 32);
-    };
-    f16x8 ah, al;
-    {
-      const char *p0 = first_block(0);
-      ah = *reinterpret_cast<const f16x8 *>(p0);
-      al = *reinterpret_cast<const f16x8 *>(p0 + 8 * MF_COPY_BYTES);
-    }
-    for (int k = 0; k < K; ++k) {
-      f32x16 acc;
-      f32x4v f[4];
-      // 1/sqrt(den) of this profile: requested before its MFMAs, used after them
-      if (bwave) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          f[g] = *reinterpret_cast<const f32x4v *>(rdb + (long)k * NzP + z0 + 8 * g);
-      } else {
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          f[g] = *reinterpret_cast<const f32x4v *>(rd_lane + k * MF_RD_BYTES + 32 * g);
-      }
-      const char *ak = a_lane + k * MF_PROF_BYTES;
-      const char *an = first_block(k + 1);
-      if (pwide[k]) mf_profile<true>(ak, an, ah, al, acc);
-      else mf_profile<false>(ak, an, ah, al, acc);
-      if (bwave) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) f[g] *= inv;
-      }
-      mf_epilogue(acc, f, k, best, bk, worst);
-    }
-    // ---- store, mask glue (steps.py:781,788)
-    unsigned char mk[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) mk[i] = 0;
-    if (mask) {  // branch-free inside: every load is issued before the first is awaited
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int zz = min(z0 + (i & 3) + 8 * (i >> 2) + 4 * h, Nz - 1);
-        mk[i] = mask[(long)zz * S + sc];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int zz = z0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-      if (zz < zc1) {
-        const long idx = (long)zz * S + sc;
-        float b = best[i];
-        int kk = bk[i];
-        if (mk[i]) b = 0.0f, kk = 0;
-        if (sv) {
-          correl[idx] = b;
-          correl_min[idx] = worst[i];
-          profile[idx] = (uint8_t)kk;
-        }
-        vmax = fmaxf(vmax, b);
-        vmin = fminf(vmin, worst[i]);
-      }
-    }
-  }
-  if (part_max) {
-    const float a = fmaxf(vmax, __shfl_xor(vmax, 32));
-    const float b = fminf(vmin, __shfl_xor(vmin, 32));
-    if (h == 0 && sv) {
-      part_max[(long)blockIdx.y * S + sc] = a;
-      part_min[(long)blockIdx.y * S + sc] = b;
-    }
-  }
-}
-
 // fallback for profiles wider than the register window: plain loops over global memory
 template <bool GENERAL>
 __global__ __launch_bounds__(256) void spectral_generic_kernel(
@@ -1148,9 +850,10 @@ int origin_glr_plan_destroy(origin_glr_plan *plan) {
   for (void *p : {(void *)plan->d_k, (void *)plan->d_k2, (void *)plan->d_w, (void *)plan->d_taps,
                   (void *)plan->d_taps2, (void *)plan->d_tap_off, (void *)plan->d_rden,
                   (void *)plan->d_htaps, (void *)plan->d_htap_off, (void *)plan->d_rows,
-                  (void *)plan->d_border, (void *)plan->d_atab,
-                  (void *)plan->d_pwide})
+                  (void *)plan->d_border, (void *)plan->d_atab, (void *)plan->d_atab_bf16,
+                  (void *)plan->d_pwide, (void *)plan->d_rdi_s})
     if (p) (void)hipFree(p);
+  delete plan->h_order;
   delete plan;
   return ORIGIN_OK;
 }
@@ -1261,30 +964,50 @@ int origin_glr_plan_create(origin_ctx *ctx, int Nz, int Ny, int Nx, int nfields,
     TRY(upload(ctx, rows, &pl->d_rows, &pl->bytes));
     pl->lwt = lwt;
   }
-  // spectral_mfma_kernel: padded tap arrays G_k[e] = p_k[lw_k + 63 - e], e = 0..(8 MF_GROUPS + 6),
-  // split into f16 hi + lo (times 2^MF_TAP_SCALE_LOG2), 8 copies shifted by 0..7 elements
+  // matrix-core spectral stage: padded tap arrays G_k[e] = p_k[lw_k + 63 - e], 8 copies shifted
+  // by 0..7 elements (glr_tables.h), profiles in processing order (narrow ones -- half width
+  // <= 16: window blocks 1..4 -- first, so that the kernel's profile pairs are narrow/narrow,
+  // at most one narrow/wide, wide/wide); f16 hi + lo (times 2^MF_TAP_SCALE_LOG2) and bf16
   if (lwmax <= 32 && K <= MF_MAX_K && pl->mode == 0) {
+    std::vector<int> order(K), pinfo(K, 0);
+    for (int kk = 0; kk < K; ++kk) order[kk] = kk;
+    auto lw_of = [&](int kk) { return (off[kk + 1] - off[kk] - 1) / 2; };
+    std::stable_sort(order.begin(), order.end(),
+                     [&](int a, int b) { return (lw_of(a) > 16) < (lw_of(b) > 16); });
     std::vector<_Float16> at((size_t)K * MF_PROF_BYTES / 2, (_Float16)0.0f);
-    std::vector<int> pwide(K, 0);
+    std::vector<unsigned short> ab((size_t)K * MF_PROF_BYTES / 2, 0);
     const float tscale = (float)(1 << MF_TAP_SCALE_LOG2);
-    for (int kk = 0; kk < K; ++kk) {
+    auto to_bf16 = [](float v) -> unsigned short {  // round to nearest even
+      unsigned u;
+      memcpy(&u, &v, 4);
+      if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+      return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    };
+    for (int slot = 0; slot < K; ++slot) {
+      const int kk = order[slot];
       const int L = off[kk + 1] - off[kk], lw = (L - 1) / 2;
-      pwide[kk] = lw > 16;
+      pinfo[slot] = kk | ((lw > 16) << 8);
       for (int c = 0; c < 8; ++c)
         for (int q = 0; q < MF_GROUPS; ++q)
           for (int j = 0; j < 8; ++j) {
             const int e = 8 * q + c + j, ti = lw + 63 - e;
-            const float g = (ti >= 0 && ti < L) ? taps[off[kk] + ti] * tscale : 0.0f;
+            const float t = (ti >= 0 && ti < L) ? taps[off[kk] + ti] : 0.0f;
+            const float g = t * tscale;
             const _Float16 gh = (_Float16)g;
             const _Float16 gl = (_Float16)(g - (float)gh);
-            const size_t base = (size_t)kk * (MF_PROF_BYTES / 2) + (size_t)c * (MF_COPY_BYTES / 2) +
-                                (size_t)q * 8 + j;
+            const size_t base = (size_t)slot * (MF_PROF_BYTES / 2) +
+                                (size_t)c * (MF_COPY_BYTES / 2) + (size_t)q * 8 + j;
             at[base] = gh;
             at[base + 8 * (MF_COPY_BYTES / 2)] = gl;
+            ab[base] = to_bf16(t);
           }
     }
     TRY(upload(ctx, at, (_Float16 **)&pl->d_atab, &pl->bytes));
-    TRY(upload(ctx, pwide, &pl->d_pwide, &pl->bytes));
+    TRY(upload(ctx, ab, (unsigned short **)&pl->d_atab_bf16, &pl->bytes));
+    TRY(upload(ctx, pinfo, &pl->d_pwide, &pl->bytes));
+    pl->n_narrow = 0;
+    for (int slot = 0; slot < K; ++slot) pl->n_narrow += (pinfo[slot] >> 8) == 0;
+    pl->h_order = new std::vector<int>(order);
     pl->precision = getenv("ORIGIN_GLR_FP32") ? 0 : 1;
   }
   // scalar loads may read a few taps past the end of a profile row: pad
@@ -1329,6 +1052,14 @@ int origin_glr_plan_create(origin_ctx *ctx, int Nz, int Ny, int Nx, int nfields,
     e = hipGetLastError();
     // the interior class is a slice of the table
     pl->d_rdi = pl->d_rden + (size_t)((P / 2) * P + P / 2) * K * pl->NzP;
+    if (e == hipSuccess && pl->h_order) {  // the same slice in the kernel's processing order
+      e = hipMalloc((void **)&pl->d_rdi_s, (size_t)K * pl->NzP * sizeof(float));
+      pl->bytes += (size_t)K * pl->NzP * sizeof(float);
+      for (int slot = 0; slot < K && e == hipSuccess; ++slot)
+        e = hipMemcpyAsync(pl->d_rdi_s + (size_t)slot * pl->NzP,
+                           pl->d_rdi + (size_t)(*pl->h_order)[slot] * pl->NzP,
+                           pl->NzP * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(ncls);
     if (e != hipSuccess) {
@@ -1343,8 +1074,9 @@ int origin_glr_plan_create(origin_ctx *ctx, int Nz, int Ny, int Nx, int nfields,
 }
 
 int origin_glr_plan_set_precision(origin_glr_plan *plan, int precision) {
-  ORIGIN_CHECK_ARG(plan && (precision == 0 || precision == 1), "precision must be 0 or 1");
-  plan->precision = (precision == 1 && plan->d_atab) ? 1 : 0;
+  ORIGIN_CHECK_ARG(plan && precision >= 0 && precision <= 2, "precision must be 0, 1 or 2");
+  // the matrix-core stages need the plan's tap tables (weights=None, half widths <= 32)
+  plan->precision = plan->d_atab ? precision : 0;
   return ORIGIN_OK;
 }
 
@@ -1364,8 +1096,9 @@ int origin_glr_work_elems(origin_glr_plan *plan, size_t *elems) {
   ORIGIN_CHECK_ARG(plan && elems, "null argument");
   const size_t cube = (size_t)plan->Nz * plan->Ny * plan->Nx;
   const size_t S = (size_t)plan->Ny * plan->Nx;
-  // cube_fsf (+ norm_fsf in mode 1) + maxmap/minmap partials (<= 64 chunks each)
-  *elems = cube * (plan->mode == 1 ? 2 : 1) + 2 * 64 * S;
+  // zero pad + cube_fsf + zero pad (+ norm_fsf in mode 1) + maxmap/minmap partials (<= 64 chunks
+  // each)
+  *elems = cube * (plan->mode == 1 ? 2 : 1) + 2 * 64 * S + (MF_PAD_FRONT + MF_PAD_BACK) * S;
   return ORIGIN_OK;
 }
 
@@ -1379,9 +1112,13 @@ int origin_glr_run(origin_ctx *ctx, origin_glr_plan *pl, const float *d_cube,
   const int Nz = pl->Nz, Ny = pl->Ny, Nx = pl->Nx, P = pl->P, K = pl->K;
   const long S = (long)Ny * Nx;
   const size_t cube = (size_t)Nz * S;
-  float *fsf = d_work;
-  float *norm = pl->mode == 1 ? d_work + cube : nullptr;
-  float *part = d_work + cube * (pl->mode == 1 ? 2 : 1);
+  // [pad | cube_fsf | pad | norm_fsf (mode 1) | partial maps]; the pads are zero channels
+  float *fsf = d_work + (size_t)MF_PAD_FRONT * S;
+  float *after = fsf + cube + (size_t)MF_PAD_BACK * S;
+  float *norm = pl->mode == 1 ? after : nullptr;
+  float *part = after + (pl->mode == 1 ? cube : 0);
+  ORIGIN_HIP(hipMemsetAsync(d_work, 0, (size_t)MF_PAD_FRONT * S * sizeof(float), ctx->stream));
+  ORIGIN_HIP(hipMemsetAsync(fsf + cube, 0, (size_t)MF_PAD_BACK * S * sizeof(float), ctx->stream));
 
   // ---- spatial stage
   auto spatial = [&](const float *A, const float *B, const float *taps, int acc, float *dst) {
@@ -1424,7 +1161,7 @@ int origin_glr_run(origin_ctx *ctx, origin_glr_plan *pl, const float *d_cube,
     ProfScope ps(ctx, K_GLR_SPATIAL);
     const float *kf = pl->d_k + (size_t)f * Nz * P * P;
     const float *wf = pl->d_w ? pl->d_w + (size_t)f * S : nullptr;
-    if (pl->mode == 0 && pl->precision == 1 && !wf && pl->nfields == 1 &&
+    if (pl->mode == 0 && pl->precision >= 1 && !wf && pl->nfields == 1 &&
         origin_spatial_mfma_ok(Ny, Nx, P)) {
       // matrix cores, two-term f16 split (glr_spatial_mfma.hip)
       int rc = origin_spatial_mfma_launch(ctx, d_cube, kf, Nz, Ny, Nx, P, fsf);
@@ -1458,30 +1195,15 @@ int origin_glr_run(origin_ctx *ctx, origin_glr_plan *pl, const float *d_cube,
   bool border_fix = false;
   {
   ProfScope ps(ctx, K_GLR_SPECTRAL);
-  const bool mfma = !gen && pl->precision == 1 && pl->d_atab && pl->d_rdi;
+  const bool mfma = !gen && pl->precision >= 1 && pl->d_atab && pl->d_rdi;
   const bool packed = !mfma && !gen && (S & 1) == 0 && pl->lwt;
   if (mfma) {
-    // matrix-core path: a wave = 64 spaxels x 32-channel tiles; z chunks sized to give every CU
-    // several blocks (one 4-wave block per CU at a time: K * 4.5 KiB of LDS)
-    const long bx = cdiv(S, 32 * MF_WAVES);
-    int nzm = (int)(((long)ctx->num_cu * 8 + bx - 1) / bx);
-    nzm = std::max(1, std::min(nzm, std::min(64, cdiv(Nz, 64))));
-    int zcm = (cdiv(Nz, nzm) + 31) / 32 * 32;
-    nzm = cdiv(Nz, zcm);
-    nzc = nzm;
-    pmax = want_maps ? part : nullptr;
-    pmin = want_maps ? part + (size_t)nzc * S : nullptr;
-    const size_t lds = (size_t)K * (MF_PROF_BYTES + MF_WAVES * MF_RD_BYTES);
-    static bool attr_done = false;
-    if (!attr_done) {
-      ORIGIN_HIP(hipFuncSetAttribute((const void *)spectral_mfma_kernel,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     MF_MAX_K * (MF_PROF_BYTES + MF_WAVES * MF_RD_BYTES)));
-      attr_done = true;
-    }
-    hipLaunchKernelGGL(spectral_mfma_kernel, dim3((unsigned)bx, nzm), dim3(64 * MF_WAVES), lds, ctx->stream,
-                       fsf, pl->d_rden, pl->NzP, pl->d_atab, pl->d_pwide, K, Nz, Ny, Nx, P, zcm,
-                       d_mask, d_correl, d_profile, d_correl_min, pmax, pmin);
+    int rc = origin_spectral_mfma_launch(
+        ctx, pl->precision == 2 ? 1 : 3, fsf, pl->d_rden, pl->d_rdi_s, pl->NzP,
+        pl->precision == 2 ? pl->d_atab_bf16 : pl->d_atab, pl->d_pwide, K, pl->n_narrow, Nz, Ny, Nx,
+        P, d_mask,
+        d_correl, d_profile, d_correl_min, part, want_maps, &nzc, &pmax, &pmin);
+    if (rc) return rc;
   } else if (packed) {
     // packed path: one lane = two adjacent spaxels, SPEC_ZC channels per step
     dim3 g2(cdiv(S / 2, 256), nzc);

@@ -1,0 +1,26 @@
+// Layout of the LDS tap table of the matrix-core spectral GLR stage, shared by the plan builder
+// (glr.hip) and the kernel (glr_spectral_mfma.hip).
+//
+// Per profile (in the order the kernel processes them: narrow ones first), the padded tap array
+// G_k[e] = p_k[lw_k + 63 - e], e = 0 .. 8 MF_GROUPS + 6, as 8 copies shifted by 0..7 elements --
+// so that the 8 consecutive entries a lane needs for an A fragment are ONE aligned 16-byte read
+// -- first the "hi" halves of all 8 copies, then the "lo" halves (two-term f16 split, taps times
+// 2^MF_TAP_SCALE_LOG2; the bf16 table holds the rounded taps in the hi half and zeros in lo).
+#pragma once
+
+constexpr int MF_TAP_SCALE_LOG2 = 12;                 // f16 taps are stored times 2^12
+constexpr int MF_GROUPS = 20;                         // 16-byte groups per shifted copy (15 used)
+constexpr int MF_COPY_BYTES = MF_GROUPS * 16;         // 320 = 256 + 64: conflict-free ds_read_b128
+constexpr int MF_PROF_BYTES = 2 * 8 * MF_COPY_BYTES;  // hi copies, then lo copies
+constexpr int MF_RD_BYTES = 32 * 4;                   // per wave and profile: 32 channels of 1/sqrt(den)
+constexpr int MF_WAVES = 8;                           // waves per block (two per SIMD)
+constexpr int MF_MAX_K = 26;                          // 26 * (5120 + 8 * 128) B = 156 KiB of LDS
+// zero channels in front of / behind the cube_fsf work cube: the matrix-core spectral kernel reads
+// its 96-channel windows [z0 - 32, z0 + 63] without bounds tests
+constexpr int MF_PAD_FRONT = 32, MF_PAD_BACK = 64;
+
+int origin_spectral_mfma_launch(origin_ctx *ctx, int terms, const float *fsf, const float *rden,
+                                const float *rdi_s, int NzP, const uint4 *atab, const int *pinfo, int K,
+                                int nN, int Nz, int Ny, int Nx, int P, const uint8_t *mask, float *correl,
+                                uint8_t *profile, float *correl_min, float *part, bool want_maps,
+                                int *nzc_out, float **pmax_out, float **pmin_out);

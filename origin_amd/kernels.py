@@ -102,12 +102,15 @@ class GLRPlan:
     """Device-side constants of a GLR run: zero-mean PSFs, weights, prepared profiles and
     normalisation tables (include/origin_hip.h: origin_glr_plan)."""
 
+    PRECISIONS = ("f32", "f16x2", "bf16")   # origin_glr_plan_set_precision codes 0, 1, 2
+
     def __init__(self, ctx, shape, fsf, weights, profiles, pcut=None, pmeansub=True,
                  precision=None):
-        """``precision``: None = library default, "f16x2" = spectral stage on the matrix cores
-        (two-term f16 split, fp32 accumulation), "f32" = fp32 FMA kernels.  ``self.precision``
-        tells what the plan will run (plans with weight maps or very wide profiles only have
-        "f32")."""
+        """``precision``: None = library default ("f16x2" where eligible), "f16x2" = both GLR stages
+        on the matrix cores with a two-term f16 split (fp32 accumulation, fp32-class results),
+        "bf16" = spectral stage with ONE bf16 MFMA per product (BASELINE config 4: SURVEY 8c
+        bf16 tolerances), "f32" = fp32 FMA kernels.  ``self.precision`` tells what the plan will
+        run (plans with weight maps or very wide profiles only have "f32")."""
         Nz, Ny, Nx = (int(s) for s in shape)
         self.ctx, self.shape = ctx, (Nz, Ny, Nx)
         if weights is None:  # one FSF                         (lib_origin.py:1112-1114)
@@ -144,14 +147,14 @@ class GLRPlan:
         self.nbytes = n.value
         self._work = None
         if precision is not None:
-            if precision not in ("f32", "f16x2"):
-                raise ValueError("precision must be None, 'f32' or 'f16x2'")
-            _capi.call("origin_glr_plan_set_precision", self._h, int(precision == "f16x2"))
+            if precision not in self.PRECISIONS:
+                raise ValueError("precision must be None, 'f32', 'f16x2' or 'bf16'")
+            _capi.call("origin_glr_plan_set_precision", self._h, self.PRECISIONS.index(precision))
         got = C.c_int()
         _capi.call("origin_glr_plan_get_precision", self._h, C.byref(got))
-        self.precision = "f16x2" if got.value == 1 else "f32"
+        self.precision = self.PRECISIONS[got.value]
         # mirrors origin_spatial_mfma_ok (csrc/glr_spatial_mfma.hip): which spatial kernel runs
-        self.spatial_on_matrix_cores = (self.precision == "f16x2" and w is None and
+        self.spatial_on_matrix_cores = (self.precision != "f32" and w is None and
                                         self.P <= 25 and (self.P // 2) % 4 == 0 and Nx % 4 == 0)
 
     def close(self):

@@ -264,6 +264,68 @@ def test_glr_matrix_core_spatial_stage(ctx, shape, P):
     assert np.max(np.abs(got["f16x2"] - got["f32"])) <= 1e-4
 
 
+def test_glr_bf16_precision_meets_the_bf16_tolerance(ctx):
+    """precision="bf16" (BASELINE config 4): one bf16 MFMA per product in the spectral stage.
+    SURVEY 8c tolerance for bf16 operands with wide accumulation: |dT| <= 5e-2, rms <= 5e-3,
+    arg-max mismatches <= 2 % and only where the two best profiles are closer than 5e-2."""
+    from origin_amd import kernels
+    rng = np.random.default_rng(12)
+    Nz, Ny, Nx = 300, 40, 44
+    cube = rng.standard_normal((Nz, Ny, Nx)).astype(np.float32)
+    cube[150, 20, 22] += 30.0
+    psf = synth.moffat_psf(Nz, 25).astype(np.float64)
+    prof = synth.dico_fwhm(20)
+    ref = cpu_ref.Correlation_GLR_test(cube.astype(np.float64), psf, None, prof, nthreads=1,
+                                       pcut=1e-8, pmeansub=True)
+    plan = kernels.GLRPlan(ctx, cube.shape, psf, None, prof, 1e-8, True, precision="bf16")
+    assert plan.precision == "bf16"
+    out = plan.run(ctx.to_device(cube), mask=None, want_maps=True)
+    T, Tmin, arg = out["correl"].to_host(), out["correl_min"].to_host(), out["profile"].to_host()
+    d = T - ref[0]
+    assert np.max(np.abs(d)) <= 5e-2 and np.sqrt(np.mean(d * d)) <= 5e-3
+    assert np.max(np.abs(Tmin - ref[2])) <= 5e-2
+    wrong = arg != ref[1]
+    assert wrong.mean() <= 0.02
+    # a wrong index only where the runner-up is within 5e-2: T at the device's index is that close
+    # to the true maximum by the bound above
+    assert np.max(np.abs(out["maxmap"].to_host() - ref[0].max(axis=0))) <= 5e-2
+    plan.close()
+    # and it is really a different arithmetic from the fp32-class path
+    plan = kernels.GLRPlan(ctx, cube.shape, psf, None, prof, 1e-8, True, precision="f16x2")
+    T2 = plan.run(ctx.to_device(cube), mask=None, want_maps=False)["correl"].to_host()
+    plan.close()
+    assert np.max(np.abs(T2 - ref[0])) <= 1e-4 < np.max(np.abs(d))
+
+
+@pytest.mark.parametrize("nprof,expect", [(20, "even"), (3, "odd tail"), (5, "mixed pair"),
+                                          (7, "mixed pair + odd tail"), (2, "two"), (1, "one")])
+def test_glr_matrix_core_profile_list_shapes(ctx, nprof, expect):
+    """The spectral kernel's stage sequence is compiled per shape of the profile list (narrow
+    profiles first, in pairs; one mixed pair; an odd one out): every variant against the
+    oracle, with the first-maximum rule checked exactly by duplicating a profile."""
+    from origin_amd import kernels
+    rng = np.random.default_rng(nprof)
+    Nz, Ny, Nx = 130, 26, 36
+    cube = rng.standard_normal((Nz, Ny, Nx)).astype(np.float32)
+    cube[:, 3, 4:9] = 0.0                 # spaxels of zeros: every T equal -> index 0
+    psf = synth.moffat_psf(Nz, 25).astype(np.float64)
+    prof = synth.dico_fwhm(nprof) if nprof > 1 else synth.dico_fwhm(3)[1:2]
+    if nprof == 5:
+        prof = list(prof) + [prof[1]]     # a duplicate: ties must go to the FIRST index
+    ref = cpu_ref.Correlation_GLR_test(cube.astype(np.float64), psf, None, prof, nthreads=1,
+                                       pcut=1e-8, pmeansub=True)
+    plan = kernels.GLRPlan(ctx, cube.shape, psf, None, prof, 1e-8, True, precision="f16x2")
+    assert plan.precision == "f16x2"
+    out = plan.run(ctx.to_device(cube), mask=None, want_maps=False)
+    assert np.max(np.abs(out["correl"].to_host() - ref[0])) <= 1e-4
+    assert np.max(np.abs(out["correl_min"].to_host() - ref[2])) <= 1e-4
+    arg = out["profile"].to_host()
+    assert np.mean(arg != ref[1]) <= 1e-4
+    if nprof == 5:
+        assert not np.any(arg == 5)       # the duplicate (index 5) never beats index 1
+    plan.close()
+
+
 def test_glr_f16_split_survives_huge_dynamic_range(ctx):
     """Per-tile power-of-two scaling: slabs of channels at 1e-6, 1 and 1e+7 times unit noise must
     neither overflow the f16 halves nor lose the faint slabs.  Error bound relative to the
