@@ -96,8 +96,8 @@ int origin_scratch(origin_ctx *ctx, size_t bytes, void **out);
 
 // glr_spatial_mfma.hip: matrix-core spatial GLR stage (one field, no weight map)
 int origin_spatial_mfma_ok(int Ny, int Nx, int P);
-int origin_spatial_mfma_launch(origin_ctx *ctx, const float *A, const float *taps, int Nz, int Ny,
-                               int Nx, int P, float *out);
+int origin_spatial_mfma_launch(origin_ctx *ctx, int terms, const float *A, const float *taps,
+                               int Nz, int Ny, int Nx, int P, float *out);
 
 #define ORIGIN_CHECK_ARG(cond, ...)       \
   do {                                    \

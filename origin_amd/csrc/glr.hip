@@ -1164,7 +1164,8 @@ int origin_glr_run(origin_ctx *ctx, origin_glr_plan *pl, const float *d_cube,
     if (pl->mode == 0 && pl->precision >= 1 && !wf && pl->nfields == 1 &&
         origin_spatial_mfma_ok(Ny, Nx, P)) {
       // matrix cores, two-term f16 split (glr_spatial_mfma.hip)
-      int rc = origin_spatial_mfma_launch(ctx, d_cube, kf, Nz, Ny, Nx, P, fsf);
+      int rc = origin_spatial_mfma_launch(ctx, pl->precision == 2 ? 1 : 3, d_cube, kf, Nz, Ny, Nx, P,
+                                          fsf);
       if (rc) return rc;
       continue;
     }

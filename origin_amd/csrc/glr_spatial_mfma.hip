@@ -2,272 +2,360 @@
 // for one field without weight map:  cube_fsf[z] = corr2(cube[z], psf_z - mean(psf_z)), 'same',
 // zeros outside the field).
 //
-// For one channel and a tile of 32 output columns x0..x0+31 and 32 output rows y0..y0+31
-//     out[y0+n][x0+m] = sum_dy sum_i A_dy[m][i] X_dy[i][n]
-//     A_dy[m][i] = k[dy][i - m]              (0 <= i - m < P, banded Toeplitz, 32 x 64)
-//     X_dy[i][n] = in[y0 + n + dy - c][x0 - c + i]
-// i.e. P accumulated [32 x 64] x [64 x 32] products: the x axis of the kernel becomes the K
-// dimension of an MFMA, the y axis stays an outer sum whose B operand is the input tile read
-// one row lower each time.  As in spectral_mfma_kernel the product runs on
-// v_mfma_f32_32x32x16_f16 with a two-term f16 split of both operands (data scaled by a power of
-// two per block and channel, taps by 2^12; Ah Bh + Ah Bl + Al Bh, fp32 accumulation).
+// Round 1 put only the x axis of the PSF on the K dimension of the MFMA (banded Toeplitz, 32
+// outputs against a 64-column window: 25 of 64 products useful, 300 MFMAs per 1024 outputs).
+// Here BOTH axes are: an M tile is a PATCH of 8 (x) by 4 (y) outputs, its K dimension the
+// (8 + P - 1) x (4 + P - 1) input window around it (32 x 28 for P = 25), so that for output
+// m = (my, mx) and window pixel k = (wy, wx)
+//     A[m][k] = psf[wy - my][wx - mx]        (zero outside the P x P support)
+//     B[k][n] = in[oy_n + wy][ox_n + wx]     (n = one of 32 patch origins, 8 apart in x, 4 in y)
+// -- 625 of 896 products useful, 56 k-steps of 16 = 168 MFMAs (three per k-step, two-term f16
+// split as everywhere in the GLR) per 1024 outputs instead of 300.  A wave owns a 32 x 32 output
+// area = 4 x 8 patches; a k-step is half a window row (16 consecutive wx: lane half h takes 8).
+//   * B fragments are 16-byte reads of an f16 image of the input region in LDS (row pitch =
+//     16 mod 64 bytes: the 16 lanes a ds_read_b128 serves at once fall on distinct banks);
+//   * A fragments are 16-byte reads of a per-channel table: for every kernel row 8 copies of
+//     the zero-padded row shifted by 0..7 elements (entry pitch 80 bytes: conflict free), rows
+//     -3..-1 and P..P+2 all zero for the outputs of a patch whose my puts wy - my outside.
 //
-// A block (8 waves, two per SIMD) owns a 128 x 64 region (two of them, stacked in y, sharing
-// the channel's fragment table) of one channel at a time and marches z.  Per channel it (1) converts the (128+P-1) x (64+P-1) input tile -- staged in registers
-// while the previous channel was computed -- to f16 hi/lo images in LDS (row pitch 19 x 16 B:
-// the 16-byte B-fragment reads of a lane group fall on distinct banks), (2) expands the P x P
-// taps into the Toeplitz fragment table: per kernel row 8 copies of the zero-padded tap array
-// shifted by 0..7 elements, so that the A fragment of any (lane, k-step) is one aligned
-// ds_read_b128 (pitch between copies = 64 mod 256 B: conflict free), (3) runs P x 4 k-steps x 3
-// MFMAs per wave, four 16-byte LDS reads per 3 MFMAs (LDS sustains two ds_read_b128 per MFMA
-// slot and SIMD; MI355X_MICROARCH.md, LDS), no VALU work in the loop, (4) stores the 32 x 32
-// tile.  Only eligible shapes come here (P <= 25, P/2 and Nx multiples of 4); everything else
-// -- weight maps, several fields, other PSF sizes -- stays on spatial4x4_kernel / spatial_kernel.
+// The PSF differs per channel, so image AND table change with every channel.  A block (8 waves
+// = two groups of 4) owns a 64 x 64 region and marches z; the groups take alternate channels and
+// alternate ROLES, separated by one block barrier per phase: while one group issues the 168
+// MFMAs of its channel (one wave per SIMD: the matrix pipe's full rate), the other converts its
+// next channel's input tile to the f16 hi / lo images and builds its table (VALU + LDS writes:
+// ~2200 cycles against ~5400), then they swap.  Global loads of the tile after next and its
+// taps are issued at the start of a group's MFMA phase and land in registers; the tile's
+// power-of-two scale (max |x|) is reduced at the end of that phase, so the conversion phase
+// starts with everything at hand.  LDS: 2 x (36.6 KB images + 39.7 KB table + 2.5 KB taps).
+//
+// TERMS = 1: bf16 operands, one MFMA per k-step (BASELINE config 4's bf16 GLR), no scaling.
+//
+// Eligible shapes: P in {9, 17, 25}, Nx % 4 == 0 (16-byte tile loads); everything else -- weight
+// maps, several fields, other PSF sizes -- stays on spatial4x4_kernel / spatial_kernel.
 #include <algorithm>
 
 #include "common.h"
 
 namespace {
 
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int SM_PMAX = 25;
-constexpr int SM_RX = 128, SM_RY = 64;          // region of a block
-constexpr int SM_IW = SM_RX + SM_PMAX - 1;      // 152 input columns
-constexpr int SM_IH = SM_RY + SM_PMAX - 1;      // 88 input rows
-constexpr int SM_PITCH = 304;                   // bytes per image row: 152 f16 = 19 x 16 B (odd)
-constexpr int SM_IMG = SM_IH * SM_PITCH + 32;   // one f16 image (hi or lo) + pad (a window of
-                                                // the last wave column runs 8 columns past a row)
-constexpr int SM_GROUPS = 12;                   // 16-byte groups of a shifted tap copy
-constexpr int SM_TAP_LOG2 = 12;
-constexpr int SM_NQ = (SM_IW / 4 * SM_IH + 511) / 512;  // staged float4 per thread (7)
+constexpr int S2_R = 64;           // region side (outputs) of a block
+constexpr int S2_TAP_LOG2 = 12;    // f16 taps are stored times 2^12
+constexpr int S2_ENTRY = 80;       // bytes of one (row, copy) table entry: 40 taps, 5 groups of 8
 
-// Fragment table (bytes): offset(copy, dy, hl, q) = copy * sm_copy_all(P) + (2 dy + hl) * 192 + 16 q;
-// the pitch between the 8 shifted copies is 64 mod 256 (the lanes of a ds_read_b128 group differ
-// in copy and q: with this pitch their 16-byte slots are distinct modulo the 64 banks).
-__host__ __device__ constexpr int sm_copy_all(int P) {
-  const int raw = P * 2 * SM_GROUPS * 16;
-  return (raw + 255) / 256 * 256 + 64;
+template <int P>
+struct S2Geom {
+  static constexpr int H = P - 1;                       // halo
+  static constexpr int IW = S2_R + H, IH = S2_R + H;    // input tile
+  static constexpr int WROWS = 4 + H;                   // window rows of a patch
+  static constexpr int WCOLS = 8 + H;                   // window columns (<= 32)
+  static constexpr int KROW = (WCOLS + 15) / 16;        // k-steps per window row
+  static constexpr int NKS = WROWS * KROW;              // k-steps per channel
+  static constexpr int PITCH = ((IW * 2 + 63) / 64) * 64 + 16;  // bytes, = 16 mod 64, > 2 IW
+  static constexpr int IMG = IH * PITCH;                // one f16 / bf16 image
+  static constexpr int TROWS = P + 6;                   // table rows: dy = -3 .. P + 2
+  static constexpr int TAB = TROWS * 8 * S2_ENTRY;      // one table (hi or lo)
+  static constexpr int NQ = (IW / 4 * IH + 255) / 256;  // staged float4 per thread of a group
+  static constexpr int NT = (P * P + 255) / 256;        // staged taps per thread
+  static constexpr int TAPS = (P * P * 4 + 15) / 16 * 16;
+  static_assert(IW % 4 == 0 && WCOLS <= 32 && PITCH >= 2 * IW + 16, "geometry");
+};
+
+template <int P, int TERMS>
+constexpr size_t s2_group_bytes() {
+  using G = S2Geom<P>;
+  return (size_t)(TERMS == 3 ? 2 : 1) * (G::IMG + G::TAB) + G::TAPS + 16;
 }
 
-template <bool DUMMY>
-__global__ __launch_bounds__(512, 1) void spatial_mfma_kernel(const float *__restrict__ A,
-                                                              const float *__restrict__ taps,
-                                                              int Nz, int Ny, int Nx, int P,
-                                                              int zper, int R,
-                                                              float *__restrict__ out) {
-  extern __shared__ __align__(16) char sm_lds[];
-  const int copy_all = sm_copy_all(P);
-  char *tab = sm_lds;                           // Toeplitz fragments
-  char *img_h = sm_lds + 8 * copy_all;          // f16 hi image of the input tile
-  char *img_l = img_h + SM_IMG;                 // f16 lo image
-  float *tapf = reinterpret_cast<float *>(img_l + SM_IMG);  // [P*P] taps of this channel
-  unsigned *redmax = reinterpret_cast<unsigned *>(tapf + SM_PMAX * SM_PMAX);
+// two-term split of y into f16 hi + lo
+__device__ __forceinline__ void s2_split(float y, _Float16 &hi, _Float16 &lo) {
+  hi = (_Float16)y;
+  lo = (_Float16)(y - (float)hi);
+}
 
-  const int c = P / 2, H = P - 1;
-  // all 152 columns are staged whatever P (the k-steps of a wave always read a 64-column
-  // window; columns beyond x0 + 127 + H only ever meet zero taps but must be finite)
-  const int iw4 = SM_IW / 4, ih = SM_RY + H;
-  // a block serves R regions stacked in y: the fragment table of a channel is built once for
-  // all of them (the PSF differs per channel, not per region)
-  const int x0 = blockIdx.x * SM_RX;
-  const int yb = blockIdx.y * R * SM_RY;  // y0 of sub-region r is yb + r * SM_RY
-  const int nr = min(R, (Ny - yb + SM_RY - 1) / SM_RY);  // sub-regions inside the field
+template <int P, int TERMS>
+__global__ __launch_bounds__(512, 1) void spatial2_kernel(const float *__restrict__ A,
+                                                          const float *__restrict__ taps, int Nz,
+                                                          int Ny, int Nx, int zper,
+                                                          float *__restrict__ out) {
+  using G = S2Geom<P>;
+  extern __shared__ __align__(16) char s2_lds[];
+  constexpr int c = P / 2;
+  constexpr size_t GB = s2_group_bytes<P, TERMS>();
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, gw = wave & 3, gt = tid & 255;  // group, wave / thread in group
+  char *base = s2_lds + grp * GB;
+  char *img_h = base, *img_l = base + (TERMS == 3 ? G::IMG : 0);
+  char *tab_h = base + (TERMS == 3 ? 2 : 1) * G::IMG, *tab_l = tab_h + (TERMS == 3 ? G::TAB : 0);
+  float *tapst = reinterpret_cast<float *>(tab_h + (TERMS == 3 ? 2 : 1) * G::TAB);
+  unsigned *maxw = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(tapst) + G::TAPS);
+
+  const int x0 = blockIdx.x * S2_R, y0 = blockIdx.y * S2_R;
   const long S = (long)Ny * Nx;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, h = lane >> 5;
-  const int wx = wave & 3, wy = wave >> 2;
   const int z0 = blockIdx.z * zper, z1 = min(Nz, z0 + zper);
+  const int n = lane & 31, h = lane >> 5;
 
-  // ---- register staging of the next channel's input tile and taps
-  float4 stage[SM_NQ];
-  float tapreg[2];
-  auto load_tile = [&](int z, int y0) {
+  // ---- zero everything once: table rows outside the PSF stay zero for good, image pads finite
+  for (int i = tid; i < (int)(2 * GB / 16); i += 512)
+    reinterpret_cast<uint4 *>(s2_lds)[i] = make_uint4(0u, 0u, 0u, 0u);
+
+  // ---- register staging of this group's NEXT channel: input tile, taps
+  float4 stage[G::NQ];
+  float tapreg[G::NT];
+  auto prefetch = [&](int z) {
     const float *Az = A + (long)z * S;
 #pragma unroll
-    for (int q = 0; q < SM_NQ; ++q) {
-      const int e = tid + 512 * q;
-      const int ry = e / iw4, cx = e - ry * iw4;
-      const int y = y0 - c + ry, x = x0 - c + 4 * cx;  // x % 4 == 0, Nx % 4 == 0
+    for (int q = 0; q < G::NQ; ++q) {
+      const int e = gt + 256 * q;
+      const int ry = e / (G::IW / 4), cx = e - ry * (G::IW / 4);
+      const int y = y0 - c + ry, x = x0 - c + 4 * cx;  // x % 4 == 0 (c % 4 == 0), Nx % 4 == 0
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ry < ih && y >= 0 && y < Ny && x >= 0 && x < Nx)
+      if (ry < G::IH && y >= 0 && y < Ny && x >= 0 && x < Nx)
         v = *reinterpret_cast<const float4 *>(Az + (long)y * Nx + x);
       stage[q] = v;
     }
     const float *kz = taps + (long)z * P * P;
-    tapreg[0] = tid < P * P ? kz[tid] : 0.f;
-    tapreg[1] = tid + 512 < P * P ? kz[tid + 512] : 0.f;
+#pragma unroll
+    for (int q = 0; q < G::NT; ++q) tapreg[q] = gt + 256 * q < P * P ? kz[gt + 256 * q] : 0.f;
+  };
+  // max |x| of the staged tile -> maxw[slot]; taps -> LDS staging (both read after a barrier)
+  auto publish = [&](int slot) {
+    if constexpr (TERMS == 3) {
+      float m = 0.f;
+#pragma unroll
+      for (int q = 0; q < G::NQ; ++q)
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(stage[q].x), fabsf(stage[q].y))),
+                  fmaxf(fabsf(stage[q].z), fabsf(stage[q].w)));
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+      if (lane == 0) atomicMax(&maxw[slot], __float_as_uint(m));
+    }
+#pragma unroll
+    for (int q = 0; q < G::NT; ++q)
+      if (gt + 256 * q < P * P) tapst[gt + 256 * q] = tapreg[q];
   };
 
-  // per-lane fragment addresses
-  const int E0 = 8 * h - r + 31;
-  const char *a_lane = tab + (E0 & 7) * copy_all + (E0 >> 3) * 16;
-  const int b_off = (wy * 32 + r) * SM_PITCH + (wx * 32 + 8 * h) * 2;
-
-  // unwritten image rows / pads must read as finite numbers (they only meet zero taps)
-  for (int i = tid; i < (2 * SM_IMG) / 16; i += 512)
-    reinterpret_cast<uint4 *>(img_h)[i] = make_uint4(0u, 0u, 0u, 0u);
-  load_tile(z0, yb);
-  for (int z = z0; z < z1; ++z)
-  for (int rr = 0; rr < nr; ++rr) {
-    const int y0 = yb + rr * SM_RY;
-    // ---- (1) scale of this channel's tile: max |x| -> 2^e with max |y| in [2^14, 2^15)
-    float m = 0.f;
-#pragma unroll
-    for (int q = 0; q < SM_NQ; ++q)
-      m = fmaxf(fmaxf(m, fmaxf(fabsf(stage[q].x), fabsf(stage[q].y))),
-                fmaxf(fabsf(stage[q].z), fabsf(stage[q].w)));
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if (tid == 0) *redmax = 0u;
-    __syncthreads();  // also: every wave is done with the previous channel's LDS images
-    if (lane == 0) atomicMax(redmax, __float_as_uint(m));
-    if (rr == 0) {  // taps of this channel (they came with the tile of sub-region 0)
-      if (tid < P * P) tapf[tid] = tapreg[0];
-      if (tid + 512 < P * P) tapf[tid + 512] = tapreg[1];
+  // ---- conversion phase: staged tile -> f16 hi / lo (or bf16) image; taps -> fragment table
+  auto convert = [&](int slot, float &inv_out) {
+    float scale = 1.f, inv = 1.f;
+    if constexpr (TERMS == 3) {
+      const int ex = (int)((maxw[slot] >> 23) & 0xffu);
+      const bool tiny = ex < 40 || ex == 255;  // zero / denormal-small / non-finite: no scaling
+      scale = __uint_as_float((unsigned)(tiny ? 127 : 268 - ex) << 23);  // max |y| in [2^14, 2^15)
+      inv = __uint_as_float((unsigned)(tiny ? 127 - S2_TAP_LOG2 : ex - 14 - S2_TAP_LOG2) << 23);
+      if (gt == 0) maxw[slot ^ 1] = 0u;  // the word the NEXT publish of this group adds to
     }
-    __syncthreads();
-    const int ex = (int)((*redmax >> 23) & 0xffu);
-    const bool tiny = ex < 40 || ex == 255;
-    const float scale = __uint_as_float((unsigned)(tiny ? 127 : 268 - ex) << 23);
-    const float inv = __uint_as_float((unsigned)(tiny ? 127 - SM_TAP_LOG2 : ex - 14 - SM_TAP_LOG2)
-                                      << 23);
-    // ---- (2a) f16 hi / lo images of the tile
+    inv_out = inv;
 #pragma unroll
-    for (int q = 0; q < SM_NQ; ++q) {
-      const int e = tid + 512 * q;
-      const int ry = e / iw4, cx = e - ry * iw4;
-      if (ry < ih) {
+    for (int q = 0; q < G::NQ; ++q) {
+      const int e = gt + 256 * q;
+      const int ry = e / (G::IW / 4), cx = e - ry * (G::IW / 4);
+      if (ry < G::IH) {
         const float v[4] = {stage[q].x * scale, stage[q].y * scale, stage[q].z * scale,
                             stage[q].w * scale};
-        f16x4 vh, vl;
+        if constexpr (TERMS == 3) {
+          f16x4 vh, vl;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const _Float16 yh = (_Float16)v[j];
-          vh[j] = yh;
-          vl[j] = (_Float16)(v[j] - (float)yh);
+          for (int j = 0; j < 4; ++j) {
+            _Float16 a, b;
+            s2_split(v[j], a, b);
+            vh[j] = a, vl[j] = b;
+          }
+          *reinterpret_cast<f16x4 *>(img_h + ry * G::PITCH + cx * 8) = vh;
+          *reinterpret_cast<f16x4 *>(img_l + ry * G::PITCH + cx * 8) = vl;
+        } else {
+          bf16x2 a, b;
+          a[0] = (__bf16)v[0], a[1] = (__bf16)v[1], b[0] = (__bf16)v[2], b[1] = (__bf16)v[3];
+          u32x2v w;
+          w[0] = __builtin_bit_cast(unsigned, a), w[1] = __builtin_bit_cast(unsigned, b);
+          *reinterpret_cast<u32x2v *>(img_h + ry * G::PITCH + cx * 8) = w;
         }
-        *reinterpret_cast<f16x4 *>(img_h + ry * SM_PITCH + cx * 8) = vh;
-        *reinterpret_cast<f16x4 *>(img_l + ry * SM_PITCH + cx * 8) = vl;
       }
     }
-    // ---- (2b) Toeplitz fragment table: G_dy[e] = k[dy][e - 31] (0 outside), copies shifted
-    // by 0..7 elements, hi and lo; group (dy, hl, copy, q) holds G_dy[8 q + copy .. + 7]
-    if (rr == 0) {
-      const float tscale = (float)(1 << SM_TAP_LOG2);
-      const int ngroups = P * 8 * SM_GROUPS;
-      for (int gidx = tid; gidx < ngroups; gidx += 512) {
-        const int q = gidx % SM_GROUPS;
-        const int cp = (gidx / SM_GROUPS) & 7;
-        const int dy = gidx / (SM_GROUPS * 8);
-        f16x8 gh, gl;
+    // table entry (row t = dy + 3, copy cp): G_dy[e + cp], e = 0..39, G_dy[e] = k[dy][e - 7]
+    for (int ent = gt; ent < P * 8; ent += 256) {
+      const int dy = ent >> 3, cp = ent & 7;
+      char *dst_h = tab_h + ((dy + 3) * 8 + cp) * S2_ENTRY;
+      char *dst_l = tab_l + ((dy + 3) * 8 + cp) * S2_ENTRY;
+#pragma unroll
+      for (int g8 = 0; g8 < 5; ++g8) {
+        float t[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const int d = 8 * q + cp + j - 31;
+          const int d = 8 * g8 + j + cp - 7;
           // branch-free: all eight LDS reads of a group are in flight together
-          const float t0 = tapf[dy * P + min(max(d, 0), P - 1)];
-          const float g = (d >= 0 && d < P) ? t0 * tscale : 0.f;
-          const _Float16 t = (_Float16)g;
-          gh[j] = t;
-          gl[j] = (_Float16)(g - (float)t);
+          const float t0 = tapst[dy * P + min(max(d, 0), P - 1)];
+          t[j] = (d >= 0 && d < P) ? t0 : 0.f;
         }
-        char *dst = tab + cp * copy_all + (dy * 2) * (SM_GROUPS * 16) + q * 16;
-        *reinterpret_cast<f16x8 *>(dst) = gh;
-        *reinterpret_cast<f16x8 *>(dst + SM_GROUPS * 16) = gl;
+        if constexpr (TERMS == 3) {
+          f16x8 gh, gl;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            _Float16 a, b;
+            s2_split(t[j] * (float)(1 << S2_TAP_LOG2), a, b);
+            gh[j] = a, gl[j] = b;
+          }
+          *reinterpret_cast<f16x8 *>(dst_h + 16 * g8) = gh;
+          *reinterpret_cast<f16x8 *>(dst_l + 16 * g8) = gl;
+        } else {
+          bf16x8 gb;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) gb[j] = (__bf16)t[j];
+          *reinterpret_cast<bf16x8 *>(dst_h + 16 * g8) = gb;
+        }
       }
     }
-    __syncthreads();
-    // next tile (same channel, next sub-region; else next channel): in flight during the MFMAs
-    if (rr + 1 < nr) load_tile(z, y0 + SM_RY);
-    else if (z + 1 < z1) load_tile(z + 1, yb);
+  };
 
-    // ---- (3) P x 4 k-steps: acc += Ah Bh + Ah Bl + Al Bh
+  // ---- MFMA phase: this wave's 32 x 32 area (ax, ay) of the region
+  const int ax = gw & 1, ay = gw >> 1;
+  const int ox = 8 * (n & 3), oy = 4 * (n >> 2);  // patch origin of column n
+  const int mx = n & 7, my = n >> 3;              // output of row m = n (A operand: lane = row)
+  // A: entry (row wy - my + 3, copy 7 - mx), group 2 half + h;  B: image row 32 ay + oy + wy,
+  // columns 32 ax + ox + 16 half + 8 h + j
+  const int a_off = ((3 - my) * 8 + (7 - mx)) * S2_ENTRY + 16 * h;
+  const int b_off = (32 * ay + oy) * G::PITCH + (32 * ax + ox + 8 * h) * 2;
+  auto mfma_phase = [&](int z, float inv) {
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    {
-      // the 16 fragments of kernel row dy+1 are requested before the 12 MFMAs of row dy: a
-      // whole row (>= 384 cycles) of matrix work covers the LDS latency of the next one
-      const char *ap = a_lane, *bp = img_h + b_off;
-      f16x8 ah[4], al[4], bh[4], bl[4];
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        ah[ks] = *reinterpret_cast<const f16x8 *>(ap + ks * 32);
-        al[ks] = *reinterpret_cast<const f16x8 *>(ap + ks * 32 + SM_GROUPS * 16);
-        bh[ks] = *reinterpret_cast<const f16x8 *>(bp + ks * 32);
-        bl[ks] = *reinterpret_cast<const f16x8 *>(bp + ks * 32 + SM_IMG);
+    const char *ap = tab_h + a_off, *bp = img_h + b_off;
+    constexpr int LOA = G::TAB, LOB = G::IMG;
+    constexpr int DEPTH = 2;  // k-steps of fragments in flight ahead of the MFMAs
+    u32x4v fah[DEPTH + 1], fal[DEPTH + 1], fbh[DEPTH + 1], fbl[DEPTH + 1];
+    auto fetch = [&](int ks, int slot) {
+      const int wy = ks / G::KROW, half = ks - wy * G::KROW;
+      const int ao = wy * 8 * S2_ENTRY + half * 32, bo = wy * G::PITCH + half * 32;
+      fah[slot] = *reinterpret_cast<const u32x4v *>(ap + ao);
+      fbh[slot] = *reinterpret_cast<const u32x4v *>(bp + bo);
+      if constexpr (TERMS == 3) {
+        fal[slot] = *reinterpret_cast<const u32x4v *>(ap + ao + LOA);
+        fbl[slot] = *reinterpret_cast<const u32x4v *>(bp + bo + LOB);
       }
-      for (int dy = 0; dy < P; ++dy) {
-        const bool last = dy == P - 1;  // the last row re-reads itself (valid addresses)
-        const char *an = last ? ap : ap + 2 * SM_GROUPS * 16;
-        const char *bn = last ? bp : bp + SM_PITCH;
-        f16x8 nah[4], nal[4], nbh[4], nbl[4];
+    };
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          nah[ks] = *reinterpret_cast<const f16x8 *>(an + ks * 32);
-          nal[ks] = *reinterpret_cast<const f16x8 *>(an + ks * 32 + SM_GROUPS * 16);
-          nbh[ks] = *reinterpret_cast<const f16x8 *>(bn + ks * 32);
-          nbl[ks] = *reinterpret_cast<const f16x8 *>(bn + ks * 32 + SM_IMG);
-        }
+    for (int ks = 0; ks < DEPTH; ++ks) fetch(ks, ks);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bh[ks], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bl[ks], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], bh[ks], acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) ah[ks] = nah[ks], al[ks] = nal[ks], bh[ks] = nbh[ks], bl[ks] = nbl[ks];
-        ap = an;
-        bp = bn;
+    for (int ks = 0; ks < G::NKS; ++ks) {
+      const int cur = ks % (DEPTH + 1);
+      if (ks + DEPTH < G::NKS) fetch(ks + DEPTH, (ks + DEPTH) % (DEPTH + 1));
+      // asm volatile statements keep their order, and the fragment reads above stay where they
+      // are written: DEPTH k-steps ahead of their use (with the builtins hipcc sinks every
+      // ds_read to just in front of its MFMA and waits for it there)
+      if constexpr (TERMS == 3) {
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(fah[cur]), "v"(fbh[cur]));
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(fah[cur]), "v"(fbl[cur]));
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(fal[cur]), "v"(fbh[cur]));
+      } else {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(fah[cur]), "v"(fbh[cur]));
       }
     }
-    // ---- (4) store: lane (r, h) holds row y0 + 32 wy + r, columns x0 + 32 wx + 8 g + 4 h + 0..3
-    const int y = y0 + wy * 32 + r;
-    if (y < Ny) {
-      float *o = out + (long)z * S + (long)y * Nx + x0 + wx * 32 + 4 * h;
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc));  // last MFMA result -> VALU readers
+    // store: accumulator register i of lane (n, h) is output m = (i&3) + 8 (i>>2) + 4 h of patch
+    // n, i.e. patch row i >> 2, patch columns 4 h + (i & 3): one float4 per patch row
+    const int xo = x0 + 32 * ax + ox + 4 * h;
+    if (xo < Nx) {  // Nx % 4 == 0: a float4 is inside or outside as a whole
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int x = x0 + wx * 32 + 8 * g + 4 * h;
-        if (x < Nx)  // Nx % 4 == 0: a float4 is inside or outside as a whole
-          *reinterpret_cast<float4 *>(o + 8 * g) =
-              make_float4(acc[4 * g] * inv, acc[4 * g + 1] * inv, acc[4 * g + 2] * inv,
-                          acc[4 * g + 3] * inv);
+      for (int pr = 0; pr < 4; ++pr) {
+        const int y = y0 + 32 * ay + oy + pr;
+        if (y < Ny)
+          *reinterpret_cast<float4 *>(out + (long)z * S + (long)y * Nx + xo) =
+              make_float4(acc[4 * pr] * inv, acc[4 * pr + 1] * inv, acc[4 * pr + 2] * inv,
+                          acc[4 * pr + 3] * inv);
       }
     }
+  };
+
+  // ---- schedule.  Group g takes channels z0 + g + 2 i; in phase p it converts channel i when
+  // p = 2 i + g and runs the MFMAs of channel i when p = 2 i + g + 1.  One barrier per phase.
+  const int nch = z1 - z0;
+  const int ng = (nch - grp + 1) / 2;  // channels of this group
+  __syncthreads();                     // zero fill done
+  if (ng > 0) {
+    prefetch(z0 + grp);
+    publish(0);
+  }
+  __syncthreads();
+  float inv_cur = 1.f;
+  const int nphase = 2 * ((nch + 1) / 2) + 2;
+  for (int p = 0; p < nphase; ++p) {
+    const int q = p - grp;
+    if (q >= 0) {
+      const int i = q >> 1;
+      if ((q & 1) == 0) {
+        if (i < ng) convert(i & 1, inv_cur);
+      } else if (i < ng) {
+        if (i + 1 < ng) prefetch(z0 + grp + 2 * (i + 1));
+        mfma_phase(z0 + grp + 2 * i, inv_cur);
+        if (i + 1 < ng) publish((i + 1) & 1);
+      }
+    }
+    __syncthreads();
   }
 }
 
 }  // namespace
 
-// 1 if this shape can run on spatial_mfma_kernel
+// 1 if this shape can run on spatial2_kernel
 int origin_spatial_mfma_ok(int Ny, int Nx, int P) {
-  return P >= 1 && P <= SM_PMAX && (P & 1) && ((P / 2) & 3) == 0 && (Nx & 3) == 0 && Ny >= 1;
+  return (P == 9 || P == 17 || P == 25) && (Nx & 3) == 0 && Ny >= 1;
 }
 
-int origin_spatial_mfma_launch(origin_ctx *ctx, const float *A, const float *taps, int Nz, int Ny,
-                               int Nx, int P, float *out) {
-  const size_t lds = (size_t)8 * sm_copy_all(P) + 2 * SM_IMG + SM_PMAX * SM_PMAX * sizeof(float) + 64;
+template <int P, int TERMS>
+static int s2_launch(origin_ctx *ctx, const float *A, const float *taps, int Nz, int Ny, int Nx,
+                     float *out) {
+  const size_t lds = 2 * s2_group_bytes<P, TERMS>();
   static bool attr_done = false;
   if (!attr_done) {
-    ORIGIN_HIP(hipFuncSetAttribute((const void *)spatial_mfma_kernel<true>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ORIGIN_HIP(hipFuncSetAttribute((const void *)spatial2_kernel<P, TERMS>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
-  // R regions stacked in y share a block (the per-channel fragment table is built once for all
-  // of them); more z chunks keep the number of blocks up
-  const int ry = cdiv(Ny, SM_RY);
-  int R = 1;  // largest divisor of the region count up to 10 (no idle sub-region slots)
-  for (int c = 2; c <= 10; ++c)
-    if (ry % c == 0) R = c;
-  const long groups = (long)cdiv(Nx, SM_RX) * cdiv(ry, R);
-  int nzb = (int)(((long)ctx->num_cu * 4 + groups - 1) / groups);
-  nzb = std::max(1, std::min(nzb, Nz));
-  const int zper = cdiv(Nz, nzb);
-  dim3 grid(cdiv(Nx, SM_RX), cdiv(ry, R), cdiv(Nz, zper));
-  hipLaunchKernelGGL(spatial_mfma_kernel<true>, grid, dim3(512), lds, ctx->stream, A, taps, Nz, Ny,
-                     Nx, P, zper, R, out);
+  // one block per CU at a time (LDS): choose the number of z chunks so that the blocks fill
+  // whole rounds of the chip (an even number of channels per chunk keeps both groups busy)
+  const long regions = (long)cdiv(Nx, S2_R) * cdiv(Ny, S2_R);
+  const int ncu = std::max(1, ctx->num_cu);
+  int best_nzb = 1;
+  double best_eff = 0.0;
+  for (int nzb = 1; nzb <= std::max(1, Nz / 32); ++nzb) {
+    int zp = cdiv(Nz, nzb);
+    zp += zp & 1;
+    const long blocks = regions * cdiv(Nz, zp);
+    const long rounds = (blocks + ncu - 1) / ncu;
+    // useful channel slots / (rounds x chunk length x CUs), with a per-block cost of ~3 channels
+    const double eff = (double)regions * Nz / ((double)rounds * ncu * (zp + 3));
+    if (eff > best_eff) best_eff = eff, best_nzb = nzb;
+  }
+  int zper = cdiv(Nz, best_nzb);
+  zper += zper & 1;
+  dim3 grid(cdiv(Nx, S2_R), cdiv(Ny, S2_R), cdiv(Nz, zper));
+  hipLaunchKernelGGL((spatial2_kernel<P, TERMS>), grid, dim3(512), lds, ctx->stream, A, taps, Nz,
+                     Ny, Nx, zper, out);
   ORIGIN_LAUNCH_CHECK();
   return ORIGIN_OK;
+}
+
+int origin_spatial_mfma_launch(origin_ctx *ctx, int terms, const float *A, const float *taps,
+                               int Nz, int Ny, int Nx, int P, float *out) {
+#define S2_CASE(PP)                                                        \
+  case PP:                                                                 \
+    return terms == 3 ? s2_launch<PP, 3>(ctx, A, taps, Nz, Ny, Nx, out)   \
+                      : s2_launch<PP, 1>(ctx, A, taps, Nz, Ny, Nx, out)
+  switch (P) {
+    S2_CASE(9);
+    S2_CASE(17);
+    S2_CASE(25);
+  }
+#undef S2_CASE
+  origin_set_error("spatial MFMA kernel: PSF size %d not supported", P);
+  return ORIGIN_E_ARG;
 }
