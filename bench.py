@@ -281,19 +281,24 @@ def main():
             # algorithmic rate against the fp32 FMA peak the same problem has without them.
             gplan = glr.plan if world > 1 else plan
             vox = ext_vox if world > 1 else local_vox
-            on_mfma = (dominant == "glr_spectral" and glr_precision == "f16x2") or \
+            on_mfma = (dominant == "glr_spectral" and glr_precision != "f32") or \
                       (dominant == "glr_spatial" and gplan.spatial_on_matrix_cores)
             ach, unit = per_launch / avg_s / 1e12, "TFLOP/s"
             peak = F16_MFMA_PEAK_TFLOPS if on_mfma else FP32_PEAK_TFLOPS
             if on_mfma:
+                terms = 1.0 if glr_precision == "bf16" else 3.0
                 if dominant == "glr_spectral":
+                    # banded Toeplitz [32 x 96]: 4 (half width <= 16) or 6 k-steps per profile
                     nks = sum(6 if (n - 1) // 2 > 16 else 4 for n in gplan.tap_lengths)
-                    mfma_per_vox = 3.0 * nks / 1024.0
+                    mfma_per_vox = terms * nks / 1024.0
                 else:
-                    mfma_per_vox = 3.0 * 4 * gplan.P / 1024.0
+                    # 8 x 4 output patches against their (8+P-1) x (4+P-1) window: k-steps of 16
+                    Pp = gplan.P
+                    mfma_per_vox = terms * (4 + Pp - 1) * ((8 + Pp - 1 + 15) // 16) / 1024.0
                 ex = mfma_per_vox * 32768.0 * vox / avg_s / 1e12
                 extra = dict(executed=round(ex, 1), executed_frac=round(ex / peak, 4),
-                             fp32_frac=round(ach / FP32_PEAK_TFLOPS, 4), arithmetic="f16x2 MFMA")
+                             fp32_frac=round(ach / FP32_PEAK_TFLOPS, 4),
+                             arithmetic=glr_precision + " MFMA")
         # HBM traffic of the dominant kernel: bench.py cannot read PMC counters itself, so it
         # takes the per-launch FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 --pmc passes
         # of this very command (profiles/, tools/summarize_rocprof.py) when the workload is the
