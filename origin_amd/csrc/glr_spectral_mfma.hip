@@ -118,22 +118,25 @@ constexpr int sm_epi_start(int j, int NM) {
 
 // One pipeline stage: the MFMAs of one profile pair (A fragments at ak: the lane's own profile
 // of the pair) into acc, interleaved with the epilogue of the previous pair (its accumulator
-// pacc, its 1/sqrt(den) values pfa / pfb, its keys' index parts pca / pcb).  NB: window blocks
-// used, 3 (both profiles narrow: blocks 1..3) or 5.
-template <int TERMS, int NB>
-__device__ __forceinline__ void sm_stage(const char *ak, const u32x4v (&bh)[5],
-                                         const u32x4v (&bl)[5], f32x16 &acc, const f32x16 &pacc,
+// pacc, its 1/sqrt(den) values pfa / pfb, its keys' index parts pca / pcb).  Window blocks
+// OFF+1 .. OFF+3 always; blocks OFF+0 and OFF+4 after them when the pair is wide (a wave-uniform
+// branch around six bare MFMAs: one stage body for every pair, so the pair loop is ONE loop and
+// the state registers never move; the epilogue sits in the gaps of the nine mandatory MFMAs).
+// OFF: 0 for the first 16 channels of a 32-channel tile, 1 for the second (window one block on).
+template <int TERMS, int OFF>
+__device__ __forceinline__ void sm_stage(const char *ak, bool wide, const u32x4v (&bh)[6],
+                                         const u32x4v (&bl)[6], f32x16 &acc, const f32x16 &pacc,
                                          const f32x4v (&pfa)[2], const f32x4v (&pfb)[2],
                                          SmState &st, unsigned maskv, int pca, int pcb) {
   constexpr int LO = 8 * MF_COPY_BYTES;
-  constexpr int KS0 = NB == 5 ? 0 : 1;
-  constexpr int NM = TERMS * NB;
-  u32x4v ah = *reinterpret_cast<const u32x4v *>(ak + KS0 * 32), al = ah;
-  if constexpr (TERMS == 3) al = *reinterpret_cast<const u32x4v *>(ak + KS0 * 32 + LO);
-  sm_for<0, NB>([&](auto ic) {
-    constexpr int g = decltype(ic)::value, ks = KS0 + g;
+  constexpr int NM = TERMS * 3;
+  // A fragments of window blocks 1, 2, 3 (mandatory), requested one block ahead
+  u32x4v ah = *reinterpret_cast<const u32x4v *>(ak + 32), al = ah;
+  if constexpr (TERMS == 3) al = *reinterpret_cast<const u32x4v *>(ak + 32 + LO);
+  sm_for<0, 3>([&](auto ic) {
+    constexpr int g = decltype(ic)::value, ks = 1 + g;
     u32x4v nh = ah, nl = al;
-    if constexpr (g + 1 < NB) {  // A fragments are requested one block ahead
+    if constexpr (g + 1 < 3) {
       nh = *reinterpret_cast<const u32x4v *>(ak + (ks + 1) * 32);
       if constexpr (TERMS == 3) nl = *reinterpret_cast<const u32x4v *>(ak + (ks + 1) * 32 + LO);
     }
@@ -143,16 +146,33 @@ __device__ __forceinline__ void sm_stage(const char *ak, const u32x4v (&bh)[5],
         sm_epi_item<decltype(kc)::value>(pacc, pfa, pfb, st, maskv, pca, pcb);
       });
     };
-    sm_mma<TERMS, g == 0>(acc, ah, bh[ks]);
+    sm_mma<TERMS, g == 0>(acc, ah, bh[OFF + ks]);
     gap(std::integral_constant<int, TERMS * g>{});
     if constexpr (TERMS == 3) {
-      sm_mma<TERMS, false>(acc, ah, bl[ks]);
+      sm_mma<TERMS, false>(acc, ah, bl[OFF + ks]);
       gap(std::integral_constant<int, TERMS * g + 1>{});
-      sm_mma<TERMS, false>(acc, al, bh[ks]);
+      sm_mma<TERMS, false>(acc, al, bh[OFF + ks]);
       gap(std::integral_constant<int, TERMS * g + 2>{});
     }
     ah = nh, al = nl;
   });
+  if (wide) {  // window blocks 0 and 4
+    const u32x4v a0h = *reinterpret_cast<const u32x4v *>(ak);
+    const u32x4v a4h = *reinterpret_cast<const u32x4v *>(ak + 4 * 32);
+    if constexpr (TERMS == 3) {
+      const u32x4v a0l = *reinterpret_cast<const u32x4v *>(ak + LO);
+      const u32x4v a4l = *reinterpret_cast<const u32x4v *>(ak + 4 * 32 + LO);
+      sm_mma<TERMS, false>(acc, a0h, bh[OFF + 0]);
+      sm_mma<TERMS, false>(acc, a0h, bl[OFF + 0]);
+      sm_mma<TERMS, false>(acc, a0l, bh[OFF + 0]);
+      sm_mma<TERMS, false>(acc, a4h, bh[OFF + 4]);
+      sm_mma<TERMS, false>(acc, a4h, bl[OFF + 4]);
+      sm_mma<TERMS, false>(acc, a4l, bh[OFF + 4]);
+    } else {
+      sm_mma<TERMS, false>(acc, a0h, bh[OFF + 0]);
+      sm_mma<TERMS, false>(acc, a4h, bh[OFF + 4]);
+    }
+  }
 }
 
 // the epilogue of the last pair, nothing to overlap it with
@@ -166,63 +186,97 @@ __device__ __forceinline__ void sm_drain(const f32x16 &pacc, const f32x4v (&pfa)
   });
 }
 
-// Everything a wave does: march z in tiles of 16 channels.  BW: the wave touches the field border
-// (each lane reads the 1/sqrt(den) values of its own border class from global memory; interior
-// waves share the interior class through an LDS table).  A template parameter, not a run-time
-// test inside the loop: with a test the two kinds of pointer merge into flat loads.
-// NODD / WODD: the number of narrow / wide profile pairs is odd.  Compile-time too: the pair loop
-// is then loops of ONE stage variant each with the two accumulators in fixed roles and nothing
-// conditional between them (with run-time choices hipcc shuffles the state registers at every
-// merge).
-template <int TERMS, bool BW, bool NODD, bool WODD>
+// Everything a wave does: march z in tiles of 32 channels -- one load + conversion of the
+// 96-channel window x[z0-32 .. z0+63] (six blocks), then the two 16-channel halves, each with its
+// own pass over the profile pairs (window blocks 0..4 and 1..5).  BW: the wave touches the field
+// border (each lane reads the 1/sqrt(den) values of its own border class from global memory;
+// interior waves share the interior class through an LDS table).  A template parameter, not a
+// run-time test inside the loop: with a test the two kinds of pointer merge into flat loads.
+// PODD: the number of profile pairs is odd (the two accumulators alternate per pair; the pair
+// loop is unrolled by two, and an odd count leaves one stage behind it).
+template <int TERMS, bool BW, bool PODD>
 __device__ __forceinline__ void sm_tiles(
     const float *__restrict__ fsf, const float *__restrict__ rdb, const float *__restrict__ rdi_s,
-    int NzP, const int *__restrict__ pinfo, int K, int nNp, int NP, int Nz, long S, long s_base,
-    int rr, bool sv, bool all_valid, int h, int lane, const char *a_lane, char *rd_wave, int zc0,
-    int zc1, const uint8_t *__restrict__ mask, float *__restrict__ correl,
-    uint8_t *__restrict__ profile, float *__restrict__ correl_min, float &vmax, float &vmin) {
+    int NzP, const int *__restrict__ pinfo, int K, int NP, int Nz, long S, long s_base, int rr,
+    bool sv, bool all_valid, int h, int lane, const char *a_lane, char *rd_wave, int zc0, int zc1,
+    const uint8_t *__restrict__ mask, float *__restrict__ correl, uint8_t *__restrict__ profile,
+    float *__restrict__ correl_min, float &vmax, float &vmin) {
   const char *rd_lane = rd_wave + 16 * h;  // channels 4h..4h+3 of each group of 8
   const bool second = (lane & 16) != 0;    // this lane's A rows belong to the pair's profile b
   // Addresses are a wave-uniform base (SGPR pair) plus ONE 32-bit lane offset: the window rows,
   // stores and mask bytes of a tile would otherwise hold a 64-bit pointer each.  (The fsf work
   // cube is padded with 32 zero channels in front and 64 behind, origin_glr_run: every window
   // is read without a bounds test.)
-  const int off_in = (int)(8 * h * S) + rr;   // window rows 16 ks + 8 h + j
-  const int off_out = (int)(4 * h * S) + rr;  // outputs (o&3) + 8 (o>>2) + 4 h
-  const int off_rd = (lane >> 4) * NzP + (lane & 15);
+  // (unsigned BYTE offsets: global_load / global_store take an SGPR base plus a zero-extended
+  // 32-bit VGPR byte offset -- with element offsets hipcc adds base and offset on the VALU)
+  const unsigned off_in = 4u * ((unsigned)(8 * h * S) + rr);   // window rows 16 ks + 8 h + j
+  const unsigned off_out = (unsigned)(4 * h * S) + rr;         // outputs (o&3) + 8 (o>>2) + 4 h
+  const unsigned off_out4 = 4u * off_out;
+  const unsigned off_rd = 4u * (unsigned)((lane >> 5) * NzP + (lane & 31));
+  // (the empty asm keeps the zero-extension of the offset in the basic block of the access:
+  // hoisted out of the loop it becomes a 64-bit VGPR pair, and the instruction selector no longer
+  // sees "SGPR base + zext(VGPR)" -- one v_lshl_add_u64 per load)
+  auto ldf = [](const float *base, unsigned boff) {
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + boff);
+  };
+  auto stf = [](float *base, unsigned boff, float v) {
+    *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + boff) = v;
+  };
+#define SM_PIN(v) asm volatile("" : "+v"(v))  // "defined here": once per straight-line block
   unsigned maskv = 0xffffffe0u;
   asm volatile("" : "+v"(maskv));  // in a VGPR: a VOP3 instruction takes one SGPR, no literal
 
-  for (int z0 = zc0; z0 < zc1; z0 += 16) {
-    // ---- 1/sqrt(den)[slot][z0 .. z0+15] of the interior class -> this wave's LDS table (raw:
+  float xn[6][8];  // the next tile's window, in flight during the current tile's second half
+  auto load_window = [&](int z0, float (&w)[6][8]) {
+    const float *ub = fsf + (long)(z0 - 32) * S + s_base;  // uniform, one row on per load
+    unsigned oin = off_in;
+    SM_PIN(oin);
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        w[ks][j] = ldf(ub, oin);
+        ub += S;
+      }
+      ub += 8 * S;
+    }
+  };
+  for (int z0 = zc0; z0 < zc1; z0 += 32) {
+    // ---- 1/sqrt(den)[slot][z0 .. z0+31] of the interior class -> this wave's LDS table (raw:
     // the power-of-two unscaling is applied to the final max / min).  rdi_s is in processing
-    // order [slot][NzP]: element i = lane + 64 q is slot (lane>>4) + 4q, channel lane & 15
+    // order [slot][NzP]: element i = lane + 64 q is slot (lane>>5) + 2q, channel lane & 31
     if constexpr (!BW) {
-      float rv[(MF_MAX_K + 3) / 4];
+      float rv[MF_MAX_K / 2];
       const float *ub = rdi_s + z0;
+      unsigned ord = off_rd;
+      SM_PIN(ord);
 #pragma unroll
-      for (int q = 0; q < (MF_MAX_K + 3) / 4; ++q)
-        rv[q] = (lane >> 4) + 4 * q < K ? (ub + (long)(4 * q) * NzP)[off_rd] : 0.0f;
+      for (int q = 0; q < MF_MAX_K / 2; ++q) {
+        rv[q] = (lane >> 5) + 2 * q < K ? ldf(ub, ord) : 0.0f;
+        ub += 2 * NzP;
+      }
 #pragma unroll
-      for (int q = 0; q < (MF_MAX_K + 3) / 4; ++q)
-        if ((lane >> 4) + 4 * q < K) reinterpret_cast<float *>(rd_wave)[lane + 64 * q] = rv[q];
+      for (int q = 0; q < MF_MAX_K / 2; ++q)
+        if ((lane >> 5) + 2 * q < K) reinterpret_cast<float *>(rd_wave)[lane + 64 * q] = rv[q];
     }
-    // ---- window X[z0-32 .. z0+47] in B-fragment order: lane (n, h) holds rows 16 ks + 8 h + j
-    float x[5][8];
-    {
-      const float *ub = fsf + (long)(z0 - 32) * S + s_base;  // uniform
+    // ---- window X[z0-32 .. z0+63] in B-fragment order: lane (n, h) holds rows 16 ks + 8 h + j.
+    // It was requested while the previous tile's second half ran (xn); only the first tile of a
+    // chunk loads it here.
+    float x[6][8];
+    if (z0 == zc0) load_window(z0, x);
+    else {
 #pragma unroll
-      for (int ks = 0; ks < 5; ++ks)
+      for (int ks = 0; ks < 6; ++ks)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[ks][j] = (ub + (long)(16 * ks + j) * S)[off_in];
+        for (int j = 0; j < 8; ++j) x[ks][j] = xn[ks][j];
     }
-    u32x4v bh[5], bl[5];
+    u32x4v bh[6], bl[6];
     float inv = 1.0f;
     if constexpr (TERMS == 3) {
       // power-of-two scale of this tile: max |y| in [2^14, 2^15)
       float m = 0.0f;
 #pragma unroll
-      for (int ks = 0; ks < 5; ++ks)
+      for (int ks = 0; ks < 6; ++ks)
 #pragma unroll
         for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(x[ks][j]));
       if (!all_valid) m = sv ? m : 0.0f;  // lanes past the end of the field hold a copy
@@ -235,7 +289,7 @@ __device__ __forceinline__ void sm_tiles(
       inv = __uint_as_float((unsigned)(tiny ? 127 - MF_TAP_SCALE_LOG2
                                             : ex - 14 - MF_TAP_SCALE_LOG2) << 23);
 #pragma unroll
-      for (int ks = 0; ks < 5; ++ks) {
+      for (int ks = 0; ks < 6; ++ks) {
         f16x2v hh[4], ll[4];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -252,7 +306,7 @@ __device__ __forceinline__ void sm_tiles(
       }
     } else {
 #pragma unroll
-      for (int ks = 0; ks < 5; ++ks)
+      for (int ks = 0; ks < 6; ++ks)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
@@ -264,116 +318,128 @@ __device__ __forceinline__ void sm_tiles(
         }
     }
 
-    SmState st;
+    // ---- the two 16-channel halves
+    sm_for<0, 2>([&](auto hc) {
+      constexpr int HALF = decltype(hc)::value;
+      const int zh = z0 + 16 * HALF;  // first output channel of this half
+      if constexpr (HALF == 1) {
+        if (z0 + 32 < zc1) load_window(z0 + 32, xn);  // lands while this half computes
+      }
+      if (zh >= zc1) return;  // (uniform)
+      // mask bytes of this half's outputs (steps.py:781,788): requested now, used after the pairs.
+      // Output i of the lane is channel zh + (i&3) + 8 (i>>2) + 4 h: uniform row pointers
+      const bool inside = zh + 16 <= zc1;  // (uniform) every channel of the half exists
+      unsigned char mk[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) st.best[i] = -INFINITY, st.worst[i] = INFINITY, st.key[i] = -INFINITY;
+      for (int i = 0; i < 8; ++i) mk[i] = 0;
+      if (mask) {  // branch-free inside: every load is issued before the first is awaited
+        if (inside) {
+          const uint8_t *mp = mask + (long)zh * S + s_base;
+          unsigned om = off_out;
+          SM_PIN(om);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            mk[i] = mp[om];
+            mp += (i & 3) == 3 ? 5 * S : S;
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            // channel min(zu + 4 h, Nz - 1): the lane part clamped at the cube's end
+            const int zu = min(zh + (i & 3) + 8 * (i >> 2), Nz - 1);
+            const unsigned hs = (unsigned)(min(4, Nz - 1 - zu) * S);
+            mk[i] = (mask + (long)zu * S + s_base)[(unsigned)rr + (h ? hs : 0u)];
+          }
+        }
+      }
+      SmState st;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        st.best[i] = -INFINITY, st.worst[i] = INFINITY, st.key[i] = -INFINITY;
 
-    // ---- profile pairs, software pipelined; two accumulators in ping-pong: a stage writes one
-    // while the epilogue of the pair before reads the other.  The first stage runs the same code
-    // as every other: its "previous pair" is neutral -- 1/sqrt(den) = NaN makes T and its key
-    // NaN, which v_max3 / v_min3 ignore.
-    f32x16 accX, accY;
-    f32x4v fa[2], fb[2];
-    int ca = 0, cb = 0;
+      // profile pairs, software pipelined; two accumulators in ping-pong: a stage writes one
+      // while the epilogue of the pair before reads the other.  The first stage runs the same
+      // code as every other: its "previous pair" is neutral -- 1/sqrt(den) = NaN makes T and its
+      // key NaN, which v_max3 / v_min3 ignore.
+      f32x16 accX, accY;
+      f32x4v fa[2], fb[2];
+      int ca = 0, cb = 0;
 #pragma unroll
-    for (int g = 0; g < 2; ++g) fa[g] = fb[g] = (f32x4v){NAN, NAN, NAN, NAN};
-    asm volatile("s_nop 1" : "=v"(accY));  // (accY: any bits; B fragment writes -> first MFMA)
-    auto ak_of = [&](int p) {  // the lane's own profile of pair p: slot 2p (rows 0-15) or 2p+1
-      const int sa = 2 * p, sb = min(2 * p + 1, K - 1);  // (odd K: the last profile twice)
-      return a_lane + (second ? sb : sa) * MF_PROF_BYTES;
-    };
-    auto load_f = [&](int p) {
-      // 1/sqrt(den) of the pair for the lane's 8 channels: requested at the end of its stage
-      // (the epilogue that read the previous values is done), used from the third MFMA gap of
-      // the next stage
-      const int sa = 2 * p, sb = min(2 * p + 1, K - 1);
-      const int ka = pinfo[sa] & 0xff, kb = pinfo[sb] & 0xff;
-      if constexpr (BW) {
+      for (int g = 0; g < 2; ++g) fa[g] = fb[g] = (f32x4v){NAN, NAN, NAN, NAN};
+      asm volatile("s_nop 1" : "=v"(accY));  // (accY: any bits; B fragment writes -> first MFMA)
+      auto run = [&](int p, f32x16 &wacc, const f32x16 &racc) {
+        const int sa = 2 * p, sb = min(2 * p + 1, K - 1);  // (odd K: the last profile twice)
+        const int ia = pinfo[sa], ib = pinfo[sb];
+        // the lane's own profile of the pair: slot sa (rows 0-15) or sb (rows 16-31)
+        const char *ak = a_lane + (second ? sb : sa) * MF_PROF_BYTES;
+        sm_stage<TERMS, HALF>(ak, ((ia | ib) >> 8) != 0, bh, bl, wacc, racc, fa, fb, st, maskv,
+                              ca, cb);
+        // 1/sqrt(den) of this pair for the lane's 8 channels: requested now (the epilogue that
+        // read the previous values is done), used from the third MFMA gap of the next stage
+        const int ka = ia & 0xff, kb = ib & 0xff;
+        if constexpr (BW) {
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          fa[g] = *reinterpret_cast<const f32x4v *>(rdb + (long)ka * NzP + z0 + 8 * g);
-          fb[g] = *reinterpret_cast<const f32x4v *>(rdb + (long)kb * NzP + z0 + 8 * g);
+          for (int g = 0; g < 2; ++g) {
+            fa[g] = *reinterpret_cast<const f32x4v *>(rdb + (long)ka * NzP + zh + 8 * g);
+            fb[g] = *reinterpret_cast<const f32x4v *>(rdb + (long)kb * NzP + zh + 8 * g);
+          }
+        } else {
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            fa[g] = *reinterpret_cast<const f32x4v *>(rd_lane + sa * MF_RD_BYTES + 64 * HALF + 32 * g);
+            fb[g] = *reinterpret_cast<const f32x4v *>(rd_lane + sb * MF_RD_BYTES + 64 * HALF + 32 * g);
+          }
         }
-      } else {
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          fa[g] = *reinterpret_cast<const f32x4v *>(rd_lane + sa * MF_RD_BYTES + 32 * g);
-          fb[g] = *reinterpret_cast<const f32x4v *>(rd_lane + sb * MF_RD_BYTES + 32 * g);
-        }
+        ca = 31 - ka, cb = 31 - kb;
+      };
+      int p = 0;
+      for (; p + 1 < NP; p += 2) {
+        run(p, accX, accY);
+        run(p + 1, accY, accX);
       }
-      ca = 31 - ka, cb = 31 - kb;
-    };
-#define SM_ST(NB, P, W, R)                                                      \
-  do {                                                                          \
-    sm_stage<TERMS, NB>(ak_of(P), bh, bl, W, R, fa, fb, st, maskv, ca, cb);     \
-    load_f(P);                                                                  \
-  } while (0)
-    int p = 0;
-    for (; p + 1 < nNp; p += 2) {  // narrow pairs
-      SM_ST(3, p, accX, accY);
-      SM_ST(3, p + 1, accY, accX);
-    }
-    if constexpr (NODD) {
-      SM_ST(3, p, accX, accY);
-      ++p;
-      for (; p + 1 < NP; p += 2) {  // wide pairs, roles swapped
-        SM_ST(5, p, accY, accX);
-        SM_ST(5, p + 1, accX, accY);
-      }
-      if constexpr (WODD) {
-        SM_ST(5, p, accY, accX);
-        sm_drain(accY, fa, fb, st, maskv, ca, cb);
-      } else {
-        sm_drain(accX, fa, fb, st, maskv, ca, cb);
-      }
-    } else {
-      for (; p + 1 < NP; p += 2) {  // wide pairs
-        SM_ST(5, p, accX, accY);
-        SM_ST(5, p + 1, accY, accX);
-      }
-      if constexpr (WODD) {
-        SM_ST(5, p, accX, accY);
+      if constexpr (PODD) {
+        run(p, accX, accY);
         sm_drain(accX, fa, fb, st, maskv, ca, cb);
       } else {
         sm_drain(accY, fa, fb, st, maskv, ca, cb);
       }
-    }
-#undef SM_ST
 
-    // ---- store, mask glue (steps.py:781,788)
-    unsigned char mk[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) mk[i] = 0;
-    if (mask) {  // branch-free inside: every load is issued before the first is awaited
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        // channel min(zu + 4 h, Nz - 1): uniform base, the lane part clamped at the cube's end
-        const int zu = min(z0 + (i & 3) + 8 * (i >> 2), Nz - 1);
-        const int hs = (int)(min(4, Nz - 1 - zu) * S);
-        mk[i] = (mask + (long)zu * S + s_base)[rr + (h ? hs : 0)];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int zu = z0 + (i & 3) + 8 * (i >> 2);  // uniform part of the channel
-      if (zu + 4 * h < zc1) {
-        const long ubase = (long)zu * S + s_base;
-        float b = st.best[i] * inv;
-        const float w = st.worst[i] * inv;
-        int kk = 31 - (int)(__float_as_uint(st.key[i]) & 31u);
-        // profiles run narrow-first, not in index order: when every T is the same number (a
-        // spaxel of zeros) the first maximum is index 0 (np.argmax semantics, lib :1210)
-        if (st.best[i] == st.worst[i]) kk = 0;
-        if (mk[i]) b = 0.0f, kk = 0;
-        if (sv) {
-          (correl + ubase)[off_out] = b;
-          (correl_min + ubase)[off_out] = w;
-          (profile + ubase)[off_out] = (uint8_t)kk;
+      // store (mask glue: steps.py:781,788)
+      auto store = [&](auto straight_c) {
+        constexpr bool STRAIGHT = decltype(straight_c)::value;  // nothing to test per output
+        float *cp = correl + (long)zh * S + s_base, *np = correl_min + (long)zh * S + s_base;
+        uint8_t *pp = profile + (long)zh * S + s_base;
+        unsigned oo = off_out, oo4 = off_out4;
+        if constexpr (STRAIGHT) {
+          SM_PIN(oo);
+          SM_PIN(oo4);
         }
-        vmax = fmaxf(vmax, b);
-        vmin = fminf(vmin, w);
-      }
-    }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int zu = zh + (i & 3) + 8 * (i >> 2);  // uniform part of the channel
+          if (STRAIGHT || zu + 4 * h < zc1) {
+            float b = st.best[i] * inv;
+            const float w = st.worst[i] * inv;
+            int kk = 31 - (int)(__float_as_uint(st.key[i]) & 31u);
+            // profiles run narrow-first, not in index order: when every T is the same number (a
+            // spaxel of zeros) the first maximum is index 0 (np.argmax semantics, lib :1210)
+            if (st.best[i] == st.worst[i]) kk = 0;
+            if (mk[i]) b = 0.0f, kk = 0;
+            if (STRAIGHT || sv) {
+              stf(cp, oo4, b);
+              stf(np, oo4, w);
+              pp[oo] = (uint8_t)kk;
+            }
+            vmax = fmaxf(vmax, b);
+            vmin = fminf(vmin, w);
+          }
+          const long step = (i & 3) == 3 ? 5 * S : S;
+          cp += step, np += step, pp += step;
+        }
+      };
+      if (inside && all_valid) store(std::true_type{});
+      else store(std::false_type{});
+    });
   }
 }
 
@@ -381,8 +447,7 @@ template <int TERMS, int VARIANT>
 __global__ __launch_bounds__(64 * MF_WAVES, 1) void spectral_mfma2_kernel(
     const float *__restrict__ fsf, const float *__restrict__ rden,
     const float *__restrict__ rdi_s, int NzP, const uint4 *__restrict__ atab,
-    const int *__restrict__ pinfo, int K, int nNp, int NP, int Nz, int Ny, int Nx, int P,
-    int zchunk, const uint8_t *__restrict__ mask, float *__restrict__ correl,
+    const int *__restrict__ pinfo, int K, int NP, int Nz, int Ny, int Nx, int P, int zchunk, const uint8_t *__restrict__ mask, float *__restrict__ correl,
     uint8_t *__restrict__ profile, float *__restrict__ correl_min, float *__restrict__ part_max,
     float *__restrict__ part_min) {
   extern __shared__ __align__(16) char sm_lds[];
@@ -403,7 +468,7 @@ __global__ __launch_bounds__(64 * MF_WAVES, 1) void spectral_mfma2_kernel(
   // window block b starts at G[31 - zi + 8 h + 16 b]
   const int E0 = 8 * h - (r & 15) + 31;
   const char *a_lane = sm_lds + (E0 & 7) * MF_COPY_BYTES + (E0 >> 3) * 16;
-  // this wave's [K][16] table of 1/sqrt(den) for the current tile (behind the tap copies), in
+  // this wave's [K][32] table of 1/sqrt(den) for the current tile (behind the tap copies), in
   // the order the profiles are processed
   char *rd_wave = sm_lds + K * MF_PROF_BYTES + wv * K * MF_RD_BYTES;
   const bool sv = s_base + r < S;
@@ -419,16 +484,15 @@ __global__ __launch_bounds__(64 * MF_WAVES, 1) void spectral_mfma2_kernel(
     cls = sm_border_class(y, Ny, P) * P + sm_border_class(xx, Nx, P);
   }
   const float *rdb = rden + (long)cls * K * NzP + 4 * h;
-  // VARIANT: bit 0 = odd number of narrow pairs, bit 1 = odd number of wide pairs
-  constexpr bool NODD = (VARIANT & 1) != 0, WODD = (VARIANT & 2) != 0;
+  constexpr bool PODD = (VARIANT & 1) != 0;  // odd number of profile pairs
   if (__any(cls != ccls))
-    sm_tiles<TERMS, true, NODD, WODD>(fsf, rdb, rdi_s, NzP, pinfo, K, nNp, NP, Nz, S, s_base, rr,
-                                      sv, all_valid, h, lane, a_lane, rd_wave, zc0, zc1, mask,
-                                      correl, profile, correl_min, vmax, vmin);
+    sm_tiles<TERMS, true, PODD>(fsf, rdb, rdi_s, NzP, pinfo, K, NP, Nz, S, s_base, rr, sv,
+                                all_valid, h, lane, a_lane, rd_wave, zc0, zc1, mask, correl,
+                                profile, correl_min, vmax, vmin);
   else
-    sm_tiles<TERMS, false, NODD, WODD>(fsf, rdb, rdi_s, NzP, pinfo, K, nNp, NP, Nz, S, s_base, rr,
-                                       sv, all_valid, h, lane, a_lane, rd_wave, zc0, zc1, mask,
-                                       correl, profile, correl_min, vmax, vmin);
+    sm_tiles<TERMS, false, PODD>(fsf, rdb, rdi_s, NzP, pinfo, K, NP, Nz, S, s_base, rr, sv,
+                                 all_valid, h, lane, a_lane, rd_wave, zc0, zc1, mask, correl,
+                                 profile, correl_min, vmax, vmin);
   if (part_max) {
     const float a = fmaxf(vmax, __shfl_xor(vmax, 32));
     const float b = fminf(vmin, __shfl_xor(vmin, 32));
@@ -441,8 +505,8 @@ __global__ __launch_bounds__(64 * MF_WAVES, 1) void spectral_mfma2_kernel(
 
 }  // namespace
 
-// Launch: a wave = 32 spaxels x 16-channel tiles; z chunks sized to give every CU several blocks
-// (one 8-wave block per CU at a time: K * (5 KiB + 8 * 64 B) of LDS).  Returns the number of z
+// Launch: a wave = 32 spaxels x 32-channel tiles (two 16-channel halves); z chunks sized to give every CU several blocks
+// (one block per CU at a time: K * (4.5 KiB + MF_WAVES * 128 B) of LDS).  Returns the number of z
 // chunks (rows of part_max / part_min) in *nzc.  nN: number of narrow profiles (the first nN
 // slots of the processing order).
 int origin_spectral_mfma_launch(origin_ctx *ctx, int terms, const float *fsf, const float *rden,
@@ -454,22 +518,19 @@ int origin_spectral_mfma_launch(origin_ctx *ctx, int terms, const float *fsf, co
   const long bx = cdiv(S, 32 * MF_WAVES);
   int nzm = (int)(((long)ctx->num_cu * 8 + bx - 1) / bx);
   nzm = std::max(1, std::min(nzm, std::min(64, cdiv(Nz, 64))));
-  const int zcm = (cdiv(Nz, nzm) + 15) / 16 * 16;
+  const int zcm = (cdiv(Nz, nzm) + 31) / 32 * 32;
   nzm = cdiv(Nz, zcm);
   float *pmax = want_maps ? part : nullptr;
   float *pmin = want_maps ? part + (size_t)nzm * S : nullptr;
   const size_t lds = (size_t)K * (MF_PROF_BYTES + MF_WAVES * MF_RD_BYTES);
-  // pairs of slots (2p, 2p+1): narrow while both profiles are narrow (an odd last profile pairs
-  // with itself)
+  // pairs of slots (2p, 2p+1); an odd last profile pairs with itself
   const int NP = (K + 1) / 2;
-  int nNp = 0;
-  for (int p = 0; p < NP; ++p) nNp += std::min(2 * p + 1, K - 1) < nN;
-  const int variant = (nNp & 1) | (((NP - nNp) & 1) << 1);
+  const int variant = NP & 1;
+  (void)nN;
   const void *fn = nullptr;
 #define SM_PICK(T, V) \
   if (terms == T && variant == V) fn = (const void *)spectral_mfma2_kernel<T, V>
-  SM_PICK(3, 0); SM_PICK(3, 1); SM_PICK(3, 2); SM_PICK(3, 3);
-  SM_PICK(1, 0); SM_PICK(1, 1); SM_PICK(1, 2); SM_PICK(1, 3);
+  SM_PICK(3, 0); SM_PICK(3, 1); SM_PICK(1, 0); SM_PICK(1, 1);
 #undef SM_PICK
   if (!fn) {
     origin_set_error("spectral MFMA kernel: no variant %d for %d terms", variant, terms);
@@ -481,11 +542,9 @@ int origin_spectral_mfma_launch(origin_ctx *ctx, int terms, const float *fsf, co
   const uint4 *a_atab = atab;
   const int *a_pinfo = pinfo;
   const uint8_t *a_mask = mask;
-  int a_NzP = NzP, a_K = K, a_nNp = nNp, a_NP = NP, a_Nz = Nz, a_Ny = Ny, a_Nx = Nx, a_P = P,
-      a_zcm = zcm;
-  void *args[] = {&a_fsf, &a_rden, &a_rdi, &a_NzP, &a_atab, &a_pinfo, &a_K, &a_nNp, &a_NP, &a_Nz,
-                  &a_Ny, &a_Nx, &a_P, &a_zcm, &a_mask, &correl, &profile, &correl_min, &pmax,
-                  &pmin};
+  int a_NzP = NzP, a_K = K, a_NP = NP, a_Nz = Nz, a_Ny = Ny, a_Nx = Nx, a_P = P, a_zcm = zcm;
+  void *args[] = {&a_fsf, &a_rden, &a_rdi, &a_NzP, &a_atab, &a_pinfo, &a_K, &a_NP, &a_Nz, &a_Ny,
+                  &a_Nx, &a_P, &a_zcm, &a_mask, &correl, &profile, &correl_min, &pmax, &pmin};
   ORIGIN_HIP(hipLaunchKernel(fn, dim3((unsigned)bx, nzm), dim3(64 * MF_WAVES), args, lds,
                              ctx->stream));
   ORIGIN_LAUNCH_CHECK();

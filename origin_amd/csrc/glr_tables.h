@@ -9,12 +9,14 @@
 #pragma once
 
 constexpr int MF_TAP_SCALE_LOG2 = 12;                 // f16 taps are stored times 2^12
-constexpr int MF_GROUPS = 20;                         // 16-byte groups per shifted copy (15 used)
-constexpr int MF_COPY_BYTES = MF_GROUPS * 16;         // 320 = 256 + 64: conflict-free ds_read_b128
+constexpr int MF_GROUPS = 18;                         // 16-byte groups per shifted copy (14 used)
+// 288 = 256 + 32: the 16 lanes a ds_read_b128 serves at once are the 16 output channels of a
+// tile -- 8 copies x 2 adjacent groups -- and 2 copy + group covers the 16 bank quads once
+constexpr int MF_COPY_BYTES = MF_GROUPS * 16;
 constexpr int MF_PROF_BYTES = 2 * 8 * MF_COPY_BYTES;  // hi copies, then lo copies
-constexpr int MF_RD_BYTES = 16 * 4;                   // per wave and profile: 16 channels of 1/sqrt(den)
+constexpr int MF_RD_BYTES = 32 * 4;                   // per wave and profile: 32 channels of 1/sqrt(den)
 constexpr int MF_WAVES = 8;                           // waves per block (two per SIMD)
-constexpr int MF_MAX_K = 28;                          // 28 * (5120 + 8 * 64) B = 154 KiB of LDS
+constexpr int MF_MAX_K = 28;                          // 28 * (4608 + 8 * 128) B = 154 KiB of LDS
 // zero channels in front of / behind the cube_fsf work cube: the matrix-core spectral kernel reads
 // its 96-channel windows [z0 - 32, z0 + 63] without bounds tests
 constexpr int MF_PAD_FRONT = 32, MF_PAD_BACK = 64;
