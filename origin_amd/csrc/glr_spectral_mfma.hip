@@ -47,6 +47,10 @@
 
 namespace {
 
+// Measured at 3681 x 600 x 600: two waves per SIMD with the next tile's window prefetched into
+// registers (240 VGPRs) 12.6 ms, three waves per SIMD without it (168 VGPRs) 11.7 ms.
+constexpr bool SM_PREFETCH = MF_WAVES <= 8;
+
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -263,7 +267,7 @@ __device__ __forceinline__ void sm_tiles(
     // It was requested while the previous tile's second half ran (xn); only the first tile of a
     // chunk loads it here.
     float x[6][8];
-    if (z0 == zc0) load_window(z0, x);
+    if (!SM_PREFETCH || z0 == zc0) load_window(z0, x);
     else {
 #pragma unroll
       for (int ks = 0; ks < 6; ++ks)
@@ -323,7 +327,7 @@ __device__ __forceinline__ void sm_tiles(
       constexpr int HALF = decltype(hc)::value;
       const int zh = z0 + 16 * HALF;  // first output channel of this half
       if constexpr (HALF == 1) {
-        if (z0 + 32 < zc1) load_window(z0 + 32, xn);  // lands while this half computes
+        if (SM_PREFETCH && z0 + 32 < zc1) load_window(z0 + 32, xn);  // lands while this half computes
       }
       if (zh >= zc1) return;  // (uniform)
       // mask bytes of this half's outputs (steps.py:781,788): requested now, used after the pairs.

@@ -15,8 +15,8 @@ constexpr int MF_GROUPS = 18;                         // 16-byte groups per shif
 constexpr int MF_COPY_BYTES = MF_GROUPS * 16;
 constexpr int MF_PROF_BYTES = 2 * 8 * MF_COPY_BYTES;  // hi copies, then lo copies
 constexpr int MF_RD_BYTES = 32 * 4;                   // per wave and profile: 32 channels of 1/sqrt(den)
-constexpr int MF_WAVES = 8;                           // waves per block (two per SIMD)
-constexpr int MF_MAX_K = 28;                          // 28 * (4608 + 8 * 128) B = 154 KiB of LDS
+constexpr int MF_WAVES = 12;                          // waves per block (three per SIMD: 168 VGPRs)
+constexpr int MF_MAX_K = 26;                          // 26 * (4608 + 12 * 128) B = 156 KiB of LDS
 // zero channels in front of / behind the cube_fsf work cube: the matrix-core spectral kernel reads
 // its 96-channel windows [z0 - 32, z0 + 63] without bounds tests
 constexpr int MF_PAD_FRONT = 32, MF_PAD_BACK = 64;
