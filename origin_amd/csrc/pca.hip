@@ -79,6 +79,12 @@ enum {
 };
 constexpr int PCA_CAP = 64;  // vectors kept per area before the cube is flushed (F = X - U C)
 #define DSC(f, k) (D[(long)(f) * nw + (k)])
+// The host builds an iteration's work list from the nuisance counts of the PREVIOUS selection
+// (upper bounds: the counts only shrink) and enqueues the whole chain behind the selection that
+// then writes the real counts into DF_N / DF_NB on the device (select_publish).  An area whose
+// selection came out with fewer than two nuisance spaxels has finished (lib :899 / :927): every
+// kernel of the chain leaves its slot alone.
+#define PCA_SLOT_DONE(k) (DSC(DF_N, k) < 2)
 
 // ------------------------------------------------------------------------------------
 // selection: nuisance list, background list, iteration bookkeeping.  One block per area.
@@ -565,9 +571,20 @@ __device__ __forceinline__ void pca_select_fast_body(
 // and a stream synchronisation (~30 us of wake-up latency per iteration), each block stores its
 // two numbers straight into mapped, coherent host memory; the last block to finish (device
 // counter) raises the generation flag the host spins on.
+// patchD / kidx / nw: the work list of the iteration this selection opens, already on the device
+// with counts from the previous selection; the real n / nb of the area go into its slot.
 __device__ __forceinline__ void select_publish(int a, int na, const int *n_out, const int *nb_out,
-                                               int *host_out, unsigned *counter, int gen) {
-  if (threadIdx.x != 0 || !host_out) return;
+                                               int *host_out, unsigned *counter, int gen,
+                                               long *patchD, const int *kidx, int nw) {
+  if (threadIdx.x != 0) return;
+  if (patchD) {
+    const int k = kidx[a];
+    if (k >= 0) {
+      patchD[(long)DF_N * nw + k] = n_out[a];
+      patchD[(long)DF_NB * nw + k] = nb_out[a];
+    }
+  }
+  if (!host_out) return;
   host_out[a] = n_out[a];
   host_out[na + a] = nb_out[a];
   __threadfence_system();
@@ -584,10 +601,10 @@ __global__ __launch_bounds__(1024) void pca_select_kernel(
     int *__restrict__ nbiter, int *__restrict__ nstop, int *__restrict__ mapO2,
     int *__restrict__ nuis, int *__restrict__ bg, int *__restrict__ nuis_pos,
     int *__restrict__ bg_pos, int *__restrict__ n_out, int *__restrict__ nb_out, int lds_cap,
-    int *host_out, unsigned *counter, int gen) {
+    int *host_out, unsigned *counter, int gen, long *patchD, const int *kidx, int nw) {
   pca_select_body(spx, spx_off, test, thr_, noise_pop, itermax, active, nbiter, nstop, mapO2, nuis,
                   bg, nuis_pos, bg_pos, n_out, nb_out, lds_cap);
-  select_publish(blockIdx.x, gridDim.x, n_out, nb_out, host_out, counter, gen);
+  select_publish(blockIdx.x, gridDim.x, n_out, nb_out, host_out, counter, gen, patchD, kidx, nw);
 }
 
 __global__ __launch_bounds__(1024) void pca_select_fast_kernel(
@@ -597,10 +614,10 @@ __global__ __launch_bounds__(1024) void pca_select_fast_kernel(
     int *__restrict__ nuis, int *__restrict__ bg, int *__restrict__ nuis_pos,
     int *__restrict__ bg_pos, int *__restrict__ n_out, int *__restrict__ nb_out, int *host_out,
     unsigned *counter, int gen, uint8_t *__restrict__ inB, int *__restrict__ dlist,
-    int *__restrict__ ndiff) {
+    int *__restrict__ ndiff, long *patchD, const int *kidx, int nw) {
   pca_select_fast_body(spx, spx_off, test, thr_, noise_pop, itermax, active, nbiter, nstop, mapO2,
                        nuis, bg, nuis_pos, bg_pos, n_out, nb_out, inB, dlist, ndiff);
-  select_publish(blockIdx.x, gridDim.x, n_out, nb_out, host_out, counter, gen);
+  select_publish(blockIdx.x, gridDim.x, n_out, nb_out, host_out, counter, gen, patchD, kidx, nw);
 }
 
 // ------------------------------------------------------------------------------------
@@ -611,6 +628,7 @@ __global__ __launch_bounds__(1024) void cbar_kernel(const double *__restrict__ C
                                                     const long *__restrict__ D, int nw,
                                                     double *__restrict__ cbar) {
   const int k = blockIdx.x;
+  if (PCA_SLOT_DONE(k)) return;
   const int T = (int)DSC(DF_T, k);
   const int nb = (int)DSC(DF_NB, k);
   const long o0 = DSC(DF_LIST0, k);
@@ -653,7 +671,7 @@ __global__ __launch_bounds__(256) void bmean_kernel(const float *__restrict__ X,
                                                     double *__restrict__ Ssum) {
   const int k = blockIdx.y;
   const int z = blockIdx.x * 4 + threadIdx.y;
-  if (z >= Nz) return;
+  if (z >= Nz || PCA_SLOT_DONE(k)) return;
   const long o0 = DSC(DF_LIST0, k);
   const int nb = (int)DSC(DF_NB, k), T = (int)DSC(DF_T, k);
   const int a = (int)DSC(DF_AREA, k);
@@ -703,7 +721,7 @@ __global__ __launch_bounds__(1024) void gather_xp_kernel(
   const int k = blockIdx.y;
   const int ld = (int)DSC(DF_LD, k);
   const int j = blockIdx.x * 64 + threadIdx.x;
-  if (blockIdx.x * 64 >= ld) return;  // whole block out of range (uniform)
+  if (blockIdx.x * 64 >= ld || PCA_SLOT_DONE(k)) return;  // whole block out of range (uniform)
   const int n = (int)DSC(DF_N, k), T = (int)DSC(DF_T, k);
   const bool live = j < n;   // real nuisance column
   const bool inld = j < ld;  // padded column (stored as zeros)
@@ -783,6 +801,7 @@ __global__ __launch_bounds__(256) void project_xp_kernel(const double *__restric
                                                          const double *__restrict__ cpart,
                                                          long ctot, int nzb) {
   const int k = blockIdx.y;
+  if (PCA_SLOT_DONE(k)) return;
   const int ld = (int)DSC(DF_LD, k);
   const double *F = Fb + DSC(DF_XP, k);
   double *X = Xp + DSC(DF_XP, k);
@@ -826,9 +845,11 @@ __global__ __launch_bounds__(64) void gram_kernel(const double *__restrict__ Xp,
                                                   const int *__restrict__ tile_a, int Nz,
                                                   int ksplit, double *__restrict__ slab,
                                                   const long *__restrict__ g_off,
-                                                  long slab_stride) {
+                                                  long slab_stride,
+                                                  const long *__restrict__ n_) {
   const int t = blockIdx.x;
   const int a = tile_a[t];
+  if (n_ && n_[a] < 2) return;  // the area finished with this iteration's selection
   const int ld = (int)ld_[a];
   const int i0 = tile_i[t] * 32, j0 = tile_j[t] * 32;
   const int ks = blockIdx.y;
@@ -884,9 +905,11 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const double *__restri
                                                           const int *__restrict__ tile_j,
                                                           const int *__restrict__ tile_a,
                                                           double *__restrict__ G,
-                                                          const long *__restrict__ g_off) {
+                                                          const long *__restrict__ g_off,
+                                                          const long *__restrict__ n_) {
   const int t = blockIdx.x;
   const int a = tile_a[t];
+  if (n_ && n_[a] < 2) return;
   const int ld = (int)ld_[a];
   const int i0 = tile_i[t] * 32, j0 = tile_j[t] * 32;
   double *Ga = G + g_off[a];
@@ -1331,6 +1354,8 @@ __global__ __launch_bounds__(1024) void lanczos_kernel(const double *__restrict_
   double *svec = ws.x;
   const int k = blockIdx.x;
   const int n = (int)n_[k], ld = (int)ld_[k];
+  if (n < 1) return;  // (n == 1 is a valid 1 x 1 problem for origin_pca_eig; the PCA loop never
+                      // sends fewer than two columns except for areas that have just finished)
   const double *Gk = G + g_off[k];
   double *Qk;  // (LANCZOS_M + 2) rows of length ld; last row = Ritz vector
   if constexpr (QLDS) Qk = lz_dyn;
@@ -1540,7 +1565,7 @@ __global__ __launch_bounds__(256) void xv_kernel(const double *__restrict__ Xp,
                                                  double *__restrict__ u) {
   const int k = blockIdx.y;
   const int z = blockIdx.x * 4 + threadIdx.y;
-  if (z >= Nz) return;
+  if (z >= Nz || PCA_SLOT_DONE(k)) return;
   const int ld = (int)DSC(DF_LD, k), n = (int)DSC(DF_N, k);
   const double *row = Xp + DSC(DF_XP, k) + (long)z * ld;
   const double *vk = v + DSC(DF_C, k);
@@ -1560,6 +1585,7 @@ __global__ __launch_bounds__(256) void uw_partial_kernel(const double *__restric
                                                          double *__restrict__ part) {
   __shared__ double wred[4][PCA_CAP + 1];
   const int k = blockIdx.y, b = blockIdx.x;
+  if (PCA_SLOT_DONE(k)) return;
   const int T = (int)DSC(DF_T, k);
   const double *uk = u + (long)k * Nz;
   const double *Ua = U + (long)DSC(DF_AREA, k) * Nz * PCA_CAP;
@@ -1590,6 +1616,7 @@ __global__ __launch_bounds__(1024) void normalize_kernel(double *__restrict__ u,
                                                          double *__restrict__ wq) {
   __shared__ double s_inv;
   const int k = blockIdx.x;
+  if (PCA_SLOT_DONE(k)) return;
   const int T = (int)DSC(DF_T, k);
   double *uk = u + (long)k * Nz;
   double *Ua = U + (long)DSC(DF_AREA, k) * Nz * PCA_CAP;
@@ -1625,7 +1652,7 @@ __global__ __launch_bounds__(256) void deflate_dot_kernel(const float *__restric
   const int k = blockIdx.z;
   const int ns = (int)DSC(DF_NS, k);
   const int li = blockIdx.x * 256 + threadIdx.x;
-  if (blockIdx.x * 256 >= ns) return;
+  if (blockIdx.x * 256 >= ns || PCA_SLOT_DONE(k)) return;
   const bool live = li < ns;
   const long col = spx[DSC(DF_LIST0, k) + (live ? li : ns - 1)];
   const double *uk = u + (long)k * Nz;
@@ -1653,6 +1680,7 @@ __global__ __launch_bounds__(256) void deflate_dot_rows_kernel(
   if (s < S) {
     const int a = area_of[s];
     if (a >= 0) k = kidx[a];
+    if (k >= 0 && PCA_SLOT_DONE(k)) k = -1;
   }
   if (!__any(k >= 0)) return;  // nothing of this wave's 64 spaxels iterates (no block barrier used)
   const long sc = k >= 0 ? s : (long)blockIdx.x * 256;  // idle lanes re-read the block's first spaxel
@@ -1690,7 +1718,7 @@ __global__ __launch_bounds__(256) void deflate_finish_kernel(const int *__restri
   const int k = blockIdx.y;
   const int ns = (int)DSC(DF_NS, k);
   const int li = blockIdx.x * 256 + threadIdx.x;
-  if (li >= ns) return;
+  if (li >= ns || PCA_SLOT_DONE(k)) return;
   const int T = (int)DSC(DF_T, k);
   const long pos = DSC(DF_LIST0, k) + li;
   const long ci = DSC(DF_CBASE, k) + li;
@@ -1887,7 +1915,8 @@ int eig_launch(origin_ctx *ctx, int nmat, long ldmax, const double *d_G, const l
 int gram_launch(origin_ctx *ctx, const double *d_Xp, const long *d_xp_off, const long *d_ld, int Nz,
                 int ntiles, const int *d_ti, const int *d_tj, const int *d_ta, long g_total,
                 double *d_G, const long *d_g_off, bool skip_reduce = false,
-                const double **slab_out = nullptr, int *ksplit_out = nullptr) {
+                const double **slab_out = nullptr, int *ksplit_out = nullptr,
+                const long *d_n = nullptr) {
   // K-split so that small problems still put >= ~8 waves on every CU
   int ksplit = (int)(((long)ctx->num_cu * 8 + ntiles - 1) / ntiles);
   if (ksplit < 1) ksplit = 1;
@@ -1898,13 +1927,14 @@ int gram_launch(origin_ctx *ctx, const double *d_Xp, const long *d_xp_off, const
   if (rc) return rc;
   ProfScope ps(ctx, K_PCA_GRAM, 2);
   hipLaunchKernelGGL(gram_kernel, dim3(ntiles, ksplit), dim3(64), 0, ctx->stream, d_Xp, d_xp_off,
-                     d_ld, d_ti, d_tj, d_ta, Nz, ksplit, (double *)scr, d_g_off, g_total);
+                     d_ld, d_ti, d_tj, d_ta, Nz, ksplit, (double *)scr, d_g_off, g_total, d_n);
   if (slab_out) *slab_out = (const double *)scr;
   if (ksplit_out) *ksplit_out = ksplit;
   // the small-matrix eigen-solver sums the slabs itself when every matrix of the launch is small
   if (!skip_reduce)
     hipLaunchKernelGGL(gram_reduce_kernel, dim3(ntiles), dim3(256), 0, ctx->stream,
-                       (const double *)scr, g_total, ksplit, d_ld, d_ti, d_tj, d_ta, d_G, d_g_off);
+                       (const double *)scr, g_total, ksplit, d_ld, d_ti, d_tj, d_ta, d_G, d_g_off,
+                       d_n);
   ORIGIN_LAUNCH_CHECK();
   return ORIGIN_OK;
 }
@@ -2131,47 +2161,60 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
   int iters = 0;
   int gen = 1;  // selections launched so far + 1
   const bool use_delta = bg_delta && nsmax_all <= 1024 * SEL_EPT;
-  for (;;) {
-    {
-      ProfScope ps(ctx, K_PCA_SELECT, 2);
-      if (nsmax_all <= 1024 * SEL_EPT)
-        hipLaunchKernelGGL(pca_select_fast_kernel, dim3(na), dim3(1024),
-                           (size_t)nsmax_all * sizeof(int), st, d_spx, d_spx_off, d_test, d_thr,
-                           noise_pop, itermax, d_active, d_nbiter, d_nstop, d_mapO2, d_nuis, d_bg,
-                           d_npos[iters & 1], d_bg_pos, d_n, d_nb, d_hostout, d_selcnt, gen,
-                           use_delta ? d_inb : nullptr, d_dlist, d_ndiff);
-      else
-        hipLaunchKernelGGL(pca_select_kernel, dim3(na), dim3(1024), sel_lds, st, d_spx, d_spx_off,
-                           d_test, d_thr, noise_pop, itermax, d_active, d_nbiter, d_nstop, d_mapO2,
-                           d_nuis, d_bg, d_npos[iters & 1], d_bg_pos, d_n, d_nb, sel_cap, d_hostout,
-                           d_selcnt, gen);
-    }
-    ORIGIN_LAUNCH_CHECK();
-    {
-      // n / nb arrive in mapped host memory; wait for the generation flag of this selection
-      // (everything enqueued before it on the stream is complete by then).  Fall back to a
-      // stream synchronisation after 5 s (a faulted kernel never raises the flag).
-      int *flag = h_nnb + 2 * na;
-      const auto t_start = std::chrono::steady_clock::now();
-      long polls = 0;
-      while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != gen) {
-        __builtin_ia32_pause();
-        if ((++polls & 0xfffff) == 0 &&
-            std::chrono::steady_clock::now() - t_start > std::chrono::seconds(5)) {
-          ORIGIN_HIP(hipStreamSynchronize(st));
-          if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != gen) {
-            origin_set_error("greedy PCA: the selection kernel did not report back");
-            return ORIGIN_E_HIP;
-          }
+  // The selection of iteration t; with patchD the work list of that iteration is on the device
+  // already and receives the real counts (see PCA_SLOT_DONE).
+  auto launch_select = [&](long *patchD, const int *d_kidx, int nw_) {
+    ProfScope ps(ctx, K_PCA_SELECT, 2);
+    if (nsmax_all <= 1024 * SEL_EPT)
+      hipLaunchKernelGGL(pca_select_fast_kernel, dim3(na), dim3(1024),
+                         (size_t)nsmax_all * sizeof(int), st, d_spx, d_spx_off, d_test, d_thr,
+                         noise_pop, itermax, d_active, d_nbiter, d_nstop, d_mapO2, d_nuis, d_bg,
+                         d_npos[iters & 1], d_bg_pos, d_n, d_nb, d_hostout, d_selcnt, gen,
+                         use_delta ? d_inb : nullptr, d_dlist, d_ndiff, patchD, d_kidx, nw_);
+    else
+      hipLaunchKernelGGL(pca_select_kernel, dim3(na), dim3(1024), sel_lds, st, d_spx, d_spx_off,
+                         d_test, d_thr, noise_pop, itermax, d_active, d_nbiter, d_nstop, d_mapO2,
+                         d_nuis, d_bg, d_npos[iters & 1], d_bg_pos, d_n, d_nb, sel_cap, d_hostout,
+                         d_selcnt, gen, patchD, d_kidx, nw_);
+  };
+  // n / nb arrive in mapped host memory; wait for the generation flag of the newest selection
+  // (everything enqueued before it on the stream is complete by then).  Fall back to a stream
+  // synchronisation after 5 s (a faulted kernel never raises the flag).
+  auto wait_select = [&]() -> int {
+    int *flag = h_nnb + 2 * na;
+    const auto t_start = std::chrono::steady_clock::now();
+    long polls = 0;
+    while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != gen) {
+      __builtin_ia32_pause();
+      if ((++polls & 0xfffff) == 0 &&
+          std::chrono::steady_clock::now() - t_start > std::chrono::seconds(5)) {
+        ORIGIN_HIP(hipStreamSynchronize(st));
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != gen) {
+          origin_set_error("greedy PCA: the selection kernel did not report back");
+          return ORIGIN_E_HIP;
         }
       }
-      ++gen;
     }
+    ++gen;
+    return ORIGIN_OK;
+  };
+  // Iteration 0: the selection first, then the chain with exact counts.  From iteration 1 on the
+  // host runs one selection AHEAD of the device: the work list of iteration t is built from the
+  // counts of selection t-1 (upper bounds), uploaded, and selection t + the chain of iteration t
+  // are enqueued before the host waits for selection t -- the device never waits for the host
+  // (the hand-shake + descriptor upload cost ~60 us of idle device per iteration before).
+  std::vector<int> n_lay(2 * (size_t)na, 0);  // counts the next work list is laid out for
+  launch_select(nullptr, nullptr, 0);
+  ORIGIN_LAUNCH_CHECK();
+  if ((rc = wait_select())) return rc;
+  memcpy(n_lay.data(), h_nnb, 2 * (size_t)na * sizeof(int));
+  bool exact = true;
+  for (;;) {
     // ---- work list of this iteration
     int nw = 0;
     bool full = false;
     for (int a = 0; a < na; ++a)
-      if (h_nnb[a] >= 2) {
+      if (n_lay[a] >= 2) {
         ++nw;
         full = full || T[a] >= PCA_CAP;
       }
@@ -2183,14 +2226,14 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
     std::vector<int> ti, tj, ta;
     long nsum = 0;
     for (int a = 0; a < na; ++a) {
-      const int n = h_nnb[a];
+      const int n = n_lay[a];
       if (n < 2) continue;
       const int ld = (n + 15) / 16 * 16;
       const int ns = (int)(h_spx_off[a + 1] - h_spx_off[a]);
       D[(size_t)DF_AREA * nw + k] = a;
       D[(size_t)DF_LIST0 * nw + k] = h_spx_off[a];
       D[(size_t)DF_N * nw + k] = n;
-      D[(size_t)DF_NB * nw + k] = h_nnb[na + a];
+      D[(size_t)DF_NB * nw + k] = n_lay[na + a];
       D[(size_t)DF_LD * nw + k] = ld;
       D[(size_t)DF_XP * nw + k] = xp;
       D[(size_t)DF_C * nw + k] = c;
@@ -2249,6 +2292,10 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
     const int *d_kidx_it = (const int *)((char *)b_desc.p + dbytes + tbytes);
     ORIGIN_HIP(hipMemcpyAsync(b_desc.p, h_stage, dbytes + tbytes + kbytes, hipMemcpyHostToDevice,
                               st));
+    if (!exact) {  // this iteration's selection: fills DF_N / DF_NB of the list just uploaded
+      launch_select(dD, d_kidx_it, nw);
+      ORIGIN_LAUNCH_CHECK();
+    }
     if ((rc = b_xp.reserve(ctx, (size_t)xp * sizeof(double)))) return rc;
     if ((rc = b_fb[iters & 1]->reserve(ctx, (size_t)xp * sizeof(double)))) return rc;
     double *d_Fb = (double *)b_fb[iters & 1]->p;
@@ -2299,7 +2346,7 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
     const double *d_slab = nullptr;
     int gram_ksplit = 0;
     if ((rc = gram_launch(ctx, d_Xp, dXP, dLD, Nz, ntiles, d_ti, d_tj, d_ta, g, d_G, dG, all_small,
-                          &d_slab, &gram_ksplit)))
+                          &d_slab, &gram_ksplit, dN)))
       return rc;
     {
       void *scr = nullptr;
@@ -2368,12 +2415,19 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
                          dD, nw, nzs, Nz, cb, cpart, d_wq, d_C, ntot, d_test);
     }
     ORIGIN_LAUNCH_CHECK();
+    // the real counts of this iteration (the device is busy with its chain meanwhile)
+    if (!exact) {
+      if ((rc = wait_select())) return rc;
+      memcpy(n_lay.data(), h_nnb, 2 * (size_t)na * sizeof(int));
+    }
+    exact = false;
     for (int w = 0; w < nw; ++w) {
       const int a = (int)D[(size_t)DF_AREA * nw + w];
+      if (n_lay[a] < 2) continue;  // finished with this selection: its slot was left alone
       T[a] += 1;
       fb_off[a] = D[(size_t)DF_XP * nw + w];  // this iteration's block becomes the source
       fb_ld[a] = D[(size_t)DF_LD * nw + w];
-      fb_n[a] = D[(size_t)DF_N * nw + w];
+      fb_n[a] = n_lay[a];
     }
     ++iters;
   }
