@@ -2209,7 +2209,29 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
   if ((rc = wait_select())) return rc;
   memcpy(n_lay.data(), h_nnb, 2 * (size_t)na * sizeof(int));
   bool exact = true;
+  // Default: selection, hand-shake, exact work list, chain.  ORIGIN_PCA_PIPELINED=1 lets the host
+  // run one selection ahead (below).  Measured A/B at 3681 x 600 x 600 (57 iterations): 25.7-25.9
+  // against 26.0-26.3 ms -- the loop is bound by the device (host: 2 ms of enqueueing, 20 ms of
+  // waiting), the hand-shake hides behind the chain either way, and lists laid out for the
+  // previous counts make the Gram / dot kernels of iterations 1-7 a little larger.  (The 120 us
+  // gaps per tail iteration in rocprofv3 timelines are per-dispatch profiler overhead: the
+  // unprofiled tail runs at its kernels' busy time, ~125 us per iteration.)
+  const bool pipelined = getenv("ORIGIN_PCA_PIPELINED") != nullptr;
+  // host-side phase times of the loop (ORIGIN_PCA_DEBUG): building the list, enqueueing, waiting
+  double t_build = 0, t_enq = 0, t_wait = 0;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return std::chrono::duration<double>(b - a).count();
+  };
   for (;;) {
+    const auto tp0 = now();
+    if (!pipelined && iters > 0) {
+      launch_select(nullptr, nullptr, 0);
+      ORIGIN_LAUNCH_CHECK();
+      if ((rc = wait_select())) return rc;
+      memcpy(n_lay.data(), h_nnb, 2 * (size_t)na * sizeof(int));
+      exact = true;
+    }
     // ---- work list of this iteration
     int nw = 0;
     bool full = false;
@@ -2290,6 +2312,8 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
       memcpy(ht + 3 * (size_t)ntiles, kidx.data(), kbytes);
     }
     const int *d_kidx_it = (const int *)((char *)b_desc.p + dbytes + tbytes);
+    const auto tp1 = now();
+    t_build += secs(tp0, tp1);
     ORIGIN_HIP(hipMemcpyAsync(b_desc.p, h_stage, dbytes + tbytes + kbytes, hipMemcpyHostToDevice,
                               st));
     if (!exact) {  // this iteration's selection: fills DF_N / DF_NB of the list just uploaded
@@ -2416,8 +2440,11 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
     }
     ORIGIN_LAUNCH_CHECK();
     // the real counts of this iteration (the device is busy with its chain meanwhile)
+    const auto tp2 = now();
+    t_enq += secs(tp1, tp2);
     if (!exact) {
       if ((rc = wait_select())) return rc;
+      t_wait += secs(tp2, now());
       memcpy(n_lay.data(), h_nnb, 2 * (size_t)na * sizeof(int));
     }
     exact = false;
@@ -2431,6 +2458,9 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
     }
     ++iters;
   }
+  if (getenv("ORIGIN_PCA_TIMING"))
+    fprintf(stderr, "[pca] host loop: %d iterations, build %.2f ms, enqueue %.2f ms, wait %.2f ms\n",
+            iters, 1e3 * t_build, 1e3 * t_enq, 1e3 * t_wait);
   if ((rc = flush())) return rc;
   ORIGIN_HIP(hipMemcpyAsync(h_nnb, d_nstop, sizeof(int), hipMemcpyDeviceToHost, st));
   ORIGIN_HIP(hipStreamSynchronize(st));

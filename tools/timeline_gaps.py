@@ -1,6 +1,6 @@
 """Busy time against wall span of the greedy-PCA iterations in a rocprofv3 kernel trace.
 
-usage: python tools/timeline_gaps.py <kernel_trace.csv>
+usage: python tools/timeline_gaps.py <kernel_trace.csv | results.db>
 An iteration starts at each pca_select*_kernel; for the last full PCA run in the trace the
 script prints, per iteration, the wall span, the summed kernel time and the per-kernel split.
 """
@@ -9,9 +9,21 @@ import sys
 from collections import defaultdict
 
 rows = []
-with open(sys.argv[1]) as f:
-    for r in csv.DictReader(f):
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0]))
+
+
+def clean(name):
+    return name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0]
+
+
+if sys.argv[1].endswith(".db"):  # rocprofv3's rocpd output (ROCm 7.2 default)
+    import sqlite3
+    cur = sqlite3.connect(sys.argv[1]).cursor()
+    for name, start, end in cur.execute("select name, start, end from kernels"):
+        rows.append((int(start), int(end), clean(name)))
+else:
+    with open(sys.argv[1]) as f:
+        for r in csv.DictReader(f):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), clean(r["Kernel_Name"])))
 rows.sort()
 # split into iterations at select kernels
 starts = [i for i, r in enumerate(rows) if "pca_select" in r[2]]
