@@ -162,6 +162,7 @@ def main():
 
     def one_step():
         t0 = time.perf_counter()
+        ctx.aux_join()  # (coef_buf / cont_dct of the previous step: idle after its closing sync)
         coef = kernels.dct_fit(ctx, raw, var, mask, 10, False, coef=coef_buf)
         zsum, zcnt = kernels.dct_resid_sums(ctx, raw, mask, coef, zsum=zsum_buf, zcnt=zcnt_buf)
         if comm is not None:
@@ -169,9 +170,10 @@ def main():
         pre = kernels.dct_standardize(ctx, raw, var, mask, coef, zsum, zcnt, cube_std=cube_std,
                                       want_cont=False, o2=o2_buf, ima_std=ima_std)
         o2 = pre["o2"].to_host()
-        # the continuum cube is not needed by anything below: it runs while the host fits the
-        # thresholds (same step, same stream; the closing synchronisation waits for it)
-        kernels.dct_cont_std(ctx, var, coef, cont_dct=cont_dct, ima_dct=ima_dct)
+        # the continuum cube is not needed by anything below: it runs on the auxiliary
+        # low-priority stream, under the host's threshold fit and the latency-bound kernels of the
+        # greedy PCA (same step: the closing synchronisation waits for both streams)
+        kernels.dct_cont_std(ctx, var, coef, cont_dct=cont_dct, ima_dct=ima_dct, aux=True)
         t1 = time.perf_counter()
         thr = pipeline.pca_threshold(o2, local_map, nb_local, 0.01, spx=spx)
         t2 = time.perf_counter()
@@ -436,6 +438,23 @@ def main():
                           "cube_faint, cube_correl, maxmap); H2D + D2H + float64 widening "
                           "included; never `value`")
 
+    # ---- per-rank phase times and PCA imbalance (each rank fills its row of one all-reduce) ----
+    per_rank = None
+    if comm is not None:
+        keys = ("dct_std", "threshold_fit_host", "greedy_pca", "glr")
+        row = np.zeros((world, len(keys) + 3))
+        row[rank, :len(keys)] = [1e3 * phase.get(k_, 0.0) / max(1, args.steps) for k_ in keys]
+        row[rank, len(keys):] = [info.get("pca_iters", 0), len(spx), float(ny * nx)]
+        allrows = comm.allreduce_sum(row.reshape(-1)).reshape(world, -1)
+        per_rank = dict(phases_ms={k_: [round(v, 2) for v in allrows[:, i]]
+                                   for i, k_ in enumerate(keys)},
+                        pca_iterations=[int(v) for v in allrows[:, len(keys)]],
+                        areas=[int(v) for v in allrows[:, len(keys) + 1]],
+                        spaxels=[int(v) for v in allrows[:, len(keys) + 2]],
+                        note="wall time per step on each rank between its own synchronisation "
+                             "points; a rank that finishes its PCA early waits in the halo exchange "
+                             "(counted in glr)")
+
     if rank == 0:
         line = {
             "metric": "voxels/s through DCT+PCA+GLR (ORIGIN hot path)",
@@ -466,6 +485,7 @@ def main():
             "cpu_baseline": cpu_baseline,
             "check": check,
             "e2e": e2e,
+            "per_rank": per_rank,
             "wall_ms_per_step_by_phase": {k: round(1e3 * v / max(1, args.steps), 2)
                                           for k, v in phase.items()},
             "kernels_ms_per_step": {k: round(v[0] / max(1, args.steps), 3)

@@ -46,7 +46,12 @@ int origin_abi_version(void);
 int origin_device_count(int *count);
 int origin_ctx_create(int device, origin_ctx **out);
 int origin_ctx_destroy(origin_ctx *ctx);
-int origin_sync(origin_ctx *ctx);
+int origin_sync(origin_ctx *ctx); /* main stream and, if work is pending there, the aux stream */
+/* Work enqueued through an *_async entry point runs on the context's low-priority auxiliary
+ * stream, ordered after everything enqueued on the main stream before the call.  Its inputs
+ * must stay untouched and its outputs unread until origin_aux_join (the main stream waits for
+ * it; no host synchronisation) or origin_sync. */
+int origin_aux_join(origin_ctx *ctx);
 int origin_device_name(origin_ctx *ctx, char *buf, int buflen);
 int origin_mem_info(origin_ctx *ctx, size_t *free_bytes, size_t *total_bytes);
 /* the hipStream_t of the context, as an opaque pointer (for interop / RCCL) */
@@ -167,6 +172,10 @@ int origin_dct_standardize(origin_ctx *ctx, const float *d_raw, const float *d_v
  * Same values as origin_dct_standardize gives. */
 int origin_dct_cont_std(origin_ctx *ctx, const float *d_var, const double *d_coef, int Nz, int Ny,
                         int Nx, int order, float *d_cont_dct, float *d_ima_dct);
+/* the same on the auxiliary stream (see origin_aux_join): nothing downstream of the O2 map needs
+ * cont_dct, so the pass can hide behind the greedy PCA's latency-bound kernels */
+int origin_dct_cont_std_async(origin_ctx *ctx, const float *d_var, const double *d_coef, int Nz,
+                              int Ny, int Nx, int order, float *d_cont_dct, float *d_ima_dct);
 
 /* ---- B. O2 test and greedy PCA ---------------------------------------------------- */
 

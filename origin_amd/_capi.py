@@ -58,6 +58,8 @@ SIGNATURES = {
     "origin_dct_resid_sums": [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp],
     "origin_dct_standardize": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp],
     "origin_dct_cont_std": [vp, vp, vp, i32, i32, i32, i32, vp, vp],
+    "origin_dct_cont_std_async": [vp, vp, vp, i32, i32, i32, i32, vp, vp],
+    "origin_aux_join": [vp],
     "origin_o2": [vp, vp, i32, i64, vp],
     "origin_pca_run": [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, C.c_double, i32, vp, PP(i32),
                        PP(i32), vp, i32],

@@ -63,7 +63,21 @@ struct origin_ctx {
   // persistent workspace of origin_pca_run (owned by pca.hip)
   void *pca_ws;
   void (*pca_ws_free)(void *);
+  // Auxiliary low-priority stream: HBM-bound passes nothing downstream waits for (the cont_dct
+  // cube; the final F = X - U C of areas that have finished) run here in the shadow of the greedy
+  // PCA's latency-bound kernels.  aux_join is recorded after the last piece of aux work;
+  // origin_aux_join() makes the main stream wait for it, origin_sync() waits for both streams.
+  hipStream_t aux_stream;
+  hipEvent_t aux_fork, aux_join;
+  bool aux_pending;
+  void *aux_scratch;
+  size_t aux_scratch_bytes;
 };
+
+// aux stream plumbing (ctx.hip)
+int origin_aux_begin(origin_ctx *ctx);                        // aux waits for the main stream's work so far
+int origin_aux_end(origin_ctx *ctx);                          // marks the end of the aux work enqueued
+int origin_aux_scratch(origin_ctx *ctx, size_t bytes, void **out);
 
 // An event pair costs ~10 us of stream time on this hardware (barrier packets): 13 scopes in each
 // of the 56 PCA iterations add 5 ms to a 95 ms step.  Scopes therefore carry a level; bench.py

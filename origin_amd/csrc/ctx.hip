@@ -45,6 +45,42 @@ int origin_scratch(origin_ctx *ctx, size_t bytes, void **out) {
   return ORIGIN_OK;
 }
 
+// The aux stream is created on first use, with the lowest priority the device offers: its
+// thousands of HBM-bound workgroups must not sit in front of the one-block kernels of the PCA.
+int origin_aux_begin(origin_ctx *ctx) {
+  if (!ctx->aux_stream) {
+    int lo = 0, hi = 0;
+    ORIGIN_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));  // lo = least urgent
+    ORIGIN_HIP(hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, lo));
+    ORIGIN_HIP(hipEventCreateWithFlags(&ctx->aux_fork, hipEventDisableTiming));
+    ORIGIN_HIP(hipEventCreateWithFlags(&ctx->aux_join, hipEventDisableTiming));
+  }
+  ORIGIN_HIP(hipEventRecord(ctx->aux_fork, ctx->stream));
+  ORIGIN_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->aux_fork, 0));
+  return ORIGIN_OK;
+}
+
+int origin_aux_end(origin_ctx *ctx) {
+  ORIGIN_HIP(hipEventRecord(ctx->aux_join, ctx->aux_stream));
+  ctx->aux_pending = true;
+  return ORIGIN_OK;
+}
+
+int origin_aux_scratch(origin_ctx *ctx, size_t bytes, void **out) {
+  if (bytes > ctx->aux_scratch_bytes) {
+    if (ctx->aux_scratch) {
+      if (ctx->aux_stream) ORIGIN_HIP(hipStreamSynchronize(ctx->aux_stream));
+      ORIGIN_HIP(hipFree(ctx->aux_scratch));
+      ctx->aux_scratch = nullptr;
+      ctx->aux_scratch_bytes = 0;
+    }
+    ORIGIN_HIP(hipMalloc(&ctx->aux_scratch, bytes + bytes / 4 + (1 << 20)));
+    ctx->aux_scratch_bytes = bytes + bytes / 4 + (1 << 20);
+  }
+  *out = ctx->aux_scratch;
+  return ORIGIN_OK;
+}
+
 static hipEvent_t prof_event(origin_ctx *ctx) {
   if (!ctx->prof_free.empty()) {
     hipEvent_t e = ctx->prof_free.back();
@@ -161,6 +197,11 @@ int origin_ctx_create(int device, origin_ctx **out) {
   ctx->prof_level = false;
   ctx->pca_ws = nullptr;
   ctx->pca_ws_free = nullptr;
+  ctx->aux_stream = nullptr;
+  ctx->aux_fork = ctx->aux_join = nullptr;
+  ctx->aux_pending = false;
+  ctx->aux_scratch = nullptr;
+  ctx->aux_scratch_bytes = 0;
   memset(ctx->prof_ms, 0, sizeof(ctx->prof_ms));
   memset(ctx->prof_n, 0, sizeof(ctx->prof_n));
   hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
@@ -185,6 +226,13 @@ int origin_ctx_destroy(origin_ctx *ctx) {
       hipEventDestroy(ctx->ev_start[i]);
       hipEventDestroy(ctx->ev_stop[i]);
     }
+  if (ctx->aux_stream) {
+    hipStreamSynchronize(ctx->aux_stream);
+    hipStreamDestroy(ctx->aux_stream);
+    hipEventDestroy(ctx->aux_fork);
+    hipEventDestroy(ctx->aux_join);
+  }
+  if (ctx->aux_scratch) hipFree(ctx->aux_scratch);
   if (ctx->scratch) hipFree(ctx->scratch);
   if (ctx->ctab) hipFree(ctx->ctab);
   if (ctx->pca_ws && ctx->pca_ws_free) ctx->pca_ws_free(ctx->pca_ws);
@@ -198,6 +246,19 @@ int origin_ctx_destroy(origin_ctx *ctx) {
 int origin_sync(origin_ctx *ctx) {
   ORIGIN_USE(ctx);
   ORIGIN_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->aux_stream && ctx->aux_pending) {
+    ORIGIN_HIP(hipStreamSynchronize(ctx->aux_stream));
+    ctx->aux_pending = false;
+  }
+  return ORIGIN_OK;
+}
+
+int origin_aux_join(origin_ctx *ctx) {
+  ORIGIN_USE(ctx);
+  if (ctx->aux_stream && ctx->aux_pending) {
+    ORIGIN_HIP(hipStreamWaitEvent(ctx->stream, ctx->aux_join, 0));
+    ctx->aux_pending = false;
+  }
   return ORIGIN_OK;
 }
 

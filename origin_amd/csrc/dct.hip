@@ -750,8 +750,9 @@ int origin_dct_standardize(origin_ctx *ctx, const float *d_raw, const float *d_v
   return ORIGIN_OK;
 }
 
-int origin_dct_cont_std(origin_ctx *ctx, const float *d_var, const double *d_coef, int Nz, int Ny,
-                        int Nx, int order, float *d_cont_dct, float *d_ima_dct) {
+static int dct_cont_std_on(origin_ctx *ctx, bool aux, const float *d_var, const double *d_coef,
+                           int Nz, int Ny, int Nx, int order, float *d_cont_dct,
+                           float *d_ima_dct) {
   ORIGIN_USE(ctx);
   int rc = check_dims(Nz, Ny, Nx, order);
   if (rc) return rc;
@@ -765,25 +766,41 @@ int origin_dct_cont_std(origin_ctx *ctx, const float *d_var, const double *d_coe
   const int nzc = cdiv(Nz, zchunk);
   double *part = nullptr;
   if (d_ima_dct) {
-    void *scr = nullptr;
-    rc = origin_scratch(ctx, (size_t)nzc * S * sizeof(double), &scr);
+    void *scr = nullptr;  // (the aux stream has a scratch of its own: the PCA uses the main one)
+    rc = aux ? origin_aux_scratch(ctx, (size_t)nzc * S * sizeof(double), &scr)
+             : origin_scratch(ctx, (size_t)nzc * S * sizeof(double), &scr);
     if (rc) return rc;
     part = (double *)scr;
   }
   dim3 grid(cdiv(S, 256), nzc);
-  ProfScope ps(ctx, K_DCT_CONTINUUM);
-#define CALL(O)                                                                             \
-  hipLaunchKernelGGL(dct_cont_std_kernel<O>, grid, dim3(256), 0, ctx->stream, d_var, d_coef, \
-                     tab.p, Nz, S, zchunk, d_cont_dct, part)
-  DISPATCH_ORDER(order, CALL)
+  if (aux && (rc = origin_aux_begin(ctx))) return rc;
+  hipStream_t st = aux ? ctx->aux_stream : ctx->stream;
+  {
+    ProfScope ps(ctx, K_DCT_CONTINUUM, aux ? 3 : 1);  // (events of the main stream: sync form only)
+#define CALL(O)                                                                              \
+  hipLaunchKernelGGL(dct_cont_std_kernel<O>, grid, dim3(256), 0, st, d_var, d_coef, tab.p, Nz, S, \
+                     zchunk, d_cont_dct, part)
+    DISPATCH_ORDER(order, CALL)
 #undef CALL
-  ORIGIN_LAUNCH_CHECK();
-  if (d_ima_dct) {
-    hipLaunchKernelGGL(cont_image_final_kernel, dim3(cdiv(S, 256)), dim3(256), 0, ctx->stream, part,
-                       nzc, S, Nz, d_ima_dct);
     ORIGIN_LAUNCH_CHECK();
+    if (d_ima_dct) {
+      hipLaunchKernelGGL(cont_image_final_kernel, dim3(cdiv(S, 256)), dim3(256), 0, st, part, nzc,
+                         S, Nz, d_ima_dct);
+      ORIGIN_LAUNCH_CHECK();
+    }
   }
+  if (aux && (rc = origin_aux_end(ctx))) return rc;
   return ORIGIN_OK;
+}
+
+int origin_dct_cont_std(origin_ctx *ctx, const float *d_var, const double *d_coef, int Nz, int Ny,
+                        int Nx, int order, float *d_cont_dct, float *d_ima_dct) {
+  return dct_cont_std_on(ctx, false, d_var, d_coef, Nz, Ny, Nx, order, d_cont_dct, d_ima_dct);
+}
+
+int origin_dct_cont_std_async(origin_ctx *ctx, const float *d_var, const double *d_coef, int Nz,
+                              int Ny, int Nx, int order, float *d_cont_dct, float *d_ima_dct) {
+  return dct_cont_std_on(ctx, true, d_var, d_coef, Nz, Ny, Nx, order, d_cont_dct, d_ima_dct);
 }
 
 int origin_o2(origin_ctx *ctx, const float *d_cube, int Nz, long S, double *d_out) {

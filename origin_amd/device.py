@@ -41,6 +41,10 @@ class Context:
         _capi.call("origin_mem_info", self._h, C.byref(f), C.byref(t))
         return f.value, t.value
 
+    def aux_join(self):
+        """Main stream waits for the work pending on the auxiliary stream (no host sync)."""
+        _capi.call("origin_aux_join", self.handle)
+
     def sync(self):
         _capi.call("origin_sync", self._h)
 

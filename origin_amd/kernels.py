@@ -59,16 +59,18 @@ def dct_standardize(ctx, raw, var, mask, coef, zsum, zcnt, cube_std=None, cont_d
     return dict(cube_std=cube_std, cont_dct=cont_dct, ima_std=ima_std, ima_dct=ima_dct, o2=o2)
 
 
-def dct_cont_std(ctx, var, coef, cont_dct=None, want_image=True, ima_dct=None):
+def dct_cont_std(ctx, var, coef, cont_dct=None, want_image=True, ima_dct=None, aux=False):
     """cont_dct = continuum / sqrt(var) and its mean image, as a pass of its own (what
     ``dct_standardize(want_cont=False)`` leaves out).  Give ``cont_dct`` / ``ima_dct`` buffers to
-    keep the call free of allocations (an allocation can wait for the device)."""
+    keep the call free of allocations (an allocation can wait for the device).  ``aux``: on the
+    context's low-priority auxiliary stream -- ``ctx.aux_join()`` or ``ctx.sync()`` before the
+    outputs are read or ``var`` / ``coef`` rewritten."""
     Nz, Ny, Nx = var.shape
     cont_dct = ctx.empty((Nz, Ny, Nx), np.float32) if cont_dct is None else cont_dct
     if ima_dct is None and want_image:
         ima_dct = ctx.empty((Ny, Nx), np.float32)
-    _capi.call("origin_dct_cont_std", ctx.handle, var.p, coef.p, Nz, Ny, Nx, coef.shape[0] - 1,
-               cont_dct.p, _p(ima_dct))
+    _capi.call("origin_dct_cont_std_async" if aux else "origin_dct_cont_std", ctx.handle, var.p,
+               coef.p, Nz, Ny, Nx, coef.shape[0] - 1, cont_dct.p, _p(ima_dct))
     return dict(cont_dct=cont_dct, ima_dct=ima_dct)
 
 

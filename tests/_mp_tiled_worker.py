@@ -5,6 +5,9 @@ mode 'cpu' : host arrays + the CPU oracle per tile (gloo) -- checks the tiling a
              classes of the extended tile) against the untiled oracle, bit-for-bit level.
 mode 'gpu' : the same decomposition through the HIP path (all ranks share GPU 0, strips are
              host-staged over gloo) against the single-context HIP result.
+mode 'rccl': one GPU per rank, native RCCL communicator on the library's stream: device
+             all-reduce of the per-channel sums and GPU-to-GPU halo strips (what bench.py --gpus N
+             runs); needs as many devices as ranks.
 """
 import os
 import sys
@@ -31,7 +34,8 @@ def field():
 def main():
     mode, out = sys.argv[1], sys.argv[2]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    comm = multigpu.init_comm(rank, world, 0, backend="gloo")
+    comm = multigpu.init_comm(rank, world, rank if mode == "rccl" else 0,
+                              backend=None if mode == "rccl" else "gloo")
     f, raw, var, mask = field()
     Nz, Ny, Nx = raw.shape
     tiling = multigpu.Tiling(Ny, Nx, world, area_size=20, halo=f.PSF.shape[1] // 2)
@@ -68,11 +72,17 @@ def main():
     else:
         from origin_amd import kernels, pipeline
         from origin_amd.device import Context
-        ctx = Context(0)
+        ctx = Context(rank if mode == "rccl" else 0)
         d_raw, d_var = ctx.to_device(traw, np.float32), ctx.to_device(tvar, np.float32)
         d_mask = ctx.to_device(tmask.astype(np.uint8))
-        pre = pipeline.preprocess(ctx, d_raw, d_var, d_mask, 10, False,
-                                  allreduce=comm.allreduce_sum)
+        if mode == "rccl":
+            comm.attach(ctx)  # RCCL communicator on this context (collective)
+            assert comm.backend == "rccl", (comm.backend, comm.note)
+            pre = pipeline.preprocess(ctx, d_raw, d_var, d_mask, 10, False,
+                                      allreduce_dev=comm.allreduce_sum_device)
+        else:
+            pre = pipeline.preprocess(ctx, d_raw, d_var, d_mask, 10, False,
+                                      allreduce=comm.allreduce_sum)
         spx = pipeline.area_lists(lmap, len(labels))
         thr = pipeline.pca_threshold(pre["o2"].to_host(), lmap, len(labels), 0.01, spx=spx)
         faint, mapO2, nstop, _ = pipeline.greedy_pca(ctx, pre["cube_std"], lmap, len(labels),

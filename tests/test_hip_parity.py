@@ -199,6 +199,27 @@ def test_greedy_pca_area_golden(hip):
     assert np.max(np.abs(faint - ref)) <= 1e-4
 
 
+def test_greedy_pca_pipelined_host_loop_is_identical(hip, monkeypatch):
+    """ORIGIN_PCA_PIPELINED=1: the host builds each work list from the previous selection's counts
+    and the selection patches the real ones in on the device (csrc/pca.hip).  Areas that finish
+    at different iterations (2 x 2 areas golden) and a long single-area run: same cube, same map,
+    bit for bit, as the synchronous order."""
+    g = load("g4_pca")
+    inp = gc.g4_inputs()
+    cube, areamap, nb = inp["area_cube"], inp["areamap"], inp["nbAreas"]
+    res = [hip.Compute_PCA_threshold(cube[:, areamap == i], 0.01) for i in range(1, nb + 1)]
+    args = (nb, cube, areamap, 50, list(g["area_thr"]), 100, [r[0] for r in res])
+    a = hip.Compute_GreedyPCA_area(*args)
+    one = (inp["a"], g["a_test"], float(g["a_thr"][0]), 50, 100)
+    a1 = hip.Compute_GreedyPCA(*one)
+    monkeypatch.setenv("ORIGIN_PCA_PIPELINED", "1")
+    b = hip.Compute_GreedyPCA_area(*args)
+    b1 = hip.Compute_GreedyPCA(*one)
+    for x, y in ((a, b), (a1, b1)):
+        assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and x[2] == y[2]
+    assert np.array_equal(b[1], g["area_mapO2"])
+
+
 # ------------------------------------------------------------------------------- GLR
 @pytest.mark.parametrize("name", list("abcde"))
 def test_glr_golden(hip, name):

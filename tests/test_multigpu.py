@@ -110,6 +110,36 @@ def test_tiled_hip_equals_single_hip(tmp_path, world):
     assert np.max(np.abs(stitch(tiles, "maxmap", shape[1:]) - ref["maxmap"])) <= 2e-4
 
 
+def _device_count():
+    import ctypes as C
+    from origin_amd import _capi
+    n = C.c_int(0)
+    _capi.call("origin_device_count", C.byref(n))
+    return n.value
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_tiled_hip_native_rccl_one_gpu_per_rank(tmp_path, world):
+    """The path `bench.py --gpus N` runs: one process and one MI355X per rank, RCCL all-reduce
+    and two-phase halo exchange between DEVICES (origin_comm_* on the library's stream), against
+    the single-GPU chain.  Skips itself on boxes with fewer devices than ranks."""
+    if _device_count() < world:
+        pytest.skip(f"needs {world} GPUs, this box has {_device_count()}")
+    from _mp_tiled_worker import field
+    f, raw, var, mask = field()
+    tiles = run_ranks("rccl", world, str(tmp_path / "rccl"))
+    single = run_ranks("gpu", 1, str(tmp_path / "one"))
+    shape = raw.shape
+    for key, tol in (("cube_std", 1e-6), ("cube_faint", 1e-5), ("correl", 1e-4),
+                     ("correl_min", 1e-4)):
+        got, one = stitch(tiles, key, shape), stitch(single, key, shape)
+        assert np.max(np.abs(got - one)) <= tol, key
+    assert np.array_equal(stitch(tiles, "mapO2", shape[1:]), stitch(single, "mapO2", shape[1:]))
+    assert np.max(np.abs(stitch(tiles, "maxmap", shape[1:]) -
+                         stitch(single, "maxmap", shape[1:]))) <= 1e-4
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("order", ["torch-first", "lib-first"])
 def test_native_rccl_communicator_world1(order):
