@@ -1,4 +1,7 @@
 // Context, device memory, copies and HIP-event timers of liborigin_hip.so.
+#include <algorithm>
+#include <cstdlib>
+
 #include "common.h"
 
 static thread_local char g_err[1024] = "";
@@ -49,9 +52,19 @@ int origin_scratch(origin_ctx *ctx, size_t bytes, void **out) {
 // thousands of HBM-bound workgroups must not sit in front of the one-block kernels of the PCA.
 int origin_aux_begin(origin_ctx *ctx) {
   if (!ctx->aux_stream) {
-    int lo = 0, hi = 0;
-    ORIGIN_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));  // lo = least urgent
-    ORIGIN_HIP(hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, lo));
+    // ORIGIN_AUX_CUS=n: restrict the stream to n CUs (hipExtStreamCreateWithCUMask), leaving the
+    // rest of the chip to the main stream's small kernels; default: lowest priority, all CUs
+    const char *cus = getenv("ORIGIN_AUX_CUS");
+    if (cus && atoi(cus) > 0) {
+      const int n = std::min(atoi(cus), ctx->num_cu > 0 ? ctx->num_cu : 256);
+      uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int i = 0; i < n; ++i) mask[i >> 5] |= 1u << (i & 31);
+      ORIGIN_HIP(hipExtStreamCreateWithCUMask(&ctx->aux_stream, 8, mask));
+    } else {
+      int lo = 0, hi = 0;
+      ORIGIN_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));  // lo = least urgent
+      ORIGIN_HIP(hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, lo));
+    }
     ORIGIN_HIP(hipEventCreateWithFlags(&ctx->aux_fork, hipEventDisableTiming));
     ORIGIN_HIP(hipEventCreateWithFlags(&ctx->aux_join, hipEventDisableTiming));
   }

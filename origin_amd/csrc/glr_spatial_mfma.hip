@@ -30,8 +30,9 @@
 //
 // TERMS = 1: bf16 operands, one MFMA per k-step (BASELINE config 4's bf16 GLR), no scaling.
 //
-// Eligible shapes: P in {9, 17, 25}, Nx % 4 == 0 (16-byte tile loads); everything else -- weight
-// maps, several fields, other PSF sizes -- stays on spatial4x4_kernel / spatial_kernel.
+// Eligible shapes: P in {9, 17, 25} (any field size: 16-byte accesses when Nx % 4 == 0, element
+// accesses otherwise); weight maps, several fields and other PSF sizes stay on spatial4x4_kernel /
+// spatial_kernel.
 #include <algorithm>
 
 #include "common.h"
@@ -81,7 +82,9 @@ __device__ __forceinline__ void s2_split(float y, _Float16 &hi, _Float16 &lo) {
   lo = (_Float16)(y - (float)hi);
 }
 
-template <int P, int TERMS>
+// VEC: Nx % 4 == 0 -- rows of the cube are 16-byte aligned, the tile is loaded and the outputs are
+// stored four at a time; otherwise element by element.
+template <int P, int TERMS, bool VEC>
 __global__ __launch_bounds__(512, 1) void spatial2_kernel(const float *__restrict__ A,
                                                           const float *__restrict__ taps, int Nz,
                                                           int Ny, int Nx, int zper,
@@ -119,8 +122,16 @@ __global__ __launch_bounds__(512, 1) void spatial2_kernel(const float *__restric
       const int ry = e / (G::IW / 4), cx = e - ry * (G::IW / 4);
       const int y = y0 - c + ry, x = x0 - c + 4 * cx;  // x % 4 == 0 (c % 4 == 0), Nx % 4 == 0
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ry < G::IH && y >= 0 && y < Ny && x >= 0 && x < Nx)
-        v = *reinterpret_cast<const float4 *>(Az + (long)y * Nx + x);
+      if constexpr (VEC) {
+        if (ry < G::IH && y >= 0 && y < Ny && x >= 0 && x < Nx)
+          v = *reinterpret_cast<const float4 *>(Az + (long)y * Nx + x);
+      } else if (ry < G::IH && y >= 0 && y < Ny) {
+        const float *row = Az + (long)y * Nx;
+        if (x >= 0 && x < Nx) v.x = row[x];
+        if (x + 1 >= 0 && x + 1 < Nx) v.y = row[x + 1];
+        if (x + 2 >= 0 && x + 2 < Nx) v.z = row[x + 2];
+        if (x + 3 >= 0 && x + 3 < Nx) v.w = row[x + 3];
+      }
       stage[q] = v;
     }
     const float *kz = taps + (long)z * P * P;
@@ -263,14 +274,20 @@ __global__ __launch_bounds__(512, 1) void spatial2_kernel(const float *__restric
     // store: accumulator register i of lane (n, h) is output m = (i&3) + 8 (i>>2) + 4 h of patch
     // n, i.e. patch row i >> 2, patch columns 4 h + (i & 3): one float4 per patch row
     const int xo = x0 + 32 * ax + ox + 4 * h;
-    if (xo < Nx) {  // Nx % 4 == 0: a float4 is inside or outside as a whole
+    if (xo < Nx) {
 #pragma unroll
       for (int pr = 0; pr < 4; ++pr) {
         const int y = y0 + 32 * ay + oy + pr;
-        if (y < Ny)
-          *reinterpret_cast<float4 *>(out + (long)z * S + (long)y * Nx + xo) =
-              make_float4(acc[4 * pr] * inv, acc[4 * pr + 1] * inv, acc[4 * pr + 2] * inv,
-                          acc[4 * pr + 3] * inv);
+        if (y >= Ny) continue;
+        float *o = out + (long)z * S + (long)y * Nx + xo;
+        if constexpr (VEC) {  // Nx % 4 == 0: a float4 is inside or outside as a whole
+          *reinterpret_cast<float4 *>(o) = make_float4(acc[4 * pr] * inv, acc[4 * pr + 1] * inv,
+                                                       acc[4 * pr + 2] * inv, acc[4 * pr + 3] * inv);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (xo + e < Nx) o[e] = acc[4 * pr + e] * inv;
+        }
       }
     }
   };
@@ -307,16 +324,16 @@ __global__ __launch_bounds__(512, 1) void spatial2_kernel(const float *__restric
 
 // 1 if this shape can run on spatial2_kernel
 int origin_spatial_mfma_ok(int Ny, int Nx, int P) {
-  return (P == 9 || P == 17 || P == 25) && (Nx & 3) == 0 && Ny >= 1;
+  return (P == 9 || P == 17 || P == 25) && Nx >= 1 && Ny >= 1;
 }
 
-template <int P, int TERMS>
+template <int P, int TERMS, bool VEC>
 static int s2_launch(origin_ctx *ctx, const float *A, const float *taps, int Nz, int Ny, int Nx,
                      float *out) {
   const size_t lds = 2 * s2_group_bytes<P, TERMS>();
   static bool attr_done = false;
   if (!attr_done) {
-    ORIGIN_HIP(hipFuncSetAttribute((const void *)spatial2_kernel<P, TERMS>,
+    ORIGIN_HIP(hipFuncSetAttribute((const void *)spatial2_kernel<P, TERMS, VEC>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
@@ -338,18 +355,22 @@ static int s2_launch(origin_ctx *ctx, const float *A, const float *taps, int Nz,
   int zper = cdiv(Nz, best_nzb);
   zper += zper & 1;
   dim3 grid(cdiv(Nx, S2_R), cdiv(Ny, S2_R), cdiv(Nz, zper));
-  hipLaunchKernelGGL((spatial2_kernel<P, TERMS>), grid, dim3(512), lds, ctx->stream, A, taps, Nz,
-                     Ny, Nx, zper, out);
+  hipLaunchKernelGGL((spatial2_kernel<P, TERMS, VEC>), grid, dim3(512), lds, ctx->stream, A, taps,
+                     Nz, Ny, Nx, zper, out);
   ORIGIN_LAUNCH_CHECK();
   return ORIGIN_OK;
 }
 
 int origin_spatial_mfma_launch(origin_ctx *ctx, int terms, const float *A, const float *taps,
                                int Nz, int Ny, int Nx, int P, float *out) {
-#define S2_CASE(PP)                                                        \
-  case PP:                                                                 \
-    return terms == 3 ? s2_launch<PP, 3>(ctx, A, taps, Nz, Ny, Nx, out)   \
-                      : s2_launch<PP, 1>(ctx, A, taps, Nz, Ny, Nx, out)
+  const bool vec = (Nx & 3) == 0;
+#define S2_CASE(PP)                                                                          \
+  case PP:                                                                                   \
+    if (vec)                                                                                 \
+      return terms == 3 ? s2_launch<PP, 3, true>(ctx, A, taps, Nz, Ny, Nx, out)              \
+                        : s2_launch<PP, 1, true>(ctx, A, taps, Nz, Ny, Nx, out);             \
+    return terms == 3 ? s2_launch<PP, 3, false>(ctx, A, taps, Nz, Ny, Nx, out)               \
+                      : s2_launch<PP, 1, false>(ctx, A, taps, Nz, Ny, Nx, out)
   switch (P) {
     S2_CASE(9);
     S2_CASE(17);

@@ -1823,19 +1823,6 @@ __global__ __launch_bounds__(256, 4) void flush_kernel(const float *X, float *F,
   }
 }
 
-// descriptors of an early flush (a handful of areas that have just finished), passed as kernel
-// arguments and written to the device list the flush kernel reads: no host buffer to keep alive,
-// no copy that could wait for the auxiliary stream
-struct FlushSet {
-  long v[4][8];  // area, list0, ns, T
-  int n;
-};
-__global__ void flush_setup_kernel(FlushSet fs, long *__restrict__ dst) {
-  const int k = threadIdx.x;
-  if (k < fs.n)
-    for (int f = 0; f < 4; ++f) dst[(long)f * fs.n + k] = fs.v[f][k];
-}
-
 // ------------------------------------------------------------------------------------
 // host helpers
 // ------------------------------------------------------------------------------------
@@ -1886,7 +1873,7 @@ struct HostBuf {
 };
 
 struct PcaWorkspace {
-  DevBuf b[21];
+  DevBuf b[20];
   HostBuf h_nnb, h_stage;
 };
 
@@ -2118,21 +2105,14 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
   // F = X - U C for every area that holds vectors (every area at all when the output is a
   // different buffer and has not been written yet); afterwards T = 0 and the cube is read
   // from d_F
-  // Areas that have finished are flushed at once on the context's auxiliary low-priority stream
-  // (early_flush below): their F = X - U C -- 97 % of the cube's flush traffic at 600 x 600 --
-  // then runs in the shadow of the iterations of the areas that go on (a handful of one-block
-  // kernels each: the chip is all but idle during the tail of the loop).
-  std::vector<char> flushed(na, 0);
-  const bool early = getenv("ORIGIN_PCA_NO_EARLY_FLUSH") == nullptr;
-  int early_slot = 0;
-  if (early && (rc = W.b[20].reserve(ctx, (size_t)(na + 8) * 32 * sizeof(long)))) return rc;
+  // (Flushing the areas that have finished at once, on a second low-priority or CU-masked stream
+  // in the shadow of the iterations that go on, was built and measured: no gain -- 25.4-25.5 ms
+  // against 25.0-25.1; the one-block kernels of the chain slow down by what the flush overlaps.)
   auto flush = [&]() -> int {
     const bool all = src != d_F;
     std::vector<long> fd;
     int nf = 0, nsmax = 0;
-    auto wanted = [&](int a) {
-      return !flushed[a] && (all || T[a] > 0) && h_spx_off[a + 1] > h_spx_off[a];
-    };
+    auto wanted = [&](int a) { return (all || T[a] > 0) && h_spx_off[a + 1] > h_spx_off[a]; };
     for (int a = 0; a < na; ++a) nf += wanted(a);
     if (nf > 0) {
       fd.assign((size_t)4 * nf, 0);
@@ -2165,45 +2145,6 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
     src = d_F;
     return ORIGIN_OK;
   };
-  // counts: the newest selection's n per area (n < 2: the area has finished, nothing will touch
-  // its columns of the cube, its vectors or its coefficient columns again)
-  auto early_flush = [&](const int *counts) -> int {
-    if (!early) return ORIGIN_OK;
-    FlushSet fs;
-    fs.n = 0;
-    int nsmax = 0;
-    auto fire = [&]() -> int {
-      if (fs.n == 0) return ORIGIN_OK;
-      int r;
-      if ((r = origin_aux_begin(ctx))) return r;  // behind everything enqueued so far
-      long *dst = (long *)W.b[20].p + (size_t)early_slot * 32;
-      early_slot = (early_slot + 1) % (na + 8);
-      hipLaunchKernelGGL(flush_setup_kernel, dim3(1), dim3(8), 0, ctx->aux_stream, fs, dst);
-      const int nxb = cdiv(nsmax, 256), nzb = cdiv(Nz, FLUSH_ZB);
-      const long ngroups = ((long)nxb * nzb + 7) / 8;
-      hipLaunchKernelGGL(flush_kernel, dim3((unsigned)(ngroups * fs.n * 8)), dim3(256), 0,
-                         ctx->aux_stream, src, d_F, Nz, S, d_spx, (const long *)dst, fs.n, d_U, d_C,
-                         ntot, nxb, nzb);
-      ORIGIN_LAUNCH_CHECK();
-      if ((r = origin_aux_end(ctx))) return r;
-      fs.n = 0;
-      nsmax = 0;
-      return ORIGIN_OK;
-    };
-    for (int a = 0; a < na; ++a) {
-      const int ns = (int)(h_spx_off[a + 1] - h_spx_off[a]);
-      if (flushed[a] || counts[a] >= 2 || ns == 0) continue;
-      flushed[a] = 1;
-      if (src == d_F && T[a] == 0) continue;  // in place and nothing removed: already final
-      fs.v[0][fs.n] = a, fs.v[1][fs.n] = h_spx_off[a], fs.v[2][fs.n] = ns, fs.v[3][fs.n] = T[a];
-      nsmax = std::max(nsmax, ns);
-      T[a] = 0;
-      int r;
-      if (++fs.n == 8 && (r = fire())) return r;
-    }
-    return fire();
-  };
-
   // LDS cache of the select kernel: the largest area, if it fits in 120 KiB
   int nsmax_all = 0;
   for (int a = 0; a < na; ++a) nsmax_all = std::max(nsmax_all, (int)(h_spx_off[a + 1] - h_spx_off[a]));
@@ -2270,7 +2211,6 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
   ORIGIN_LAUNCH_CHECK();
   if ((rc = wait_select())) return rc;
   memcpy(n_lay.data(), h_nnb, 2 * (size_t)na * sizeof(int));
-  if ((rc = early_flush(n_lay.data()))) return rc;
   bool exact = true;
   // Default: selection, hand-shake, exact work list, chain.  ORIGIN_PCA_PIPELINED=1 lets the host
   // run one selection ahead (below).  Measured A/B at 3681 x 600 x 600 (57 iterations): 25.7-25.9
@@ -2293,8 +2233,7 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
       ORIGIN_LAUNCH_CHECK();
       if ((rc = wait_select())) return rc;
       memcpy(n_lay.data(), h_nnb, 2 * (size_t)na * sizeof(int));
-      if ((rc = early_flush(n_lay.data()))) return rc;
-      exact = true;
+          exact = true;
     }
     // ---- work list of this iteration
     int nw = 0;
@@ -2520,14 +2459,12 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
       fb_ld[a] = D[(size_t)DF_LD * nw + w];
       fb_n[a] = n_lay[a];
     }
-    if (pipelined && (rc = early_flush(n_lay.data()))) return rc;
     ++iters;
   }
   if (getenv("ORIGIN_PCA_TIMING"))
     fprintf(stderr, "[pca] host loop: %d iterations, build %.2f ms, enqueue %.2f ms, wait %.2f ms\n",
             iters, 1e3 * t_build, 1e3 * t_enq, 1e3 * t_wait);
   if ((rc = flush())) return rc;
-  if ((rc = origin_aux_join(ctx))) return rc;  // the main stream continues behind the early flushes
   ORIGIN_HIP(hipMemcpyAsync(h_nnb, d_nstop, sizeof(int), hipMemcpyDeviceToHost, st));
   ORIGIN_HIP(hipStreamSynchronize(st));
   *h_nstop = h_nnb[0];

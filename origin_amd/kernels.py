@@ -157,7 +157,7 @@ class GLRPlan:
         self.precision = self.PRECISIONS[got.value]
         # mirrors origin_spatial_mfma_ok (csrc/glr_spatial_mfma.hip): which spatial kernel runs
         self.spatial_on_matrix_cores = (self.precision != "f32" and w is None and
-                                        self.P in (9, 17, 25) and Nx % 4 == 0)
+                                        self.P in (9, 17, 25))
 
     def close(self):
         if self._h is not None and self._h.value:

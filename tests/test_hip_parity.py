@@ -256,11 +256,13 @@ def test_glr_golden_both_arithmetics(ctx, name, precision):
 
 
 @pytest.mark.parametrize("shape,P", [((70, 67, 132), 25), ((40, 30, 20), 25), ((50, 26, 140), 9),
-                                      ((33, 130, 260), 17)])
+                                      ((33, 130, 260), 17), ((45, 70, 131), 25),
+                                      ((37, 65, 66), 9)])
 def test_glr_matrix_core_spatial_stage(ctx, shape, P):
-    """Shapes that take the matrix-core spatial kernel (Nx % 4 == 0, P in 9/17/25): several
-    128x64 regions, partial regions, fields narrower than a region, against the float64 oracle
-    and against the fp32 kernels."""
+    """Shapes that take the matrix-core spatial kernel (P in 9/17/25): several 64x64 regions,
+    partial regions, fields narrower than a region, row lengths that are not multiples of four
+    (element-wise tile loads and stores), against the float64 oracle and against the fp32
+    kernels."""
     from origin_amd import kernels
     rng = np.random.default_rng(P + shape[2])
     Nz, Ny, Nx = shape
@@ -276,6 +278,7 @@ def test_glr_matrix_core_spatial_stage(ctx, shape, P):
     got = {}
     for prec in ("f16x2", "f32"):
         plan = kernels.GLRPlan(ctx, shape, psf, None, prof, 1e-8, True, precision=prec)
+        assert plan.spatial_on_matrix_cores == (prec == "f16x2")
         out = plan.run(d, mask=None, want_maps=False)
         got[prec] = out["correl"].to_host()
         assert np.max(np.abs(got[prec] - ref[0])) <= 1e-4
