@@ -35,8 +35,11 @@ def main():
                 res[k][c] = v / max(1, len(disp))
                 res[k]["launches"] = len(disp)
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
-    for k, v in sorted(res.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", kv[1].get("FETCH_SIZE", 0))):
-        print(k, {c: (round(x) if isinstance(x, float) else x) for c, x in sorted(v.items())})
+    top = sorted(res.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", kv[1].get("FETCH_SIZE", 0)))[:8]
+    for k, v in top:
+        keys = ("launches", "SQ_INSTS_MFMA", "SQ_INSTS_VALU", "SQ_VALU_MFMA_BUSY_CYCLES",
+                "SQ_WAVE_CYCLES", "SQ_LDS_BANK_CONFLICT")
+        print(f"{k:28s} " + " ".join(f"{c.replace('SQ_', '')}={v[c]:.3g}" for c in keys if c in v))
 
 
 if __name__ == "__main__":
