@@ -311,8 +311,8 @@ def main():
             if world == 1 and (Nz, N, args.nprof) == (3681, 600, 20):
                 pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)),
                                                   "profiles", PMC_PROFILE)))
-                kmap = {"glr_spectral": ["spectral_mfma_kernel", "spectral3_kernel"],
-                        "glr_spatial": ["spatial_mfma_kernel", "spatial4x4_kernel"],
+                kmap = {"glr_spectral": ["spectral_mfma2_kernel", "spectral3_kernel"],
+                        "glr_spatial": ["spatial2_kernel", "spatial4x4_kernel"],
                         "dct_fit": ["dct_moments_kernel"], "dct_plane_sums": ["dct_plane_sums_kernel"],
                         "dct_standardize": ["dct_standardize_kernel"],
                         "pca_deflate_dot": ["deflate_dot_kernel"], "pca_flush": ["flush_kernel"]}
@@ -321,7 +321,7 @@ def main():
                         e = pmc[kn]
                         # FETCH_SIZE counts 16-byte coalesced reads at half size (MI355X_MICROARCH.md,
                         # HBM): the MFMA spectral kernel reads with 4-byte loads (no correction)
-                        fx = 1.0 if kn == "spectral_mfma_kernel" else 2.0
+                        fx = 1.0 if kn == "spectral_mfma2_kernel" else 2.0
                         traffic = round((fx * e.get("FETCH_SIZE_GB_per_launch", 0.0) +
                                          e.get("WRITE_SIZE_GB_per_launch", 0.0)) * 1e9)
                         extra["traffic_source"] = (
