@@ -163,8 +163,8 @@ def main():
     def one_step():
         t0 = time.perf_counter()
         ctx.aux_join()  # (coef_buf / cont_dct of the previous step: idle after its closing sync)
-        coef = kernels.dct_fit(ctx, raw, var, mask, 10, False, coef=coef_buf)
-        zsum, zcnt = kernels.dct_resid_sums(ctx, raw, mask, coef, zsum=zsum_buf, zcnt=zcnt_buf)
+        coef, zsum, zcnt = kernels.dct_fit_sums(ctx, raw, var, mask, 10, False, coef=coef_buf,
+                                                zsum=zsum_buf, zcnt=zcnt_buf)
         if comm is not None:
             comm.allreduce_sum_device(ctx, [zsum, zcnt])
         pre = kernels.dct_standardize(ctx, raw, var, mask, coef, zsum, zcnt, cube_std=cube_std,
@@ -247,7 +247,9 @@ def main():
     algo = {
         # bytes per voxel per launch: what the kernel must move
         "dct_fit": ("hbm", 9.0 * local_vox),            # raw 4 + var 4 + mask 1
-        "dct_plane_sums": ("hbm", 5.0 * local_vox),     # raw 4 + mask 1
+        # folded into the fit's moments pass: what is left is the partial array
+        # [groups of 64 spaxels][Nz] float64, written once and read once
+        "dct_plane_sums": ("hbm", 0.25 * local_vox),
         "dct_standardize": ("hbm", 17.0 * local_vox),   # + cube_std 4 + cont_dct 4
         "pca_deflate_dot": ("hbm", 4.0),                # per voxel of the launch's areas
         "pca_flush": ("hbm", 8.0 * local_vox),
@@ -313,7 +315,7 @@ def main():
                                                   "profiles", PMC_PROFILE)))
                 kmap = {"glr_spectral": ["spectral_mfma2_kernel", "spectral3_kernel"],
                         "glr_spatial": ["spatial2_kernel", "spatial4x4_kernel"],
-                        "dct_fit": ["dct_moments_kernel"], "dct_plane_sums": ["dct_plane_sums_kernel"],
+                        "dct_fit": ["dct_moments_kernel"], "dct_plane_sums": ["dct_part_reduce_kernel"],
                         "dct_standardize": ["dct_standardize_kernel"],
                         "pca_deflate_dot": ["deflate_dot_kernel"], "pca_flush": ["flush_kernel"]}
                 for kn in kmap.get(dominant, []):

@@ -148,6 +148,14 @@ int origin_prof_get(origin_ctx *ctx, int id, const char **name, double *total_ms
 int origin_dct_fit(origin_ctx *ctx, const float *d_raw, const float *d_var,
                    const uint8_t *d_mask, int Nz, int Ny, int Nx, int order, int approx,
                    double *d_coef);
+/* origin_dct_fit followed by origin_dct_resid_sums (below), as one call: the per-channel sums
+ * of raw over the unmasked spaxels are taken inside the fit's moments pass, which reads raw and
+ * mask anyway, so the separate 5 B/voxel plane pass disappears (masked voxels are visited once
+ * more, mask bytes only, in the spaxel groups that have any).  Same d_coef, d_zsum, d_zcnt as
+ * the two calls (summation order differs: agreement to a few ulp of float64). */
+int origin_dct_fit_sums(origin_ctx *ctx, const float *d_raw, const float *d_var,
+                        const uint8_t *d_mask, int Nz, int Ny, int Nx, int order, int approx,
+                        double *d_coef, double *d_zsum, double *d_zcnt);
 /* Continuum cube D c (what dct_residual returns), float32. */
 int origin_dct_continuum(origin_ctx *ctx, const double *d_coef, int Nz, int Ny, int Nx,
                          int order, float *d_cont);

@@ -54,6 +54,7 @@ SIGNATURES = {
     "origin_prof_count": [],
     "origin_prof_get": [vp, i32, PP(C.c_char_p), PP(C.c_double), PP(C.c_long)],
     "origin_dct_fit": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "origin_dct_fit_sums": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp],
     "origin_dct_continuum": [vp, vp, i32, i32, i32, i32, vp],
     "origin_dct_resid_sums": [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp],
     "origin_dct_standardize": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp],

@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -80,17 +81,40 @@ struct CtabGuard {  // the table is cached in the context; nothing to release pe
 // field -- which takes a quarter of the float64 FMAs out of this kernel.
 // mom rows: [0, NK) M, [NK, NK+NA) Rw, NK+NA: any masked voxel.
 // ------------------------------------------------------------------------------------
-template <int ORDER>
+// How the rows reach the wave.  A row of 64 spaxels is 256 B per array and the next row is a whole
+// plane away; read this way a plain march reaches 5.7-6.1 TB/s (tools/rowmarch_probe.hip), so the
+// pattern is not the limit.  hipcc used to place the three loads of a row right before their use,
+// one row at a time: MOM_BATCH rows are now requested back-to-back before the first is used, and
+// the rows of a batch are kept apart by scheduling barriers so that each waits for its own loads
+// only.  What bounds the kernel after that is the float64 arithmetic (49 VALU per row and wave,
+// 32 of them FMAs whose table operand arrives by scalar loads that a row has to wait for) at four
+// waves per SIMD: measured 3.2 ms against 2.0 ms for the VALU work alone and 1.9 ms for the
+// bytes.  Tried and measured slower or equal: an LDS-DMA ring (`global_load_lds_*` eight rows
+// ahead: M0 / SALU overhead per row), batches of 2, 4 and 16 rows, the table row pinned in the
+// scalar cache (-4 %: the scalar loads are not the limit on their own).
+#ifndef MOM_BATCH
+#define MOM_BATCH 8
+#endif
+constexpr int MOM_PITCH = 68;  // floats per row of the wave's transpose buffer (FOLD)
+constexpr int MOM_TR_FLOATS = 16 * MOM_PITCH;
+
+// FOLD: the per-channel sums of pass 2 (sum over the unmasked spaxels of raw[z, .]) are taken
+// here, where raw and mask are in registers anyway: the 64 values of a row (0 for masked and dead
+// lanes) go to a wave-private LDS buffer, and every 16 rows the buffer is read transposed
+// (lane = row & 15, quarter = lane >> 4), summed in float64 in a fixed order and written to
+// part[group][z].  That replaces the 5 B/voxel plane pass by a 1/8 B/voxel partial array.
+template <int ORDER, bool FOLD>
 __global__ __launch_bounds__(512) void dct_moments_kernel(const float *__restrict__ raw,
                                                           const float *__restrict__ var,
                                                           const uint8_t *__restrict__ mask,
                                                           const double *__restrict__ ctab,
-                                                          int Nz, long S,
-                                                          double *__restrict__ mom) {
+                                                          int Nz, long S, int zchunk,
+                                                          double *__restrict__ mom,
+                                                          double *__restrict__ part) {
   constexpr int NA = ORDER + 1;
   constexpr int NK = 2 * ORDER + 1;
   constexpr int NACC = NK + NA;
-  extern __shared__ double lds[];  // [ZS-1][NACC+1][64]
+  extern __shared__ double lds[];  // [ZS][MOM_TR_FLOATS] floats (FOLD), then [ZS-1][NACC+1][64] doubles
 
   const int lane = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
@@ -98,6 +122,8 @@ __global__ __launch_bounds__(512) void dct_moments_kernel(const float *__restric
   const long s = (long)blockIdx.x * 64 + lane;
   const bool live = s < S;
   const long sc = live ? s : S - 1;  // clamp: dead lanes redo the last spaxel, never store
+  float *tr = reinterpret_cast<float *>(lds) + wave * MOM_TR_FLOATS;
+  double *xw = lds + (FOLD ? ZS * MOM_TR_FLOATS / 2 : 0);  // cross-wave area
 
   double M[NK], Rw[NA];
 #pragma unroll
@@ -105,28 +131,87 @@ __global__ __launch_bounds__(512) void dct_moments_kernel(const float *__restric
 #pragma unroll
   for (int a = 0; a < NA; ++a) Rw[a] = 0.0;
   int anymask = 0;
+  int nrows = 0;  // rows of this wave so far (row i is channel zc0 + wave + i ZS)
+  // blockIdx.y: a chunk of channels.  The partial moments of the chunks are summed by the solve
+  // kernel; the split gives several times more blocks than the chip holds at once, so that the
+  // last round of blocks is a small part of the run (5625 waves on 4096 slots were two rounds)
+  const int zc0 = blockIdx.y * zchunk, zc1 = min(Nz, zc0 + zchunk);
 
-#pragma unroll 4
-  for (int z = wave; z < Nz; z += ZS) {
-    const long idx = (long)z * S + sc;
-    const float r = raw[idx];
-    const float v = var[idx];
-    anymask |= mask[idx];
+  // buffered rows [i0, i0 + cnt) -> part[group][z].  Every lane ends with the sum of its row: the
+  // four lanes of a row store the same value (no branch for a full buffer: a block boundary here
+  // lets the optimiser sink the FMA chains of the rows before below it)
+  auto flush = [&](int i0, auto cnt_c) {
+    const int cnt = cnt_c;
+    const int rrow = lane & 15, seg = lane >> 4;
+    const float4 *p = reinterpret_cast<const float4 *>(tr + rrow * MOM_PITCH + seg * 16);
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 f = p[q];
+      acc += (double)f.x;
+      acc += (double)f.y;
+      acc += (double)f.z;
+      acc += (double)f.w;
+    }
+    acc += __shfl_xor(acc, 16, 64);
+    acc += __shfl_xor(acc, 32, 64);
+    double *dst = part + (long)blockIdx.x * Nz + zc0 + wave + (long)(i0 + rrow) * ZS;
+    if (cnt == 16)
+      *dst = acc;
+    else if (rrow < cnt)
+      *dst = acc;
+  };
+  auto row = [&](int z, float r, float v, int mk) {
+    anymask |= mk;
     const double *ct = ctab + (long)z * NK;  // wave-uniform -> scalar loads
     // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division: the weight is a float32
     // quantity either way.  var = inf (masked) -> weight 0
     const double wd = (double)__builtin_amdgcn_rcpf(v);
     const double wr = wd * (double)r;
+    if constexpr (FOLD) tr[(nrows & 15) * MOM_PITCH + lane] = (mk || !live) ? 0.0f : r;
 #pragma unroll
     for (int k = 0; k < NK; ++k) M[k] = fma(wd, ct[k], M[k]);
 #pragma unroll
     for (int a = 0; a < NA; ++a) Rw[a] = fma(wr, ct[a], Rw[a]);
+    ++nrows;
+  };
+
+  constexpr int B = MOM_BATCH;
+  static_assert(16 % B == 0, "a transpose buffer is a whole number of batches");
+  // one batch: B rows requested back to back, then used in order
+  auto batch = [&](int z) {
+    float r[B], v[B];
+    int mk[B];
+#pragma unroll
+    for (int u = 0; u < B; ++u) {
+      const long idx = (long)(z + u * ZS) * S + sc;
+      r[u] = raw[idx], v[u] = var[idx], mk[u] = mask[idx];
+    }
+#pragma unroll
+    for (int u = 0; u < B; ++u) {
+      __builtin_amdgcn_sched_barrier(0);  // rows in order: row u waits for ITS three loads only
+      row(z + u * ZS, r[u], v[u], mk[u]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  int z = zc0 + wave;
+  for (; z + 15 * ZS < zc1; z += 16 * ZS) {  // trips of 16 rows = one transpose buffer
+#pragma unroll
+    for (int b = 0; b < 16 / B; ++b) batch(z + b * B * ZS);
+    if constexpr (FOLD) flush(nrows - 16, std::integral_constant<int, 16>{});
+  }
+  for (; z < zc1; z += ZS) {  // the last, incomplete trip, row by row
+    const long idx = (long)z * S + sc;
+    row(z, raw[idx], var[idx], mask[idx]);
+  }
+  if constexpr (FOLD) {
+    if (nrows & 15) flush(nrows & ~15, nrows & 15);
   }
 
   // cross-wave reduction (fixed order -> deterministic)
   if (ZS > 1) {
     if (wave > 0) {
-      double *dst = lds + (long)(wave - 1) * (NACC + 1) * 64 + lane;
+      double *dst = xw + (long)(wave - 1) * (NACC + 1) * 64 + lane;
 #pragma unroll
       for (int k = 0; k < NK; ++k) dst[k * 64] = M[k];
 #pragma unroll
@@ -136,7 +221,7 @@ __global__ __launch_bounds__(512) void dct_moments_kernel(const float *__restric
     __syncthreads();
     if (wave > 0) return;
     for (int w = 1; w < ZS; ++w) {
-      const double *src = lds + (long)(w - 1) * (NACC + 1) * 64 + lane;
+      const double *src = xw + (long)(w - 1) * (NACC + 1) * 64 + lane;
 #pragma unroll
       for (int k = 0; k < NK; ++k) M[k] += src[k * 64];
 #pragma unroll
@@ -148,11 +233,12 @@ __global__ __launch_bounds__(512) void dct_moments_kernel(const float *__restric
   // moments of this spaxel -> global (the solve runs in a second, register-hungry kernel so
   // that this streaming kernel keeps a high occupancy)
   if (live) {
+    double *mc = mom + (long)blockIdx.y * (NACC + 1) * S;
 #pragma unroll
-    for (int k = 0; k < NK; ++k) mom[(long)k * S + s] = M[k];
+    for (int k = 0; k < NK; ++k) mc[(long)k * S + s] = M[k];
 #pragma unroll
-    for (int a = 0; a < NA; ++a) mom[(long)(NK + a) * S + s] = Rw[a];
-    mom[(long)NACC * S + s] = (double)anymask;
+    for (int a = 0; a < NA; ++a) mc[(long)(NK + a) * S + s] = Rw[a];
+    mc[(long)NACC * S + s] = (double)anymask;
   }
 }
 
@@ -160,7 +246,7 @@ __global__ __launch_bounds__(512) void dct_moments_kernel(const float *__restric
 // coefficients instead are flagged in need[] for dct_r0_kernel.  approx: every spaxel (mom is
 // not read).
 template <int ORDER>
-__global__ __launch_bounds__(256) void dct_solve_kernel(const double *__restrict__ mom, int Nz,
+__global__ __launch_bounds__(256) void dct_solve_kernel(const double *__restrict__ mom, int nzc,
                                                         long S, int approx,
                                                         double *__restrict__ coef,
                                                         uint8_t *__restrict__ need) {
@@ -178,7 +264,15 @@ __global__ __launch_bounds__(256) void dct_solve_kernel(const double *__restrict
   for (int k = 0; k < NK; ++k) M[k] = mom[(long)k * S + s];
 #pragma unroll
   for (int a = 0; a < NA; ++a) Rw[a] = mom[(long)(NK + a) * S + s];
-  const int anymask = mom[(long)NACC * S + s] != 0.0;
+  int anymask = mom[(long)NACC * S + s] != 0.0;
+  for (int c = 1; c < nzc; ++c) {  // the channel chunks of the moments pass, in order
+    const double *mc = mom + (long)c * (NACC + 1) * S;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) M[k] += mc[(long)k * S + s];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) Rw[a] += mc[(long)(NK + a) * S + s];
+    anymask |= mc[(long)NACC * S + s] != 0.0;
+  }
   double y[NA];
   bool weighted = !anymask;  // valid = ~any(mask, axis=0)   (lib :226)
   if (weighted) {
@@ -415,6 +509,99 @@ __global__ __launch_bounds__(256) void dct_zsum_final_kernel(const double *__res
   zcnt[z] = cnt;
 }
 
+// ---- folded form of pass 2 (origin_dct_fit_sums): dct_moments_kernel<., true> has left
+// part[group][z] = sum of raw over the group's unmasked spaxels.  Masked voxels: the groups
+// that have any (`need` of the solve kernel: a spaxel with a masked voxel, or singular weights)
+// are visited once more, mask bytes only, 64 channels per wave:
+//   part[group][z] += sum_{masked lanes} cont[z, s]      (they are in "all spaxels" Ctot)
+//   nmask[group][z] = masked lanes
+template <int ORDER>
+__global__ __launch_bounds__(64) void dct_masked_corr_kernel(const uint8_t *__restrict__ mask,
+                                                            const uint8_t *__restrict__ flagged,
+                                                            const double *__restrict__ coef,
+                                                            const double *__restrict__ ctab,
+                                                            int Nz, long S,
+                                                            double *__restrict__ part,
+                                                            uint8_t *__restrict__ nmask) {
+  constexpr int NA = ORDER + 1;
+  constexpr int NK = 2 * ORDER + 1;
+  const int lane = threadIdx.x;
+  const long s = (long)blockIdx.x * 64 + lane;
+  const bool live = s < S;
+  const long sc = live ? s : S - 1;
+  if (!__any(live && flagged[sc] != 0)) return;
+  double c[NA];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) c[a] = coef[(long)a * S + sc];
+  const int z0 = blockIdx.y * 64;
+  const int z1 = min(Nz, z0 + 64);
+  for (int zb = z0; zb < z1; zb += 16) {
+    int mk[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) mk[j] = mask[(long)min(zb + j, Nz - 1) * S + sc];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int z = zb + j;
+      const bool m = live && mk[j] && z < z1;
+      const unsigned long long b = __ballot(m);
+      if (b == 0) continue;  // (uniform)
+      double v = m ? eval_cont<ORDER>(c, ctab + (long)z * NK) : 0.0;
+      v = wave_sum(v);
+      if (lane == 0) {
+        part[(long)blockIdx.x * Nz + z] += v;
+        nmask[(long)blockIdx.x * Nz + z] = (uint8_t)__popcll(b);
+      }
+    }
+  }
+}
+
+// sum over the groups, in two fixed-order stages: slab[c][z] = sum of GSLAB groups
+constexpr int GSLAB = 64;
+__global__ __launch_bounds__(256) void dct_part_reduce_kernel(const double *__restrict__ part,
+                                                             const uint8_t *__restrict__ nmask,
+                                                             int Nz, int ngroups,
+                                                             double *__restrict__ slab) {
+  __shared__ double red[2][4][64];
+  const int zl = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const int z = blockIdx.x * 64 + zl;
+  const int g0 = blockIdx.y * GSLAB, g1 = min(ngroups, g0 + GSLAB);
+  double sum = 0.0, cnt = 0.0;
+  if (z < Nz)
+    for (int g = g0 + ph; g < g1; g += 4) {
+      sum += part[(long)g * Nz + z];
+      cnt += (double)nmask[(long)g * Nz + z];
+    }
+  red[0][ph][zl] = sum, red[1][ph][zl] = cnt;
+  __syncthreads();
+  if (ph == 0 && z < Nz) {
+    double *o = slab + ((long)blockIdx.y * Nz + z) * 2;
+    o[0] = (red[0][0][zl] + red[0][1][zl]) + (red[0][2][zl] + red[0][3][zl]);
+    o[1] = (red[1][0][zl] + red[1][1][zl]) + (red[1][2][zl] + red[1][3][zl]);
+  }
+}
+
+template <int ORDER>
+__global__ __launch_bounds__(256) void dct_zsum_fold_final_kernel(
+    const double *__restrict__ slab, int nslab, const double *__restrict__ ctot,
+    const double *__restrict__ ctab, int Nz, long S, double *__restrict__ zsum,
+    double *__restrict__ zcnt) {
+  constexpr int NA = ORDER + 1;
+  constexpr int NK = 2 * ORDER + 1;
+  const int z = blockIdx.x * 256 + threadIdx.x;
+  if (z >= Nz) return;
+  double sum = 0.0, nm = 0.0;
+  for (int c = 0; c < nslab; ++c) {
+    sum += slab[((long)c * Nz + z) * 2];
+    nm += slab[((long)c * Nz + z) * 2 + 1];
+  }
+  const double *ct = ctab + (long)z * NK;
+  double call = 0.0;
+#pragma unroll
+  for (int a = 0; a < NA; ++a) call = fma(ctot[a], ct[a], call);
+  zsum[z] = sum - call;
+  zcnt[z] = (double)S - nm;
+}
+
 // ------------------------------------------------------------------------------------
 // pass 3: standardise.  grid (spaxel blocks, z chunks); per-spaxel sums go to partials.
 // ------------------------------------------------------------------------------------
@@ -603,9 +790,10 @@ int check_dims(int Nz, int Ny, int Nx, int order) {
 
 extern "C" {
 
-int origin_dct_fit(origin_ctx *ctx, const float *d_raw, const float *d_var,
-                   const uint8_t *d_mask, int Nz, int Ny, int Nx, int order, int approx,
-                   double *d_coef) {
+// fit (+ the per-channel residual sums when d_zsum is given: origin_dct_fit_sums)
+static int dct_fit_impl(origin_ctx *ctx, const float *d_raw, const float *d_var,
+                        const uint8_t *d_mask, int Nz, int Ny, int Nx, int order, int approx,
+                        double *d_coef, double *d_zsum, double *d_zcnt) {
   ORIGIN_USE(ctx);
   int rc = check_dims(Nz, Ny, Nx, order);
   if (rc) return rc;
@@ -614,33 +802,94 @@ int origin_dct_fit(origin_ctx *ctx, const float *d_raw, const float *d_var,
   CtabGuard tab(ctx);
   rc = make_ctab(ctx, Nz, order, &tab.p);
   if (rc) return rc;
+  const bool fold = d_zsum != nullptr;
   // z-split so that small fields still fill the chip: waves = S/64 * ZS >= ~4 per SIMD
   const long waves = (S + 63) / 64;
   int ZS = 1;
   while (ZS < 8 && waves * ZS < (long)ctx->num_cu * 16) ZS *= 2;
   const int NACC = (2 * order + 1) + (order + 1);
   while (ZS > 1 && (size_t)(ZS - 1) * (NACC + 1) * 64 * sizeof(double) > 64 * 1024) ZS /= 2;
-  const size_t lds = (size_t)(ZS - 1) * (NACC + 1) * 64 * sizeof(double);
+  const size_t lds = (fold ? (size_t)ZS * MOM_TR_FLOATS * sizeof(float) : 0) +
+                     (size_t)(ZS - 1) * (NACC + 1) * 64 * sizeof(double);
   const size_t lds_r0 = (size_t)(ZS - 1) * (order + 1) * 64 * sizeof(double);
-  dim3 grid((unsigned)waves), block(64, ZS);
+  // scratch: mom | need | part [groups][Nz] | slab [nslab][Nz][2] | ctot | nmask [groups][Nz]
+  const int nslab = cdiv((int)waves, GSLAB);
+  // channel chunks of the moments pass: ~10 rounds of blocks (4 waves per SIMD), chunks >= 256
+  // rows (measured at 3681 x 600 x 600: 2 chunks 3.55 ms, 4: 3.47, 8: 3.21, 12: 3.17)
+  int nzc = (int)((10L * ctx->num_cu * 16 + waves * ZS - 1) / (waves * ZS));
+  nzc = std::max(1, std::min(std::min(nzc, 16), Nz / 256));
+  const int zchunk = cdiv(cdiv(Nz, nzc), 16 * ZS) * 16 * ZS;  // whole 16-row trips of every wave
+  nzc = cdiv(Nz, zchunk);
+  dim3 grid((unsigned)waves), gridm((unsigned)waves, nzc), block(64, ZS);
+  const size_t mom_bytes = (size_t)nzc * (NACC + 1) * S * sizeof(double);
+  const size_t need_bytes = ((size_t)S + 7) & ~(size_t)7;
+  const size_t part_bytes = fold ? (size_t)waves * Nz * sizeof(double) : 0;
+  const size_t slab_bytes = fold ? (size_t)nslab * Nz * 2 * sizeof(double) : 0;
+  const size_t nm_bytes = fold ? (size_t)waves * Nz : 0;
   void *scr = nullptr;
-  rc = origin_scratch(ctx, (size_t)(NACC + 1) * S * sizeof(double) + (size_t)S, &scr);
+  rc = origin_scratch(ctx, mom_bytes + need_bytes + part_bytes + slab_bytes + 64 * sizeof(double) +
+                               nm_bytes, &scr);
   if (rc) return rc;
   double *mom = (double *)scr;
-  uint8_t *need = (uint8_t *)(mom + (size_t)(NACC + 1) * S);
-  ProfScope ps(ctx, K_DCT_FIT);
-#define CALL(O)                                                                                 \
-  if (!approx)                                                                                  \
-    hipLaunchKernelGGL(dct_moments_kernel<O>, grid, block, lds, ctx->stream, d_raw, d_var,      \
-                       d_mask, tab.p, Nz, S, mom);                                              \
-  hipLaunchKernelGGL(dct_solve_kernel<O>, dim3(cdiv(S, 256)), dim3(256), 0, ctx->stream, mom,   \
-                     Nz, S, approx, d_coef, need);                                              \
-  hipLaunchKernelGGL(dct_r0_kernel<O>, grid, block, lds_r0, ctx->stream, d_raw, need, tab.p,    \
+  uint8_t *need = (uint8_t *)scr + mom_bytes;
+  double *part = (double *)((char *)scr + mom_bytes + need_bytes);
+  double *slab = (double *)((char *)part + part_bytes);
+  double *ctot = (double *)((char *)slab + slab_bytes);
+  uint8_t *nmask = (uint8_t *)(ctot + 64);
+  {
+    ProfScope ps(ctx, K_DCT_FIT);
+    if (fold) ORIGIN_HIP(hipMemsetAsync(nmask, 0, nm_bytes, ctx->stream));
+#define CALL(O)                                                                                  \
+  if (fold)                                                                                      \
+    hipLaunchKernelGGL((dct_moments_kernel<O, true>), gridm, block, lds, ctx->stream, d_raw,     \
+                       d_var, d_mask, tab.p, Nz, S, zchunk, mom, part);                          \
+  else if (!approx)                                                                              \
+    hipLaunchKernelGGL((dct_moments_kernel<O, false>), gridm, block, lds, ctx->stream, d_raw,    \
+                       d_var, d_mask, tab.p, Nz, S, zchunk, mom, (double *)nullptr);             \
+  hipLaunchKernelGGL(dct_solve_kernel<O>, dim3(cdiv(S, 256)), dim3(256), 0, ctx->stream, mom,    \
+                     nzc, S, approx, d_coef, need);                                              \
+  hipLaunchKernelGGL(dct_r0_kernel<O>, grid, block, lds_r0, ctx->stream, d_raw, need, tab.p,     \
                      Nz, S, d_coef)
+    DISPATCH_ORDER(order, CALL)
+#undef CALL
+    ORIGIN_LAUNCH_CHECK();
+  }
+  if (!fold) return ORIGIN_OK;
+  ProfScope ps(ctx, K_DCT_SUMS);
+  hipLaunchKernelGGL(coef_total_kernel, dim3(order + 1), dim3(1024), 0, ctx->stream, d_coef, S,
+                     ctot);
+#define CALL(O)                                                                                  \
+  hipLaunchKernelGGL(dct_masked_corr_kernel<O>, dim3((unsigned)waves, cdiv(Nz, 64)), dim3(64), 0, \
+                     ctx->stream, d_mask, need, d_coef, tab.p, Nz, S, part, nmask);              \
+  hipLaunchKernelGGL(dct_part_reduce_kernel, dim3(cdiv(Nz, 64), nslab), dim3(256), 0,            \
+                     ctx->stream, part, nmask, Nz, (int)waves, slab);                            \
+  hipLaunchKernelGGL(dct_zsum_fold_final_kernel<O>, dim3(cdiv(Nz, 256)), dim3(256), 0,           \
+                     ctx->stream, slab, nslab, ctot, tab.p, Nz, S, d_zsum, d_zcnt)
   DISPATCH_ORDER(order, CALL)
 #undef CALL
   ORIGIN_LAUNCH_CHECK();
   return ORIGIN_OK;
+}
+
+int origin_dct_fit(origin_ctx *ctx, const float *d_raw, const float *d_var,
+                   const uint8_t *d_mask, int Nz, int Ny, int Nx, int order, int approx,
+                   double *d_coef) {
+  return dct_fit_impl(ctx, d_raw, d_var, d_mask, Nz, Ny, Nx, order, approx, d_coef, nullptr,
+                      nullptr);
+}
+
+int origin_dct_fit_sums(origin_ctx *ctx, const float *d_raw, const float *d_var,
+                        const uint8_t *d_mask, int Nz, int Ny, int Nx, int order, int approx,
+                        double *d_coef, double *d_zsum, double *d_zcnt) {
+  ORIGIN_USE(ctx);
+  ORIGIN_CHECK_ARG(d_zsum && d_zcnt, "null pointer");
+  if (approx) {  // no moments pass to fold the sums into: the two calls, one after the other
+    int rc = dct_fit_impl(ctx, d_raw, d_var, d_mask, Nz, Ny, Nx, order, approx, d_coef, nullptr,
+                          nullptr);
+    if (rc) return rc;
+    return origin_dct_resid_sums(ctx, d_raw, d_mask, d_coef, Nz, Ny, Nx, order, d_zsum, d_zcnt);
+  }
+  return dct_fit_impl(ctx, d_raw, d_var, d_mask, Nz, Ny, Nx, order, 0, d_coef, d_zsum, d_zcnt);
 }
 
 int origin_dct_continuum(origin_ctx *ctx, const double *d_coef, int Nz, int Ny, int Nx,

@@ -25,6 +25,21 @@ def dct_fit(ctx, raw, var, mask, order=10, approx=False, coef=None):
     return coef
 
 
+def dct_fit_sums(ctx, raw, var, mask, order=10, approx=False, coef=None, zsum=None, zcnt=None):
+    """``dct_fit`` and ``dct_resid_sums`` in one call: the per-channel sums of raw over the
+    unmasked spaxels are taken inside the moments pass, which reads raw and mask anyway (the
+    5 B/voxel plane pass becomes a mask-only visit of the spaxel groups that have masked voxels).
+    Returns (coef, zsum, zcnt)."""
+    Nz, Ny, Nx = raw.shape
+    if coef is None:
+        coef = ctx.empty((order + 1, Ny, Nx), np.float64)
+    zsum = ctx.empty((Nz,), np.float64) if zsum is None else zsum
+    zcnt = ctx.empty((Nz,), np.float64) if zcnt is None else zcnt
+    _capi.call("origin_dct_fit_sums", ctx.handle, raw.p, var.p, mask.p, Nz, Ny, Nx, int(order),
+               int(bool(approx)), coef.p, zsum.p, zcnt.p)
+    return coef, zsum, zcnt
+
+
 def dct_continuum(ctx, coef, Nz, out=None):
     na, Ny, Nx = coef.shape
     if out is None:

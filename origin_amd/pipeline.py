@@ -21,8 +21,7 @@ def preprocess(ctx, raw, var, mask, dct_order=10, dct_approx=False, allreduce=No
     per-channel mean of steps.py:442 is over the *whole* field when the cube is tiled);
     ``allreduce_dev``: the same on the device, ``f(ctx, [DeviceArray, ...])`` in place
     (``TileComm.allreduce_sum_device``: RCCL on the context's stream, no host round trip)."""
-    coef = kernels.dct_fit(ctx, raw, var, mask, dct_order, dct_approx)
-    zsum, zcnt = kernels.dct_resid_sums(ctx, raw, mask, coef)
+    coef, zsum, zcnt = kernels.dct_fit_sums(ctx, raw, var, mask, dct_order, dct_approx)
     if allreduce_dev is not None:
         allreduce_dev(ctx, [zsum, zcnt])
     elif allreduce is not None:

@@ -95,6 +95,43 @@ def test_dct_exact_on_dct_spectra(hip):
         assert np.max(np.abs(cont - raw)) <= 2e-5 * np.max(np.abs(raw))
 
 
+@pytest.mark.parametrize("shape", [(3681, 9, 70), (200, 24, 28), (37, 5, 13), (13, 3, 5),
+                                   (611, 64, 64), (96, 40, 60)])
+def test_dct_fit_sums_equals_the_two_calls(ctx, shape):
+    """origin_dct_fit_sums (per-channel sums folded into the moments pass, rows brought in by
+    LDS-DMA) against origin_dct_fit + origin_dct_resid_sums and against NumPy: clean and masked
+    rows, fully masked spaxels, S % 64 != 0, Nz below / not a multiple of
+    the 16-row trip, fields small enough for several waves per spaxel group."""
+    from origin_amd import kernels
+    Nz, Ny, Nx = shape
+    rng = np.random.default_rng(Nz + Nx)
+    raw = (rng.standard_normal(shape) * 3 + 50 + 10 * np.linspace(0, 1, Nz)[:, None, None])
+    var = 1.0 + rng.random(shape)
+    mask = rng.random(shape) < 0.002
+    mask[:, 0, :] = True                       # a fully masked image row
+    mask[Nz // 3: Nz // 3 + 5, Ny - 1, Nx - 2] = True
+    mask[Nz - 1, 1, 1] = True
+    raw = raw.astype(np.float32)
+    raw[mask] = 0                               # ORIGIN.init: data.filled(0), var.filled(inf)
+    var = var.astype(np.float32)
+    var[mask] = np.inf
+    d_raw, d_var = ctx.to_device(raw, np.float32), ctx.to_device(var, np.float32)
+    d_mask = ctx.to_device(mask.astype(np.uint8))
+    c1 = kernels.dct_fit(ctx, d_raw, d_var, d_mask, 10, False)
+    s1, n1 = kernels.dct_resid_sums(ctx, d_raw, d_mask, c1)
+    c2, s2, n2 = kernels.dct_fit_sums(ctx, d_raw, d_var, d_mask, 10, False)
+    coef2 = c2.to_host()
+    assert np.array_equal(c1.to_host(), coef2)
+    scale = np.abs(raw).sum(axis=(1, 2), dtype=float) + 1.0
+    assert np.max(np.abs(s1.to_host() - s2.to_host()) / scale) <= 1e-14
+    assert np.array_equal(n1.to_host(), n2.to_host())
+    # NumPy: sum over the unmasked spaxels of raw - cont
+    cont = kernels.dct_continuum(ctx, c2, Nz).to_host().astype(float)   # (float32 cube)
+    ref = np.where(mask, 0.0, raw.astype(float) - cont).sum(axis=(1, 2))
+    assert np.max(np.abs(s2.to_host() - ref) / scale) <= 1e-6
+    assert np.array_equal(n2.to_host(), (~mask).sum(axis=(1, 2)).astype(float))
+
+
 # ------------------------------------------------------------------------------- PCA
 def test_gram_mfma_matches_numpy(ctx):
     """G = X^T X from v_mfma_f64_16x16x4_f64 with a deliberately asymmetric X."""
