@@ -254,6 +254,16 @@ int origin_gauss_fit(const double *h_x, const double *h_y, long m, double *h_p, 
 int origin_o2_threshold_batch(const double *h_hist, const double *h_edges, const long *h_nbins,
                               int na, long cap_bins, double coef, double *h_res, int *h_status);
 
+/* ComputePCAThreshold.run for every area in one pass over the host worker pool (steps.py:610-631,
+ * lib_origin.py:977-1024): gather the area's O2 values from the map (h_map float64 [S]; h_idx =
+ * concatenated flat spaxel indices, area a at [h_off[a], h_off[a+1])) into h_data (the
+ * reference's testO2, same layout), then origin_o2_histogram and the threshold fit of
+ * origin_o2_threshold_batch.  Outputs as those two; h_status[a] = 3 if the histogram failed. */
+int origin_o2_areas_fit(const double *h_map, const int *h_idx, const long *h_off, int na,
+                        double sigclip, int maxiters, double coef, double *h_data, double *h_hist,
+                        double *h_edges, long cap_bins, long *h_nbins, double *h_res,
+                        int *h_status);
+
 /* ---- C. GLR correlation ------------------------------------------------------------
  * Replaces Correlation_GLR_test (lib_origin.py:1070-1217) and the dense lines of
  * ComputeTGLR.run (steps.py:781-793).

@@ -71,6 +71,7 @@ SIGNATURES = {
     "origin_o2_histogram_batch": [vp, vp, i32, C.c_double, i32, vp, vp, i64, vp],
     "origin_gauss_fit": [vp, vp, i64, vp, PP(i32), PP(i32)],
     "origin_o2_threshold_batch": [vp, vp, vp, i32, i64, C.c_double, vp, vp],
+    "origin_o2_areas_fit": [vp, vp, vp, i32, C.c_double, i32, C.c_double, vp, vp, vp, i64, vp, vp, vp],
     "origin_glr_plan_create": [vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, PP(vp)],
     "origin_glr_plan_destroy": [vp],
     "origin_glr_plan_set_precision": [vp, i32],

@@ -433,26 +433,16 @@ extern "C" int origin_gauss_fit(const double *h_x, const double *h_y, long m, do
   return ORIGIN_OK;
 }
 
-// Per area: histogram (h_hist / h_edges with row pitch cap_bins + 1, h_nbins) ->
-// (thresO2, mean, stddev) in h_res[a][0..2].  coef = norm.ppf(pfa) computed by the caller.
-// status[a]: 0 ok, 1 = the histogram maximum is the first bin (the reference's argmin over an
-// empty slice raises ValueError), 2 = fewer than 3 bins to fit.
-extern "C" int origin_o2_threshold_batch(const double *h_hist, const double *h_edges,
-                                         const long *h_nbins, int na, long cap_bins, double coef,
-                                         double *h_res, int *h_status) {
-  ORIGIN_CHECK_ARG(h_hist && h_edges && h_nbins && h_res && h_status && na >= 0, "bad arguments");
-  origin_host_pool_run(na, [&](int a) {
-    const double *hist = h_hist + (size_t)a * (cap_bins + 1);
-    const double *edges = h_edges + (size_t)a * (cap_bins + 1);
-    const long nb = h_nbins[a];
-    double *res = h_res + (size_t)a * 3;
+// One area: histogram -> (thresO2, mean, stddev) in res[0..2]; returns the status code of
+// origin_o2_threshold_batch.
+static int o2_threshold_one(const double *hist, const double *edges, long nb, double coef,
+                            double *res) {
     res[0] = res[1] = res[2] = NAN;
     long ind = 0;                                      // np.argmax: first maximum
     for (long i = 1; i < nb; ++i)
       if (hist[i] > hist[ind]) ind = i;
     if (ind == 0) {
-      h_status[a] = 1;
-      return;
+      return 1;
     }
     const double mod = edges[ind];
     const double half = hist[ind] / 2;
@@ -475,8 +465,7 @@ extern "C" int origin_o2_threshold_batch(const double *h_hist, const double *h_e
       if (c < xcut) x.push_back(c), y.push_back(hist[i]);
     }
     if ((long)x.size() < NP) {
-      h_status[a] = 2;
-      return;
+      return 2;
     }
     double p[3] = {hmax, mod, sigma};
     GaussModel model{x.data(), y.data(), (int)x.size()};
@@ -485,7 +474,54 @@ extern "C" int origin_o2_threshold_batch(const double *h_hist, const double *h_e
     res[0] = mea - sd * coef;
     res[1] = mea;
     res[2] = sd;
-    h_status[a] = 0;
+    return 0;
+}
+
+// Per area: histogram (h_hist / h_edges with row pitch cap_bins + 1, h_nbins) ->
+// (thresO2, mean, stddev) in h_res[a][0..2].  coef = norm.ppf(pfa) computed by the caller.
+// status[a]: 0 ok, 1 = the histogram maximum is the first bin (the reference's argmin over an
+// empty slice raises ValueError), 2 = fewer than 3 bins to fit.
+extern "C" int origin_o2_threshold_batch(const double *h_hist, const double *h_edges,
+                                         const long *h_nbins, int na, long cap_bins, double coef,
+                                         double *h_res, int *h_status) {
+  ORIGIN_CHECK_ARG(h_hist && h_edges && h_nbins && h_res && h_status && na >= 0, "bad arguments");
+  origin_host_pool_run(na, [&](int a) {
+    h_status[a] = o2_threshold_one(h_hist + (size_t)a * (cap_bins + 1),
+                                   h_edges + (size_t)a * (cap_bins + 1), h_nbins[a], coef,
+                                   h_res + (size_t)a * 3);
+  });
+  return ORIGIN_OK;
+}
+
+// Gather + clip + histogram + fit of every area in ONE pass over the worker pool: what
+// ComputePCAThreshold.run does per area (steps.py:610-631, lib_origin.py:977-1024), from the O2
+// map and the areas' spaxel lists.  h_map: float64 [S]; h_idx: concatenated flat spaxel indices,
+// area a = [h_off[a], h_off[a+1]); h_data (out): the gathered O2 values in the same layout (the
+// reference's testO2).  Histogram outputs as origin_o2_histogram_batch, results / status as
+// origin_o2_threshold_batch (status 3: the histogram itself failed).
+extern "C" int origin_o2_areas_fit(const double *h_map, const int *h_idx, const long *h_off, int na,
+                                   double sigclip, int maxiters, double coef, double *h_data,
+                                   double *h_hist, double *h_edges, long cap_bins, long *h_nbins,
+                                   double *h_res, int *h_status) {
+  ORIGIN_CHECK_ARG(h_map && h_idx && h_off && h_data && h_hist && h_edges && h_nbins && h_res &&
+                       h_status && na >= 0,
+                   "bad arguments");
+  origin_host_pool_run(na, [&](int a) {
+    const long n = h_off[a + 1] - h_off[a];
+    double *d = h_data + h_off[a];
+    const int *ix = h_idx + h_off[a];
+    for (long i = 0; i < n; ++i) d[i] = h_map[ix[i]];
+    double *hist = h_hist + (size_t)a * (cap_bins + 1);
+    double *edges = h_edges + (size_t)a * (cap_bins + 1);
+    long nk = 0;
+    double *res = h_res + (size_t)a * 3;
+    res[0] = res[1] = res[2] = NAN;
+    if (origin_o2_histogram(d, n, sigclip, maxiters, hist, edges, cap_bins, h_nbins + a, &nk) !=
+        ORIGIN_OK) {
+      h_status[a] = 3;
+      return;
+    }
+    h_status[a] = o2_threshold_one(hist, edges, h_nbins[a], coef, res);
   });
   return ORIGIN_OK;
 }

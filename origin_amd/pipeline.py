@@ -11,7 +11,7 @@ import numpy as np
 
 from . import kernels
 from .pca import GreedyPCA
-from .thresholds import thresholds_batch
+from .thresholds import areas_fit
 
 
 def preprocess(ctx, raw, var, mask, dct_order=10, dct_approx=False, allreduce=None,
@@ -59,20 +59,18 @@ def pca_threshold(o2_map, areamap, nbAreas, pfa_test=0.01, spx=None):
     spx = area_lists(areamap, nbAreas) if spx is None else spx
     flat = np.asarray(o2_map, dtype=np.float64).reshape(-1)
 
-    # one gather through the concatenated lists (kept per list object), per-area views into it
+    # the concatenated lists are kept per list object; gather, clip, histogram, Gaussian fit and
+    # threshold of all areas: one native call spread over the host worker pool (csrc/thresh.hip,
+    # csrc/lmfit.hip)
     cat = _CAT.get(id(spx))
     if cat is None or cat[0] is not spx:
         off = np.zeros(len(spx) + 1, dtype=np.int64)
         off[1:] = np.cumsum([len(s) for s in spx])
-        idx = np.concatenate(spx) if len(spx) else np.zeros(0, np.int64)
+        idx = (np.concatenate(spx) if len(spx) else np.zeros(0)).astype(np.int32)
         _CAT.clear()
         cat = _CAT[id(spx)] = (spx, idx, off)
     _, idx, off = cat
-    data = flat[idx]
-    tests = [data[off[a]:off[a + 1]] for a in range(len(spx))]
-    # clip + histogram + Gaussian fit + threshold of all areas: two native calls spread over
-    # the host worker pool (csrc/thresh.hip, csrc/lmfit.hip)
-    fits = thresholds_batch(tests, pfa_test, _cat=(data, off)) if tests else []
+    tests, fits = areas_fit(flat, idx, off, pfa_test) if len(spx) else ([], [])
     results = [(t,) + f for t, f in zip(tests, fits)]
     testO2, histO2, binO2, thresO2, meaO2, stdO2 = zip(*results)
     return dict(testO2=testO2, histO2=histO2, binO2=binO2, thresO2=thresO2, meaO2=meaO2,

@@ -150,6 +150,38 @@ def thresholds_batch(tests, pfa, sigclip=10, _cat=None):
              res[a, 1], res[a, 2]) for a in range(na)]
 
 
+def areas_fit(o2_flat, idx, off, pfa, sigclip=10):
+    """``thresholds_batch`` straight from the O2 map: ``idx`` (int32) are the concatenated flat
+    spaxel indices of the areas, area a at ``idx[off[a]:off[a+1]]``.  Gather, clip, histogram,
+    fit and threshold of every area run in ONE dispatch of the native worker pool
+    (``origin_o2_areas_fit``).  Returns (tests, fits): the per-area O2 vectors (views into one
+    buffer, the reference's ``testO2``) and one (histO2, frecO2, thresO2, mea, std) per area."""
+    from . import _capi
+    o2_flat = np.ascontiguousarray(o2_flat, dtype=np.float64).reshape(-1)
+    na = len(off) - 1
+    lens = np.diff(off)
+    cap = int(max(4096, lens.max() if na else 0))
+    data = np.empty(int(off[-1]))
+    hist = np.empty((na, cap + 1))
+    edges = np.empty((na, cap + 1))
+    nb = np.zeros(na, dtype=np.int64)
+    res = np.empty((na, 3))
+    status = np.zeros(na, dtype=np.int32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    _capi.call("origin_o2_areas_fit", p(o2_flat), p(idx), p(off), na, float(sigclip), 5,
+               float(ndtri(pfa)), p(data), p(hist), p(edges), cap, p(nb), p(res), p(status))
+    if np.any(status == 3):
+        raise ValueError("origin_o2_histogram failed for at least one area (empty or too many bins)")
+    if np.any(status == 1):
+        raise ValueError("attempt to get argmin of an empty sequence")   # np.argmin's message
+    if np.any(status == 2):
+        raise ValueError("fewer than three histogram bins left of the mode: no Gaussian fit")
+    tests = [data[off[a]:off[a + 1]] for a in range(na)]
+    fits = [(hist[a, :nb[a]].copy(), edges[a, :nb[a] + 1].copy(), float(res[a, 0]),
+             res[a, 1], res[a, 2]) for a in range(na)]
+    return tests, fits
+
+
 def clipped_histogram_numpy(data, bins='fd', sigclip=10):
     data = np.asarray(data, dtype=float)
     data = data[data > 0]

@@ -43,6 +43,23 @@ def test_native_lm_fit_equals_scipy_leastsq():
         assert r[2] == one[2] and r[3] == one[3] and r[4] == one[4]
         np.testing.assert_array_equal(r[0], one[0])
         np.testing.assert_array_equal(r[1], one[1])
+    # and so is the single-dispatch form that starts from the O2 map and the areas' spaxel lists
+    # (what ComputePCAThreshold.run uses): scattered, interleaved index lists
+    lens = [len(t) for t in cases]
+    perm = rng.permutation(sum(lens))
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    o2map = np.empty(sum(lens))
+    o2map[perm] = np.concatenate(cases)
+    tests_, fits = thresholds.areas_fit(o2map, perm.astype(np.int32), off, 0.01)
+    for t, t2, r, f in zip(cases, tests_, res, fits):
+        np.testing.assert_array_equal(t, t2)
+        assert f[2:] == r[2:]
+        np.testing.assert_array_equal(f[0], r[0])
+        np.testing.assert_array_equal(f[1], r[1])
+    with __import__("pytest").raises(ValueError):
+        bad = np.concatenate([np.full(500, 1.0), np.linspace(1.0, 3.0, 40)])
+        thresholds.areas_fit(bad, np.arange(len(bad), dtype=np.int32),
+                             np.array([0, len(bad)], np.int64), 0.01)
 
 
 def test_threshold_batch_raises_where_the_reference_does():
