@@ -387,8 +387,16 @@ def main():
         out = last["out"]
         wins = wc.glr_windows(ny, nx) if full else \
             wc.glr_windows(ny, nx, out=32, halo=24, which=("interior",))
+        # tolerances of the arithmetic the GLR ran in: fp32-class for f32 / f16x2,
+        # screening quality for the single-bf16-MFMA form
+        if glr_precision == "bf16":
+            gtol = dict(tol=5e-2, tol_argmax=2e-2, tol_rms=5e-3)
+            gtxt = "GLR (bf16) |dT|<=5e-2, rms<=5e-3, argmax mismatch<=2e-2"
+        else:
+            gtol = dict(tol=1e-4, tol_argmax=1e-4)
+            gtxt = "GLR |dT|<=1e-4, argmax mismatch<=1e-4"
         glr_res = [wc.check_glr_window(cube_faint, out, mask, psf64, field.profiles, w,
-                                       nthreads=ncpu) for w in wins]
+                                       nthreads=ncpu, **gtol) for w in wins]
         # PCA: the area that iterated longest and (full) the one with the median count
         iters = np.array([last["mapO2"].reshape(-1)[s_].max() for s_ in spx])
         order_a = np.argsort(-iters, kind="stable")
@@ -406,7 +414,7 @@ def main():
             dct_res.append(r_)
         check = dict(level=args.check, glr=glr_res, pca=pca_res, dct=dct_res,
                      ok=bool(all(r_["ok"] for r_ in glr_res + pca_res + dct_res)),
-                     tolerances="GLR |dT|<=1e-4, argmax mismatch<=1e-4; PCA rel-Frobenius<=2e-6, "
+                     tolerances=gtxt + "; PCA rel-Frobenius<=2e-6, "
                                 "max-abs<=1e-4, mapO2 identical; DCT 1e-5*max(1,|x|)",
                      oracle="oracle.cpu_ref (float64) on haloed windows / whole areas of the "
                             "device arrays of the last step",

@@ -37,7 +37,7 @@ def _valid(lo, hi, N, c):
 
 
 def check_glr_window(faint, dev_out, mask, psf, profiles, window, pcut=1e-8, pmeansub=True,
-                     nthreads=1, tol=1e-4, tol_argmax=1e-4):
+                     nthreads=1, tol=1e-4, tol_argmax=1e-4, tol_rms=None):
     """Oracle GLR on one window of the device's input cube against the device's outputs.
 
     faint   : DeviceArray (Nz, Ny, Nx), the cube the device GLR ran on
@@ -63,9 +63,12 @@ def check_glr_window(faint, dev_out, mask, psf, profiles, window, pcut=1e-8, pme
                voxels=int(got["correl"].size))
     res["correl"] = float(np.max(np.abs(got["correl"] - correl[sl])))
     res["correl_min"] = float(np.max(np.abs(got["correl_min"] - correl_min[sl])))
+    res["correl_rms"] = float(np.sqrt(np.mean((got["correl"] - correl[sl]) ** 2)))
     res["argmax_mismatch"] = float(np.mean(got["profile"] != profile[sl]))
     res["T_range"] = [float(correl_min[sl].min()), float(correl[sl].max())]
     ok = res["correl"] <= tol and res["correl_min"] <= tol and res["argmax_mismatch"] <= tol_argmax
+    if tol_rms is not None:
+        ok = ok and res["correl_rms"] <= tol_rms
     for key, ref_map in (("maxmap", correl[sl].max(axis=0)), ("minmap", correl_min[sl].min(axis=0))):
         d = dev_out.get(key)
         if d is not None:
