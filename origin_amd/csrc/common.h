@@ -108,10 +108,12 @@ struct ProfScope {
 void origin_set_error(const char *fmt, ...);
 int origin_scratch(origin_ctx *ctx, size_t bytes, void **out);
 
-// glr_spatial_mfma.hip: matrix-core spatial GLR stage (one field, no weight map)
+// glr_spatial_mfma.hip: matrix-core spatial GLR stage (one field, or one weighted field of a
+// mosaic: W its weight map, accf = add to what the fields before left in out)
 int origin_spatial_mfma_ok(int Ny, int Nx, int P);
-int origin_spatial_mfma_launch(origin_ctx *ctx, int terms, const float *A, const float *taps,
-                               int Nz, int Ny, int Nx, int P, float *out);
+int origin_spatial_mfma_launch(origin_ctx *ctx, int terms, const float *A, const float *W,
+                               const float *taps, int Nz, int Ny, int Nx, int P, int accf,
+                               float *out);
 
 #define ORIGIN_CHECK_ARG(cond, ...)       \
   do {                                    \

@@ -58,6 +58,9 @@ struct origin_glr_plan {
   float *d_rdi_s;  // interior-class 1/sqrt(den) in processing order [slot][NzP]
   std::vector<int> *h_order;  // processing order on the host (plan creation only)
   int precision;   // 0 = fp32 FMA kernels, 1 = split-f16 MFMA stages, 2 = bf16 MFMA stages
+  float *d_normc;  // mode 1: norm_fsf [Nz][Ny][Nx], a constant of the plan (PSFs and weight maps
+                   // only), computed by the first run and kept
+  int normc_ready;
   size_t bytes;
 };
 
@@ -851,7 +854,7 @@ int origin_glr_plan_destroy(origin_glr_plan *plan) {
                   (void *)plan->d_taps2, (void *)plan->d_tap_off, (void *)plan->d_rden,
                   (void *)plan->d_htaps, (void *)plan->d_htap_off, (void *)plan->d_rows,
                   (void *)plan->d_border, (void *)plan->d_atab, (void *)plan->d_atab_bf16,
-                  (void *)plan->d_pwide, (void *)plan->d_rdi_s})
+                  (void *)plan->d_pwide, (void *)plan->d_rdi_s, (void *)plan->d_normc})
     if (p) (void)hipFree(p);
   delete plan->h_order;
   delete plan;
@@ -1010,6 +1013,11 @@ int origin_glr_plan_create(origin_ctx *ctx, int Nz, int Ny, int Nx, int nfields,
     pl->h_order = new std::vector<int>(order);
     pl->precision = getenv("ORIGIN_GLR_FP32") ? 0 : 1;
   }
+  // a mosaic of weighted fields: its spatial stage runs on the matrix cores too (per-field
+  // accumulation, glr_spatial_mfma.hip); its spectral stage convolves the norm cube next to the
+  // data and stays in fp32
+  if (h_weights && pl->precision == 0 && origin_spatial_mfma_ok(Ny, Nx, P) && !getenv("ORIGIN_GLR_FP32"))
+    pl->precision = 1;
   // scalar loads may read a few taps past the end of a profile row: pad
   for (int i = 0; i < 64; ++i) {
     taps.push_back(0.f);
@@ -1076,7 +1084,9 @@ int origin_glr_plan_create(origin_ctx *ctx, int Nz, int Ny, int Nx, int nfields,
 int origin_glr_plan_set_precision(origin_glr_plan *plan, int precision) {
   ORIGIN_CHECK_ARG(plan && precision >= 0 && precision <= 2, "precision must be 0, 1 or 2");
   // the matrix-core stages need the plan's tap tables (weights=None, half widths <= 32)
-  plan->precision = plan->d_atab ? precision : 0;
+  plan->precision = (plan->d_atab || (plan->d_w && origin_spatial_mfma_ok(plan->Ny, plan->Nx, plan->P)))
+                        ? precision
+                        : 0;
   return ORIGIN_OK;
 }
 
@@ -1096,9 +1106,10 @@ int origin_glr_work_elems(origin_glr_plan *plan, size_t *elems) {
   ORIGIN_CHECK_ARG(plan && elems, "null argument");
   const size_t cube = (size_t)plan->Nz * plan->Ny * plan->Nx;
   const size_t S = (size_t)plan->Ny * plan->Nx;
-  // zero pad + cube_fsf + zero pad (+ norm_fsf in mode 1) + maxmap/minmap partials (<= 64 chunks
-  // each)
-  *elems = cube * (plan->mode == 1 ? 2 : 1) + 2 * 64 * S + (MF_PAD_FRONT + MF_PAD_BACK) * S;
+  // zero pad + cube_fsf + zero pad + maxmap/minmap partials (<= 64 chunks each); the norm cube
+  // of mode 1 belongs to the plan
+  (void)cube;
+  *elems = cube + 2 * 64 * S + (MF_PAD_FRONT + MF_PAD_BACK) * S;
   return ORIGIN_OK;
 }
 
@@ -1112,11 +1123,17 @@ int origin_glr_run(origin_ctx *ctx, origin_glr_plan *pl, const float *d_cube,
   const int Nz = pl->Nz, Ny = pl->Ny, Nx = pl->Nx, P = pl->P, K = pl->K;
   const long S = (long)Ny * Nx;
   const size_t cube = (size_t)Nz * S;
-  // [pad | cube_fsf | pad | norm_fsf (mode 1) | partial maps]; the pads are zero channels
+  // [pad | cube_fsf | pad | partial maps]; the pads are zero channels
   float *fsf = d_work + (size_t)MF_PAD_FRONT * S;
-  float *after = fsf + cube + (size_t)MF_PAD_BACK * S;
-  float *norm = pl->mode == 1 ? after : nullptr;
-  float *part = after + (pl->mode == 1 ? cube : 0);
+  float *part = fsf + cube + (size_t)MF_PAD_BACK * S;
+  // mode 1: norm_fsf depends on the PSFs and the weight maps only -- the first run computes it
+  // into a cube the plan keeps
+  if (pl->mode == 1 && !pl->d_normc) {
+    ORIGIN_HIP(hipMalloc((void **)&pl->d_normc, cube * sizeof(float)));
+    pl->bytes += cube * sizeof(float);
+    pl->normc_ready = 0;
+  }
+  float *norm = pl->mode == 1 ? pl->d_normc : nullptr;
   ORIGIN_HIP(hipMemsetAsync(d_work, 0, (size_t)MF_PAD_FRONT * S * sizeof(float), ctx->stream));
   ORIGIN_HIP(hipMemsetAsync(fsf + cube, 0, (size_t)MF_PAD_BACK * S * sizeof(float), ctx->stream));
 
@@ -1161,20 +1178,22 @@ int origin_glr_run(origin_ctx *ctx, origin_glr_plan *pl, const float *d_cube,
     ProfScope ps(ctx, K_GLR_SPATIAL);
     const float *kf = pl->d_k + (size_t)f * Nz * P * P;
     const float *wf = pl->d_w ? pl->d_w + (size_t)f * S : nullptr;
-    if (pl->mode == 0 && pl->precision >= 1 && !wf && pl->nfields == 1 &&
-        origin_spatial_mfma_ok(Ny, Nx, P)) {
-      // matrix cores, two-term f16 split (glr_spatial_mfma.hip)
-      int rc = origin_spatial_mfma_launch(ctx, pl->precision == 2 ? 1 : 3, d_cube, kf, Nz, Ny, Nx, P,
-                                          fsf);
+    const bool sp_mfma = pl->precision >= 1 && origin_spatial_mfma_ok(Ny, Nx, P) &&
+                         ((pl->mode == 0 && !wf && pl->nfields == 1) || wf);
+    if (sp_mfma) {
+      // matrix cores, two-term f16 split (glr_spatial_mfma.hip); weighted fields accumulate
+      int rc = origin_spatial_mfma_launch(ctx, pl->precision == 2 ? 1 : 3, d_cube, wf, kf, Nz, Ny,
+                                          Nx, P, wf && f > 0, fsf);
       if (rc) return rc;
-      continue;
+    } else {
+      spatial(d_cube, wf, kf, f > 0, fsf);
     }
-    spatial(d_cube, wf, kf, f > 0, fsf);
-    if (pl->mode == 1) {
+    if (pl->mode == 1 && !pl->normc_ready) {
       const float *k2f = pl->d_k2 + (size_t)f * Nz * P * P;
       spatial(nullptr, wf, k2f, f > 0, norm);
     }
   }
+  if (pl->mode == 1) pl->normc_ready = 1;
   ORIGIN_LAUNCH_CHECK();
 
   // ---- spectral stage

@@ -31,8 +31,8 @@
 // TERMS = 1: bf16 operands, one MFMA per k-step (BASELINE config 4's bf16 GLR), no scaling.
 //
 // Eligible shapes: P in {9, 17, 25} (any field size: 16-byte accesses when Nx % 4 == 0, element
-// accesses otherwise); weight maps, several fields and other PSF sizes stay on spatial4x4_kernel /
-// spatial_kernel.
+// accesses otherwise), one field or a mosaic of weighted fields (WEIGHTED); other PSF sizes stay
+// on spatial4x4_kernel / spatial_kernel.
 #include <algorithm>
 
 #include "common.h"
@@ -84,10 +84,14 @@ __device__ __forceinline__ void s2_split(float y, _Float16 &hi, _Float16 &lo) {
 
 // VEC: Nx % 4 == 0 -- rows of the cube are 16-byte aligned, the tile is loaded and the outputs are
 // stored four at a time; otherwise element by element.
-template <int P, int TERMS, bool VEC>
+// WEIGHTED: one field of a mosaic (lib_origin.py:1029-1031, :1134-1147): the input is cube * W
+// (W [Ny][Nx], the field's weight map, multiplied in while the tile is staged) and, with accf,
+// the result is added to what the fields before left in `out`.
+template <int P, int TERMS, bool VEC, bool WEIGHTED>
 __global__ __launch_bounds__(512, 1) void spatial2_kernel(const float *__restrict__ A,
+                                                          const float *__restrict__ W,
                                                           const float *__restrict__ taps, int Nz,
-                                                          int Ny, int Nx, int zper,
+                                                          int Ny, int Nx, int zper, int accf,
                                                           float *__restrict__ out) {
   using G = S2Geom<P>;
   extern __shared__ __align__(16) char s2_lds[];
@@ -123,14 +127,26 @@ __global__ __launch_bounds__(512, 1) void spatial2_kernel(const float *__restric
       const int y = y0 - c + ry, x = x0 - c + 4 * cx;  // x % 4 == 0 (c % 4 == 0), Nx % 4 == 0
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if constexpr (VEC) {
-        if (ry < G::IH && y >= 0 && y < Ny && x >= 0 && x < Nx)
+        if (ry < G::IH && y >= 0 && y < Ny && x >= 0 && x < Nx) {
           v = *reinterpret_cast<const float4 *>(Az + (long)y * Nx + x);
+          if constexpr (WEIGHTED) {
+            const float4 w = *reinterpret_cast<const float4 *>(W + (long)y * Nx + x);
+            v.x *= w.x, v.y *= w.y, v.z *= w.z, v.w *= w.w;
+          }
+        }
       } else if (ry < G::IH && y >= 0 && y < Ny) {
         const float *row = Az + (long)y * Nx;
         if (x >= 0 && x < Nx) v.x = row[x];
         if (x + 1 >= 0 && x + 1 < Nx) v.y = row[x + 1];
         if (x + 2 >= 0 && x + 2 < Nx) v.z = row[x + 2];
         if (x + 3 >= 0 && x + 3 < Nx) v.w = row[x + 3];
+        if constexpr (WEIGHTED) {
+          const float *wr = W + (long)y * Nx;
+          if (x >= 0 && x < Nx) v.x *= wr[x];
+          if (x + 1 >= 0 && x + 1 < Nx) v.y *= wr[x + 1];
+          if (x + 2 >= 0 && x + 2 < Nx) v.z *= wr[x + 2];
+          if (x + 3 >= 0 && x + 3 < Nx) v.w *= wr[x + 3];
+        }
       }
       stage[q] = v;
     }
@@ -281,12 +297,25 @@ __global__ __launch_bounds__(512, 1) void spatial2_kernel(const float *__restric
         if (y >= Ny) continue;
         float *o = out + (long)z * S + (long)y * Nx + xo;
         if constexpr (VEC) {  // Nx % 4 == 0: a float4 is inside or outside as a whole
-          *reinterpret_cast<float4 *>(o) = make_float4(acc[4 * pr] * inv, acc[4 * pr + 1] * inv,
-                                                       acc[4 * pr + 2] * inv, acc[4 * pr + 3] * inv);
+          float4 r = make_float4(acc[4 * pr] * inv, acc[4 * pr + 1] * inv, acc[4 * pr + 2] * inv,
+                                 acc[4 * pr + 3] * inv);
+          if constexpr (WEIGHTED) {
+            if (accf) {
+              const float4 b = *reinterpret_cast<const float4 *>(o);
+              r.x += b.x, r.y += b.y, r.z += b.z, r.w += b.w;
+            }
+          }
+          *reinterpret_cast<float4 *>(o) = r;
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            if (xo + e < Nx) o[e] = acc[4 * pr + e] * inv;
+            if (xo + e < Nx) {
+              float r = acc[4 * pr + e] * inv;
+              if constexpr (WEIGHTED) {
+                if (accf) r += o[e];
+              }
+              o[e] = r;
+            }
         }
       }
     }
@@ -327,13 +356,13 @@ int origin_spatial_mfma_ok(int Ny, int Nx, int P) {
   return (P == 9 || P == 17 || P == 25) && Nx >= 1 && Ny >= 1;
 }
 
-template <int P, int TERMS, bool VEC>
-static int s2_launch(origin_ctx *ctx, const float *A, const float *taps, int Nz, int Ny, int Nx,
-                     float *out) {
+template <int P, int TERMS, bool VEC, bool WEIGHTED>
+static int s2_launch(origin_ctx *ctx, const float *A, const float *W, const float *taps, int Nz,
+                     int Ny, int Nx, int accf, float *out) {
   const size_t lds = 2 * s2_group_bytes<P, TERMS>();
   static bool attr_done = false;
   if (!attr_done) {
-    ORIGIN_HIP(hipFuncSetAttribute((const void *)spatial2_kernel<P, TERMS, VEC>,
+    ORIGIN_HIP(hipFuncSetAttribute((const void *)spatial2_kernel<P, TERMS, VEC, WEIGHTED>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
@@ -355,28 +384,39 @@ static int s2_launch(origin_ctx *ctx, const float *A, const float *taps, int Nz,
   int zper = cdiv(Nz, best_nzb);
   zper += zper & 1;
   dim3 grid(cdiv(Nx, S2_R), cdiv(Ny, S2_R), cdiv(Nz, zper));
-  hipLaunchKernelGGL((spatial2_kernel<P, TERMS, VEC>), grid, dim3(512), lds, ctx->stream, A, taps,
-                     Nz, Ny, Nx, zper, out);
+  hipLaunchKernelGGL((spatial2_kernel<P, TERMS, VEC, WEIGHTED>), grid, dim3(512), lds, ctx->stream,
+                     A, W, taps, Nz, Ny, Nx, zper, accf, out);
   ORIGIN_LAUNCH_CHECK();
   return ORIGIN_OK;
 }
 
-int origin_spatial_mfma_launch(origin_ctx *ctx, int terms, const float *A, const float *taps,
-                               int Nz, int Ny, int Nx, int P, float *out) {
+// W: weight map of the field or NULL; accf: add to `out` (fields after the first)
+int origin_spatial_mfma_launch(origin_ctx *ctx, int terms, const float *A, const float *W,
+                               const float *taps, int Nz, int Ny, int Nx, int P, int accf,
+                               float *out) {
   const bool vec = (Nx & 3) == 0;
-#define S2_CASE(PP)                                                                          \
-  case PP:                                                                                   \
-    if (vec)                                                                                 \
-      return terms == 3 ? s2_launch<PP, 3, true>(ctx, A, taps, Nz, Ny, Nx, out)              \
-                        : s2_launch<PP, 1, true>(ctx, A, taps, Nz, Ny, Nx, out);             \
-    return terms == 3 ? s2_launch<PP, 3, false>(ctx, A, taps, Nz, Ny, Nx, out)               \
-                      : s2_launch<PP, 1, false>(ctx, A, taps, Nz, Ny, Nx, out)
+  if (!W && accf) {
+    origin_set_error("spatial MFMA kernel: accumulation needs a weight map");
+    return ORIGIN_E_ARG;
+  }
+#define S2_GO(PP, TT, VV)                                                                      \
+  return W ? s2_launch<PP, TT, VV, true>(ctx, A, W, taps, Nz, Ny, Nx, accf, out)               \
+           : s2_launch<PP, TT, VV, false>(ctx, A, nullptr, taps, Nz, Ny, Nx, 0, out)
+#define S2_CASE(PP)                        \
+  case PP:                                 \
+    if (vec) {                             \
+      if (terms == 3) S2_GO(PP, 3, true);  \
+      S2_GO(PP, 1, true);                  \
+    }                                      \
+    if (terms == 3) S2_GO(PP, 3, false);   \
+    S2_GO(PP, 1, false)
   switch (P) {
     S2_CASE(9);
     S2_CASE(17);
     S2_CASE(25);
   }
 #undef S2_CASE
+#undef S2_GO
   origin_set_error("spatial MFMA kernel: PSF size %d not supported", P);
   return ORIGIN_E_ARG;
 }

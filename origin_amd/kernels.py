@@ -171,8 +171,10 @@ class GLRPlan:
         _capi.call("origin_glr_plan_get_precision", self._h, C.byref(got))
         self.precision = self.PRECISIONS[got.value]
         # mirrors origin_spatial_mfma_ok (csrc/glr_spatial_mfma.hip): which spatial kernel runs
-        self.spatial_on_matrix_cores = (self.precision != "f32" and w is None and
-                                        self.P in (9, 17, 25))
+        # (weighted mosaics included: per-field accumulation on the matrix cores; their spectral
+        # stage convolves the norm cube next to the data and stays in fp32)
+        self.spatial_on_matrix_cores = self.precision != "f32" and self.P in (9, 17, 25)
+        self.spectral_on_matrix_cores = self.precision != "f32" and w is None
 
     def close(self):
         if self._h is not None and self._h.value:

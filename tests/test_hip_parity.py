@@ -327,6 +327,56 @@ def test_glr_matrix_core_spatial_stage(ctx, shape, P):
     assert np.max(np.abs(got["f16x2"] - got["f32"])) <= 1e-4
 
 
+@pytest.mark.parametrize("shape,P,nf", [((60, 70, 132), 9, 2), ((40, 66, 67), 25, 3),
+                                         ((48, 30, 140), 17, 2)])
+def test_glr_weighted_fields_on_matrix_cores(ctx, shape, P, nf):
+    """A mosaic: several fields, each with its PSF and weight map (origin.py:600-609,
+    lib_origin.py:1029-1031, :1134-1147).  The spatial stage runs per field on the matrix cores
+    (weight map multiplied in while the tile is staged, fields accumulated), the norm cube is a
+    constant of the plan (computed by the first run), the spectral stage convolves it next to
+    the data in fp32.  Against the float64 oracle, against the fp32 plan, and a second run of
+    the same plan (cached norm cube) against the first."""
+    from origin_amd import kernels
+    rng = np.random.default_rng(P + shape[2] + nf)
+    Nz, Ny, Nx = shape
+    cube = rng.standard_normal(shape).astype(np.float32)
+    cube[Nz // 2, Ny // 2, Nx // 3] += 40.0
+    psfs, ws = [], []
+    x = np.linspace(0, 1, Nx)[None, :] * np.ones((Ny, 1))
+    y = np.linspace(0, 1, Ny)[:, None] * np.ones((1, Nx))
+    raww = [0.2 + x, 1.2 - x, 0.1 + y * y][:nf]
+    tot = sum(raww)
+    for f in range(nf):
+        p = synth.moffat_psf(Nz, P, fwhm0=3.6 - 0.4 * f, fwhm1=3.0 + 0.2 * f).astype(np.float64)
+        p *= 1.0 + 0.2 * rng.random(p.shape)
+        p /= p.sum(axis=(1, 2), keepdims=True)
+        psfs.append(p)
+        ws.append((raww[f] / tot).astype(np.float32).astype(np.float64))
+    ws[0][:5, :7] = 0.0                     # a corner one field does not cover
+    prof = synth.dico_fwhm(3)
+    ref = cpu_ref.Correlation_GLR_test(cube.astype(np.float64), psfs, ws, prof, nthreads=1,
+                                       pcut=1e-8, pmeansub=True)
+    d = ctx.to_device(cube)
+    got = {}
+    for prec in ("f16x2", "f32"):
+        plan = kernels.GLRPlan(ctx, shape, psfs, ws, prof, 1e-8, True, precision=prec)
+        assert plan.precision == prec
+        assert plan.spatial_on_matrix_cores == (prec == "f16x2")
+        assert not plan.spectral_on_matrix_cores
+        for rep in range(2):
+            out = plan.run(d, mask=None, want_maps=True)
+            c = out["correl"].to_host()
+            if rep == 1:
+                assert np.array_equal(c, got[prec])
+            got[prec] = c
+            assert np.max(np.abs(c - ref[0])) <= 1e-4
+            assert np.max(np.abs(out["correl_min"].to_host() - ref[2])) <= 1e-4
+            assert np.mean(out["profile"].to_host() != ref[1]) <= 1e-4
+            assert np.max(np.abs(out["maxmap"].to_host() - ref[0].max(axis=0))) <= 1e-4
+        plan.close()
+    assert np.max(np.abs(got["f16x2"] - got["f32"])) <= 1e-4
+
+
 def test_glr_bf16_precision_meets_the_bf16_tolerance(ctx):
     """precision="bf16" (BASELINE config 4): one bf16 MFMA per product in the spectral stage.
     SURVEY 8c tolerance for bf16 operands with wide accumulation: |dT| <= 5e-2, rms <= 5e-3,
