@@ -520,8 +520,19 @@ int origin_spectral_mfma_launch(origin_ctx *ctx, int terms, const float *fsf, co
                                 bool want_maps, int *nzc_out, float **pmax_out, float **pmin_out) {
   const long S = (long)Ny * Nx;
   const long bx = cdiv(S, 32 * MF_WAVES);
-  int nzm = (int)(((long)ctx->num_cu * 8 + bx - 1) / bx);
-  nzm = std::max(1, std::min(nzm, std::min(64, cdiv(Nz, 64))));
+  // One block per CU at a time (LDS): pick the number of z chunks so that the blocks fill whole
+  // rounds of the chip -- useful channel slots / (rounds x CUs x (chunk length + ~one tile of
+  // start-up per block)); chunks are whole 32-channel tiles, at most 64 of them (partial maps)
+  const int ncu = std::max(1, ctx->num_cu);
+  int nzm = 1;
+  double best_eff = 0.0;
+  for (int n = 1; n <= std::min(64, std::max(1, cdiv(Nz, 64))); ++n) {
+    const int zc = (cdiv(Nz, n) + 31) / 32 * 32;
+    const long blocks = bx * cdiv(Nz, zc);
+    const long rounds = (blocks + ncu - 1) / ncu;
+    const double eff = (double)bx * Nz / ((double)rounds * ncu * (zc + 32));
+    if (eff > best_eff * 1.0001) best_eff = eff, nzm = n;
+  }
   const int zcm = (cdiv(Nz, nzm) + 31) / 32 * 32;
   nzm = cdiv(Nz, zcm);
   float *pmax = want_maps ? part : nullptr;
