@@ -62,6 +62,10 @@ int origin_free(origin_ctx *ctx, void *d_ptr);
 int origin_memset(origin_ctx *ctx, void *d_ptr, int byte, size_t bytes);
 int origin_h2d(origin_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int origin_d2h(origin_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+/* Device float32 -> host float64, n elements: the widening the reference's float64 interface
+ * needs (cubes leaving through the function seam, steps.py store_cube), chunked through pinned
+ * staging and widened by the host worker pool while the next chunk is in flight. */
+int origin_d2h_f32_as_f64(origin_ctx *ctx, double *h_dst, const float *d_src, size_t n);
 int origin_d2d(origin_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
 /* strided 3-D box copy of `elem`-byte elements between (Nz, Ny, Nx)-shaped arrays; kind:
  * 0 = host->device, 1 = device->host, 2 = device->device.  Pitches in elements.  Used

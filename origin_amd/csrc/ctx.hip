@@ -2,7 +2,11 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include <functional>
+
 #include "common.h"
+
+void origin_host_pool_run(int n, const std::function<void(int)> &task);  // thresh.hip (C++ linkage)
 
 static thread_local char g_err[1024] = "";
 
@@ -336,6 +340,49 @@ int origin_d2h(origin_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
   if (bytes == 0) return ORIGIN_OK;
   ORIGIN_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   ORIGIN_HIP(hipStreamSynchronize(ctx->stream));
+  return ORIGIN_OK;
+}
+
+// Device float32 -> host float64 (the reference's arrays are float64: every cube that leaves
+// through the function seam or a LazyCube is widened).  Chunks of the device array land in two
+// pinned staging buffers by turns; while chunk i + 1 is in flight the host worker pool widens chunk
+// i into the destination -- instead of a pageable copy followed by a single-threaded astype.
+int origin_d2h_f32_as_f64(origin_ctx *ctx, double *h_dst, const float *d_src, size_t n) {
+  ORIGIN_USE(ctx);
+  if (n == 0) return ORIGIN_OK;
+  ORIGIN_CHECK_ARG(h_dst && d_src, "null pointer");
+  constexpr size_t CH = (size_t)16 << 20;  // elements per chunk: 64 MiB of float32
+  static thread_local float *stage[2] = {nullptr, nullptr};
+  static thread_local hipEvent_t ev[2];
+  if (!stage[0]) {
+    for (int b = 0; b < 2; ++b) {
+      ORIGIN_HIP(hipHostMalloc((void **)&stage[b], CH * sizeof(float), hipHostMallocDefault));
+      ORIGIN_HIP(hipEventCreateWithFlags(&ev[b], hipEventDisableTiming));
+    }
+  }
+  const size_t nch = (n + CH - 1) / CH;
+  auto issue = [&](size_t c) -> int {
+    const size_t o = c * CH, m = std::min(CH, n - o);
+    ORIGIN_HIP(hipMemcpyAsync(stage[c & 1], d_src + o, m * sizeof(float), hipMemcpyDeviceToHost,
+                              ctx->stream));
+    ORIGIN_HIP(hipEventRecord(ev[c & 1], ctx->stream));
+    return ORIGIN_OK;
+  };
+  int rc = issue(0);
+  if (rc) return rc;
+  for (size_t c = 0; c < nch; ++c) {
+    ORIGIN_HIP(hipEventSynchronize(ev[c & 1]));
+    if (c + 1 < nch && (rc = issue(c + 1))) return rc;
+    const size_t o = c * CH, m = std::min(CH, n - o);
+    const float *src = stage[c & 1];
+    double *dst = h_dst + o;
+    constexpr size_t PIECE = (size_t)1 << 18;  // 1 MiB of float32 per task
+    const int np = (int)((m + PIECE - 1) / PIECE);
+    origin_host_pool_run(np, [&](int p) {
+      const size_t a = (size_t)p * PIECE, b = std::min(m, a + PIECE);
+      for (size_t i = a; i < b; ++i) dst[i] = (double)src[i];
+    });
+  }
   return ORIGIN_OK;
 }
 

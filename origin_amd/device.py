@@ -169,6 +169,21 @@ class DeviceArray:
                    self.nbytes)
         return out
 
+    def to_host_f64(self, out=None):
+        """Host float64 copy of a float32 (or float64) device array: what the reference's
+        interface hands on.  float32 arrays are widened natively (pinned staging + host worker
+        pool, ``origin_d2h_f32_as_f64``) instead of ``to_host().astype(float64)``."""
+        if self.dtype == np.float64:
+            return self.to_host(out)
+        if self.dtype != np.float32:
+            return self.to_host().astype(np.float64)
+        if out is None:
+            out = np.empty(self.shape, dtype=np.float64)
+        assert out.flags.c_contiguous and out.size == self.size and out.dtype == np.float64
+        _capi.call("origin_d2h_f32_as_f64", self.ctx.handle, out.ctypes.data_as(C.c_void_p), self.p,
+                   self.size)
+        return out
+
     def window(self, y0, y1, x0, x1, z0=0, z1=None):
         """Host copy of the box [z0:z1, y0:y1, x0:x1] of a (Nz, Ny, Nx) array (one strided
         device->host copy: nothing but the box crosses PCIe)."""

@@ -53,7 +53,7 @@ def dct_residual(w_raw, order, var, approx, mask):
     dmask = ctx.to_device(_mask_u8(mask, shape))
     coef = kernels.dct_fit(ctx, raw, dvar, dmask, order, approx)
     cont = kernels.dct_continuum(ctx, coef, shape[0])
-    return cont.to_host().astype(np.float64)
+    return cont.to_host_f64()
 
 
 def O2test(arr):
@@ -80,7 +80,7 @@ def Compute_GreedyPCA(cube_in, test, thresO2, Noise_population, itermax):
     spx = np.arange(S, dtype=np.int32)
     mapO2, nstop = GreedyPCA(ctx).run(F, [spx], [np.asarray(test, dtype=np.float64)],
                                       [float(thresO2)], Noise_population, itermax)
-    return F.to_host().reshape(Nz, S).astype(np.float64), mapO2[0], nstop
+    return F.to_host_f64().reshape(Nz, S), mapO2[0], nstop
 
 
 def Compute_GreedyPCA_area(NbArea, cube_std, areamap, Noise_population, threshold_test,
@@ -98,7 +98,7 @@ def Compute_GreedyPCA_area(NbArea, cube_std, areamap, Noise_population, threshol
     mapO2 = np.zeros(Ny * Nx)
     for spx, m in zip(area_spx, maps):
         mapO2[spx] = m
-    return F.to_host().astype(np.float64), mapO2.reshape(Ny, Nx), nstop
+    return F.to_host_f64(), mapO2.reshape(Ny, Nx), nstop
 
 
 def Correlation_GLR_test(cube, fsf, weights, profiles, nthreads=1, pcut=None, pmeansub=True):
@@ -110,9 +110,9 @@ def Correlation_GLR_test(cube, fsf, weights, profiles, nthreads=1, pcut=None, pm
     try:
         d = ctx.to_device(cube, np.float32)
         out = plan.run(d, mask=None, want_maps=False)
-        correl = out["correl"].to_host().astype(np.float64)
+        correl = out["correl"].to_host_f64()
         profile = out["profile"].to_host()
-        correl_min = out["correl_min"].to_host().astype(np.float64)
+        correl_min = out["correl_min"].to_host_f64()
     finally:
         plan.close()
     return correl, profile, correl_min
@@ -130,7 +130,7 @@ def compute_local_max(correl, correl_min, mask, size=3):
     dm = dc if correl_min is correl else ctx.to_device(correl_min, np.float32)
     dmask = ctx.to_device(_mask_u8(mask, correl.shape))
     lmax, lmin = kernels.local_max(ctx, dc, dm, dmask, size)
-    return lmax.to_host().astype(np.float64), lmin.to_host().astype(np.float64)
+    return lmax.to_host_f64(), lmin.to_host_f64()
 
 
 class PurityTable(dict):

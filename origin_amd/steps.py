@@ -48,7 +48,8 @@ class LazyCube:
     @property
     def _data(self):
         if self._host is None:
-            self._host = self.dev.to_host().astype(self._dtype, copy=False)
+            self._host = (self.dev.to_host_f64() if self._dtype == np.float64
+                          else self.dev.to_host().astype(self._dtype, copy=False))
         return self._host
 
     data = _data
@@ -315,7 +316,8 @@ class _HipStepMixin:
         if isinstance(self, Step):
             self.store_cube(name, LazyCube(dev, dtype=dtype))
         else:
-            self.store_cube(name, dev.to_host().astype(dtype, copy=False))
+            self.store_cube(name, dev.to_host_f64() if dtype == np.float64
+                            else dev.to_host().astype(dtype, copy=False))
 
     def _get_cube(self, orig, ctx, name):
         dev = _cache(orig).get(name)

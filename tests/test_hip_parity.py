@@ -41,6 +41,22 @@ def assert_close_scaled(a, b, tol):
     assert err.max() <= tol, f"max scaled error {err.max():.3e} > {tol:.1e}"
 
 
+def test_to_host_f64_is_the_exact_widening(ctx):
+    """origin_d2h_f32_as_f64 (pinned staging, widened by the host pool while the next chunk is
+    in flight) against to_host().astype(float64): one element, a non-multiple of the task piece,
+    more than two 64-MiB chunks."""
+    rng = np.random.default_rng(1)
+    for n in (1, 1000, (1 << 18) + 17, 2 * (16 << 20) + 12345):
+        x = rng.standard_normal(n).astype(np.float32)
+        x[::7] *= 1e-30
+        x[::11] *= 1e30
+        d = ctx.to_device(x, np.float32)
+        got = d.to_host_f64()
+        assert got.dtype == np.float64 and np.array_equal(got, x.astype(np.float64))
+    d64 = ctx.to_device(np.arange(5.0), np.float64)
+    assert np.array_equal(d64.to_host_f64(), np.arange(5.0))
+
+
 # ------------------------------------------------------------------------------- DCT
 @pytest.mark.parametrize("approx", [False, True])
 def test_dct_residual_golden(hip, approx):
@@ -95,11 +111,13 @@ def test_dct_exact_on_dct_spectra(hip):
         assert np.max(np.abs(cont - raw)) <= 2e-5 * np.max(np.abs(raw))
 
 
-@pytest.mark.parametrize("shape", [(3681, 9, 70), (200, 24, 28), (37, 5, 13), (13, 3, 5),
-                                   (611, 64, 64), (96, 40, 60)])
-def test_dct_fit_sums_equals_the_two_calls(ctx, shape):
+@pytest.mark.parametrize("shape,order,approx", [
+    ((3681, 9, 70), 10, False), ((200, 24, 28), 10, False), ((37, 5, 13), 10, False),
+    ((13, 3, 5), 10, False), ((611, 64, 64), 10, False), ((96, 40, 60), 10, False),
+    ((300, 20, 33), 3, False), ((300, 20, 33), 12, False), ((300, 20, 33), 10, True)])
+def test_dct_fit_sums_equals_the_two_calls(ctx, shape, order, approx):
     """origin_dct_fit_sums (per-channel sums folded into the moments pass, rows brought in by
-    LDS-DMA) against origin_dct_fit + origin_dct_resid_sums and against NumPy: clean and masked
+    register batches) against origin_dct_fit + origin_dct_resid_sums and against NumPy: clean and masked
     rows, fully masked spaxels, S % 64 != 0, Nz below / not a multiple of
     the 16-row trip, fields small enough for several waves per spaxel group."""
     from origin_amd import kernels
@@ -117,9 +135,9 @@ def test_dct_fit_sums_equals_the_two_calls(ctx, shape):
     var[mask] = np.inf
     d_raw, d_var = ctx.to_device(raw, np.float32), ctx.to_device(var, np.float32)
     d_mask = ctx.to_device(mask.astype(np.uint8))
-    c1 = kernels.dct_fit(ctx, d_raw, d_var, d_mask, 10, False)
+    c1 = kernels.dct_fit(ctx, d_raw, d_var, d_mask, order, approx)
     s1, n1 = kernels.dct_resid_sums(ctx, d_raw, d_mask, c1)
-    c2, s2, n2 = kernels.dct_fit_sums(ctx, d_raw, d_var, d_mask, 10, False)
+    c2, s2, n2 = kernels.dct_fit_sums(ctx, d_raw, d_var, d_mask, order, approx)
     coef2 = c2.to_host()
     assert np.array_equal(c1.to_host(), coef2)
     scale = np.abs(raw).sum(axis=(1, 2), dtype=float) + 1.0
