@@ -66,6 +66,9 @@ int origin_d2h(origin_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
  * needs (cubes leaving through the function seam, steps.py store_cube), chunked through pinned
  * staging and widened by the host worker pool while the next chunk is in flight. */
 int origin_d2h_f32_as_f64(origin_ctx *ctx, double *h_dst, const float *d_src, size_t n);
+/* The other direction: host float64 -> device float32 (round to nearest even, as
+ * ndarray.astype(float32)), narrowed by the host worker pool into pinned staging. */
+int origin_h2d_f64_as_f32(origin_ctx *ctx, float *d_dst, const double *h_src, size_t n);
 int origin_d2d(origin_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
 /* strided 3-D box copy of `elem`-byte elements between (Nz, Ny, Nx)-shaped arrays; kind:
  * 0 = host->device, 1 = device->host, 2 = device->device.  Pitches in elements.  Used

@@ -34,6 +34,7 @@ SIGNATURES = {
     "origin_h2d": [vp, vp, vp, sz],
     "origin_d2h": [vp, vp, vp, sz],
     "origin_d2h_f32_as_f64": [vp, vp, vp, sz],
+    "origin_h2d_f64_as_f32": [vp, vp, vp, sz],
     "origin_d2d": [vp, vp, vp, sz],
     "origin_copy_box": [vp, i32, vp, i64, i64, vp, i64, i64, i32, i32, i32, i32],
     "origin_zmax_map": [vp, vp, vp, i32, i64, vp],

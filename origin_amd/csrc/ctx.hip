@@ -386,6 +386,41 @@ int origin_d2h_f32_as_f64(origin_ctx *ctx, double *h_dst, const float *d_src, si
   return ORIGIN_OK;
 }
 
+// Host float64 -> device float32 (the reference hands float64 cubes to the function seam): the
+// host pool narrows chunk i + 1 into a pinned staging buffer while chunk i is on its way.
+int origin_h2d_f64_as_f32(origin_ctx *ctx, float *d_dst, const double *h_src, size_t n) {
+  ORIGIN_USE(ctx);
+  if (n == 0) return ORIGIN_OK;
+  ORIGIN_CHECK_ARG(d_dst && h_src, "null pointer");
+  constexpr size_t CH = (size_t)16 << 20;  // elements per chunk
+  static thread_local float *stage[2] = {nullptr, nullptr};
+  static thread_local hipEvent_t ev[2];
+  if (!stage[0]) {
+    for (int b = 0; b < 2; ++b) {
+      ORIGIN_HIP(hipHostMalloc((void **)&stage[b], CH * sizeof(float), hipHostMallocDefault));
+      ORIGIN_HIP(hipEventCreateWithFlags(&ev[b], hipEventDisableTiming));
+      ORIGIN_HIP(hipEventRecord(ev[b], ctx->stream));
+    }
+  }
+  const size_t nch = (n + CH - 1) / CH;
+  for (size_t c = 0; c < nch; ++c) {
+    const size_t o = c * CH, m = std::min(CH, n - o);
+    float *dst = stage[c & 1];
+    const double *src = h_src + o;
+    ORIGIN_HIP(hipEventSynchronize(ev[c & 1]));  // the copy that last read this buffer is done
+    constexpr size_t PIECE = (size_t)1 << 18;
+    const int np = (int)((m + PIECE - 1) / PIECE);
+    origin_host_pool_run(np, [&](int p) {
+      const size_t a = (size_t)p * PIECE, b = std::min(m, a + PIECE);
+      for (size_t i = a; i < b; ++i) dst[i] = (float)src[i];
+    });
+    ORIGIN_HIP(hipMemcpyAsync(d_dst + o, dst, m * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    ORIGIN_HIP(hipEventRecord(ev[c & 1], ctx->stream));
+  }
+  ORIGIN_HIP(hipStreamSynchronize(ctx->stream));
+  return ORIGIN_OK;
+}
+
 int origin_d2d(origin_ctx *ctx, void *d_dst, const void *d_src, size_t bytes) {
   ORIGIN_USE(ctx);
   if (bytes == 0) return ORIGIN_OK;

@@ -94,6 +94,17 @@ class Context:
         return a
 
     def to_device(self, host, dtype=None):
+        if (dtype is not None and np.dtype(dtype) == np.float32 and isinstance(host, np.ndarray)
+                and host.dtype == np.float64 and host.flags.c_contiguous and host.size):
+            # float64 in, float32 on the device: narrowed natively on the host pool into pinned
+            # staging (origin_h2d_f64_as_f32) instead of a single-threaded astype + pageable copy
+            a = DeviceArray(self, host.shape, np.float32)
+            _capi.call("origin_h2d_f64_as_f32", self.handle, a.p, host.ctypes.data_as(C.c_void_p),
+                       host.size)
+            return a
+        if isinstance(host, np.ndarray) and host.dtype == np.bool_ and dtype is not None \
+                and np.dtype(dtype) == np.uint8:
+            host = host.view(np.uint8)   # (no copy: bool is one byte of 0 / 1)
         host = np.ascontiguousarray(host, dtype=dtype)
         a = DeviceArray(self, host.shape, host.dtype)
         a.upload(host)

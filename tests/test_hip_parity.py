@@ -55,6 +55,12 @@ def test_to_host_f64_is_the_exact_widening(ctx):
         assert got.dtype == np.float64 and np.array_equal(got, x.astype(np.float64))
     d64 = ctx.to_device(np.arange(5.0), np.float64)
     assert np.array_equal(d64.to_host_f64(), np.arange(5.0))
+    # and the way in: float64 host array -> float32 device array = astype(float32)
+    for n in (1, (1 << 18) + 17, 2 * (16 << 20) + 12345):
+        x = rng.standard_normal(n) * 10.0 ** rng.integers(-20, 20, n)
+        assert np.array_equal(ctx.to_device(x, np.float32).to_host(), x.astype(np.float32))
+    m = rng.random((3, 4, 5)) < 0.5
+    assert np.array_equal(ctx.to_device(m, np.uint8).to_host(), m.astype(np.uint8))
 
 
 # ------------------------------------------------------------------------------- DCT
