@@ -39,7 +39,11 @@
 //    exact maxima / minima (v_max3 / v_min3 on the unmodified T);
 //  * the power-of-two unscaling is applied to the final max / min, not to every 1/sqrt(den);
 //  * everything lives in VGPRs: hipcc splits the register file 128 / 128 as soon as an "a"
-//    operand appears in inline asm.
+//    operand appears in inline asm;
+//  * the window's f16 fragments are carried from tile to tile: consecutive 32-channel tiles share
+//    four of their six 16-channel blocks, so a tile loads and converts two blocks instead of
+//    six (kept fragments are multiplied by the ratio of the tile scales, a power of two within
+//    2^+-4, exact in f16; a larger step re-converts the window): 12.4 -> 11.5 ms.
 #include <algorithm>
 
 #include "common.h"
@@ -230,7 +234,6 @@ __device__ __forceinline__ void sm_tiles(
   unsigned maskv = 0xffffffe0u;
   asm volatile("" : "+v"(maskv));  // in a VGPR: a VOP3 instruction takes one SGPR, no literal
 
-  float xn[6][8];  // the next tile's window, in flight during the current tile's second half
   auto load_window = [&](int z0, float (&w)[6][8]) {
     const float *ub = fsf + (long)(z0 - 32) * S + s_base;  // uniform, one row on per load
     unsigned oin = off_in;
@@ -245,6 +248,23 @@ __device__ __forceinline__ void sm_tiles(
       ub += 8 * S;
     }
   };
+  u32x4v bh[6], bl[6];  // the window's fragments, carried from tile to tile
+  auto load_new_blocks = [&](int z0n, float (&xb)[2][8]) {  // channels z0n+32 .. z0n+63
+    const float *ub = fsf + (long)(z0n + 32) * S + s_base;
+    unsigned oin = off_in;
+    SM_PIN(oin);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        xb[ks][j] = ldf(ub, oin);
+        ub += S;
+      }
+      ub += 8 * S;
+    }
+  };
+  int bmx[6] = {0, 0, 0, 0, 0, 0};  // max |x| of each window block (float bits, wave-uniform)
+  int se_cur = 127;                 // exponent field of the scale the fragments are stored under
   for (int z0 = zc0; z0 < zc1; z0 += 32) {
     // ---- 1/sqrt(den)[slot][z0 .. z0+31] of the interior class -> this wave's LDS table (raw:
     // the power-of-two unscaling is applied to the final max / min).  rdi_s is in processing
@@ -263,72 +283,127 @@ __device__ __forceinline__ void sm_tiles(
       for (int q = 0; q < MF_MAX_K / 2; ++q)
         if ((lane >> 5) + 2 * q < K) reinterpret_cast<float *>(rd_wave)[lane + 64 * q] = rv[q];
     }
-    // ---- window X[z0-32 .. z0+63] in B-fragment order: lane (n, h) holds rows 16 ks + 8 h + j.
-    // It was requested while the previous tile's second half ran (xn); only the first tile of a
-    // chunk loads it here.
-    float x[6][8];
-    if (!SM_PREFETCH || z0 == zc0) load_window(z0, x);
-    else {
-#pragma unroll
-      for (int ks = 0; ks < 6; ++ks)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) x[ks][j] = xn[ks][j];
-    }
-    u32x4v bh[6], bl[6];
+    // ---- window X[z0-32 .. z0+63] in B-fragment order: lane (n, h) holds rows 16 ks + 8 h + j,
+    // as f16 hi / lo fragments (bh, bl) under the tile's power-of-two scale.  Consecutive tiles
+    // overlap by four of the six 16-channel blocks: those fragments are KEPT (moved two blocks
+    // down, multiplied by the ratio of the two scales when the window maximum crossed a power of
+    // two -- exact in f16 short of underflow) and only the two new blocks are loaded and
+    // converted.  The first tile of a chunk, and a tile whose scale differs from its
+    // predecessor's by more than 2^4 (or is not finite), loads and converts all six blocks:
+    // fragments kept across a large jump would have lost their low bits under the old scale.
     float inv = 1.0f;
-    if constexpr (TERMS == 3) {
-      // power-of-two scale of this tile: max |y| in [2^14, 2^15)
-      float m = 0.0f;
-#pragma unroll
-      for (int ks = 0; ks < 6; ++ks)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(x[ks][j]));
+    bool full = z0 == zc0;
+    auto scale_exp = [](float m, int &se, bool &finite) {
+      const int ex = (int)((__float_as_uint(m) >> 23) & 0xffu);
+      const bool tiny = ex < 40 || ex == 255;  // zero / denormal-small / non-finite: no scaling
+      finite = ex != 255;
+      se = tiny ? 127 : 268 - ex;  // scale = 2^(se - 127): max |y| in [2^14, 2^15)
+    };
+    auto wave_max = [&](float m) {
       if (!all_valid) m = sv ? m : 0.0f;  // lanes past the end of the field hold a copy
 #pragma unroll
       for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-      const int ex = (int)((__float_as_uint(m) >> 23) & 0xffu);
-      const bool tiny = ex < 40 || ex == 255;  // zero / denormal-small / non-finite: no scaling
-      const float scale = __uint_as_float((unsigned)(tiny ? 127 : 268 - ex) << 23);
-      // 2^-(e + MF_TAP_SCALE_LOG2): undoes both scalings, exactly
-      inv = __uint_as_float((unsigned)(tiny ? 127 - MF_TAP_SCALE_LOG2
-                                            : ex - 14 - MF_TAP_SCALE_LOG2) << 23);
-#pragma unroll
-      for (int ks = 0; ks < 6; ++ks) {
+      return __builtin_amdgcn_readfirstlane(__float_as_int(m));  // (>= 0: integer order = float order)
+    };
+    auto convert_block = [&](const float (&xb)[8], float scale, u32x4v &oh, u32x4v &ol) {
+      if constexpr (TERMS == 3) {
         f16x2v hh[4], ll[4];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float y = x[ks][j] * scale;
+          const float y = xb[j] * scale;
           const _Float16 yh = (_Float16)y;
           hh[j >> 1][j & 1] = yh;
           ll[j >> 1][j & 1] = (_Float16)(y - (float)yh);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          bh[ks][j] = __builtin_bit_cast(unsigned, hh[j]);
-          bl[ks][j] = __builtin_bit_cast(unsigned, ll[j]);
+          oh[j] = __builtin_bit_cast(unsigned, hh[j]);
+          ol[j] = __builtin_bit_cast(unsigned, ll[j]);
         }
-      }
-    } else {
-#pragma unroll
-      for (int ks = 0; ks < 6; ++ks)
+      } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
           bf2 t;  // round to nearest even (v_cvt_pk_bf16_f32)
-          t[0] = (__bf16)x[ks][2 * j];
-          t[1] = (__bf16)x[ks][2 * j + 1];
-          bh[ks][j] = __builtin_bit_cast(unsigned, t);
-          bl[ks][j] = 0u;
+          t[0] = (__bf16)xb[2 * j];
+          t[1] = (__bf16)xb[2 * j + 1];
+          oh[j] = __builtin_bit_cast(unsigned, t);
+          ol[j] = 0u;
         }
+      }
+    };
+    if (!full) {
+      // the two new blocks: window rows 64 .. 95 = channels z0+32 .. z0+63.  (Requesting them
+      // one tile ahead, in front of the previous tile's stores, was measured: 13.9 ms against
+      // 11.4 -- sixteen registers carried around the tile loop cost more than the wait.)
+      float xb[2][8];
+      load_new_blocks(z0, xb);
+      int se = 127;
+      if constexpr (TERMS == 3) {
+        float m4 = 0.0f, m5 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m4 = fmaxf(m4, fabsf(xb[0][j])), m5 = fmaxf(m5, fabsf(xb[1][j]));
+        bmx[0] = bmx[2], bmx[1] = bmx[3], bmx[2] = bmx[4], bmx[3] = bmx[5];
+        bmx[4] = wave_max(m4), bmx[5] = wave_max(m5);
+        int mm = max(max(max(bmx[0], bmx[1]), max(bmx[2], bmx[3])), max(bmx[4], bmx[5]));
+        bool finite;
+        scale_exp(__int_as_float(mm), se, finite);
+        const int d = se - se_cur;
+        if (!finite || d > 4 || d < -4) full = true;  // (uniform)
+        else if (d != 0) {
+          // kept fragments: times 2^d, eight halves of a fragment register quad at a time
+          // (element-wise updates of the unsigned vectors were mis-compiled by hipcc 7.2: element
+          // 1 came out as element 0 times the factor and was copied to elements 2 and 3)
+          typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+          const _Float16 f1 = __builtin_bit_cast(_Float16, (unsigned short)((15 + d) << 10));
+          const h8 fac = {f1, f1, f1, f1, f1, f1, f1, f1};
+#pragma unroll
+          for (int ks = 2; ks < 6; ++ks) {
+            bh[ks] = __builtin_bit_cast(u32x4v, __builtin_bit_cast(h8, bh[ks]) * fac);
+            bl[ks] = __builtin_bit_cast(u32x4v, __builtin_bit_cast(h8, bl[ks]) * fac);
+          }
+        }
+      }
+      if (!full) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) bh[ks] = bh[ks + 2], bl[ks] = bl[ks + 2];
+        const float scale = __uint_as_float((unsigned)se << 23);
+        convert_block(xb[0], scale, bh[4], bl[4]);
+        convert_block(xb[1], scale, bh[5], bl[5]);
+        se_cur = se;
+      }
+    }
+    if (full) {
+      float x[6][8];
+      load_window(z0, x);
+      int se = 127;
+      if constexpr (TERMS == 3) {
+        int mm = 0;
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+          float m = 0.0f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(x[ks][j]));
+          bmx[ks] = wave_max(m);
+          mm = max(mm, bmx[ks]);
+        }
+        bool finite;
+        scale_exp(__int_as_float(mm), se, finite);
+      }
+      const float scale = __uint_as_float((unsigned)se << 23);
+#pragma unroll
+      for (int ks = 0; ks < 6; ++ks) convert_block(x[ks], scale, bh[ks], bl[ks]);
+      se_cur = se;
+    }
+    if constexpr (TERMS == 3) {
+      // 2^-(e + MF_TAP_SCALE_LOG2): undoes both scalings, exactly  (scale = 2^(se_cur - 127))
+      inv = __uint_as_float((unsigned)(254 - se_cur - MF_TAP_SCALE_LOG2) << 23);
     }
 
     // ---- the two 16-channel halves
     sm_for<0, 2>([&](auto hc) {
       constexpr int HALF = decltype(hc)::value;
       const int zh = z0 + 16 * HALF;  // first output channel of this half
-      if constexpr (HALF == 1) {
-        if (SM_PREFETCH && z0 + 32 < zc1) load_window(z0 + 32, xn);  // lands while this half computes
-      }
       if (zh >= zc1) return;  // (uniform)
       // mask bytes of this half's outputs (steps.py:781,788): requested now, used after the pairs.
       // Output i of the lane is channel zh + (i&3) + 8 (i>>2) + 4 h: uniform row pointers

@@ -493,6 +493,37 @@ def test_glr_f16_split_survives_huge_dynamic_range(ctx):
     plan.close()
 
 
+def test_glr_kept_fragments_follow_a_moving_scale(ctx):
+    """The spectral kernel keeps four of a window's six 16-channel blocks as f16 fragments from
+    tile to tile and multiplies them by 2^d when the tile scale moves by |d| <= 4 (larger steps
+    re-convert the whole window).  Amplitude ramps of x1.3 per 16 channels (d = +-1 every other
+    tile), steps of x8 and x1/16 (d = 3, -4) and x64 (re-conversion), long enough for several
+    tiles per z chunk; same error bound as above."""
+    from scipy.ndimage import maximum_filter1d
+    from origin_amd import kernels
+    rng = np.random.default_rng(78)
+    Ny, Nx = 26, 30
+    seg = [1.3 ** (np.arange(96) // 16), 1.3 ** 5 * 1.3 ** (-(np.arange(160) // 16)),
+           np.full(64, 8.0), np.full(64, 0.5), np.full(96, 32.0), np.full(64, 1.0),
+           1.3 ** (np.arange(352) // 16 % 7)]
+    amp = np.concatenate(seg)
+    Nz = len(amp)
+    cube = (rng.standard_normal((Nz, Ny, Nx)) * amp[:, None, None]).astype(np.float32)
+    psf = synth.moffat_psf(Nz, 25).astype(np.float64)
+    prof = synth.dico_fwhm(20)
+    ref = cpu_ref.Correlation_GLR_test(cube.astype(np.float64), psf, None, prof, nthreads=1,
+                                       pcut=1e-8, pmeansub=True)
+    plan = kernels.GLRPlan(ctx, cube.shape, psf, None, prof, 1e-8, True, precision="f16x2")
+    out = plan.run(ctx.to_device(cube), mask=None, want_maps=False)
+    got, gmin = out["correl"].to_host(), out["correl_min"].to_host()
+    local = maximum_filter1d(np.abs(ref[0]).max(axis=(1, 2)), size=193, mode="nearest")
+    tol = 3e-6 * local[:, None, None]
+    assert np.all(np.abs(got - ref[0]) <= tol)
+    assert np.all(np.abs(gmin - ref[2]) <= tol)
+    assert np.mean(out["profile"].to_host() != ref[1]) <= 1e-4
+    plan.close()
+
+
 def test_glr_wide_profiles_fallback(hip):
     """pcut=None with the full 201-tap dictionary takes the generic (wide-window) kernel."""
     c = gc.g5_inputs()["a"]
