@@ -30,7 +30,8 @@
 //
 // TERMS = 1: bf16 operands, one MFMA per k-step (BASELINE config 4's bf16 GLR), no scaling.
 //
-// Eligible shapes: P in {9, 17, 25} (any field size: 16-byte accesses when Nx % 4 == 0, element
+// Eligible shapes: P in {9, 13, 17, 21, 25} (P - 1 a multiple of four: the input tile is whole
+// float4s; any field size: 16-byte accesses when Nx % 4 == 0, element
 // accesses otherwise), one field or a mosaic of weighted fields (WEIGHTED); other PSF sizes stay
 // on spatial4x4_kernel / spatial_kernel.
 #include <algorithm>
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(512, 1) void spatial2_kernel(const float *__restric
 
 // 1 if this shape can run on spatial2_kernel
 int origin_spatial_mfma_ok(int Ny, int Nx, int P) {
-  return (P == 9 || P == 17 || P == 25) && Nx >= 1 && Ny >= 1;
+  return (P == 9 || P == 13 || P == 17 || P == 21 || P == 25) && Nx >= 1 && Ny >= 1;
 }
 
 template <int P, int TERMS, bool VEC, bool WEIGHTED>
@@ -394,7 +395,8 @@ static int s2_launch(origin_ctx *ctx, const float *A, const float *W, const floa
 int origin_spatial_mfma_launch(origin_ctx *ctx, int terms, const float *A, const float *W,
                                const float *taps, int Nz, int Ny, int Nx, int P, int accf,
                                float *out) {
-  const bool vec = (Nx & 3) == 0;
+  // (tile loads start at x0 - P/2: float4-aligned only when P/2 is a multiple of four)
+  const bool vec = (Nx & 3) == 0 && ((P / 2) & 3) == 0;
   if (!W && accf) {
     origin_set_error("spatial MFMA kernel: accumulation needs a weight map");
     return ORIGIN_E_ARG;
@@ -412,7 +414,9 @@ int origin_spatial_mfma_launch(origin_ctx *ctx, int terms, const float *A, const
     S2_GO(PP, 1, false)
   switch (P) {
     S2_CASE(9);
+    S2_CASE(13);
     S2_CASE(17);
+    S2_CASE(21);
     S2_CASE(25);
   }
 #undef S2_CASE
