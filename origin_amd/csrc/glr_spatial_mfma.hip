@@ -30,8 +30,8 @@
 //
 // TERMS = 1: bf16 operands, one MFMA per k-step (BASELINE config 4's bf16 GLR), no scaling.
 //
-// Eligible shapes: P in {9, 13, 17, 21, 25} (P - 1 a multiple of four: the input tile is whole
-// float4s; any field size: 16-byte accesses when Nx % 4 == 0, element
+// Eligible shapes: odd P from 5 to 25 (float4 tile loads when P/2 is a multiple of four; any
+// field size: 16-byte accesses when Nx % 4 == 0, element
 // accesses otherwise), one field or a mosaic of weighted fields (WEIGHTED); other PSF sizes stay
 // on spatial4x4_kernel / spatial_kernel.
 #include <algorithm>
@@ -56,7 +56,9 @@ constexpr int S2_ENTRY = 80;       // bytes of one (row, copy) table entry: 40 t
 template <int P>
 struct S2Geom {
   static constexpr int H = P - 1;                       // halo
-  static constexpr int IW = S2_R + H, IH = S2_R + H;    // input tile
+  // input tile; its width rounded up to whole float4s (P - 1 not a multiple of four: up to two
+  // extra columns of real data that only ever meet zero taps)
+  static constexpr int IW = (S2_R + H + 3) / 4 * 4, IH = S2_R + H;
   static constexpr int WROWS = 4 + H;                   // window rows of a patch
   static constexpr int WCOLS = 8 + H;                   // window columns (<= 32)
   static constexpr int KROW = (WCOLS + 15) / 16;        // k-steps per window row
@@ -354,7 +356,7 @@ __global__ __launch_bounds__(512, 1) void spatial2_kernel(const float *__restric
 
 // 1 if this shape can run on spatial2_kernel
 int origin_spatial_mfma_ok(int Ny, int Nx, int P) {
-  return (P == 9 || P == 13 || P == 17 || P == 21 || P == 25) && Nx >= 1 && Ny >= 1;
+  return P >= 5 && P <= 25 && (P & 1) && Nx >= 1 && Ny >= 1;
 }
 
 template <int P, int TERMS, bool VEC, bool WEIGHTED>
@@ -412,13 +414,24 @@ int origin_spatial_mfma_launch(origin_ctx *ctx, int terms, const float *A, const
     }                                      \
     if (terms == 3) S2_GO(PP, 3, false);   \
     S2_GO(PP, 1, false)
+#define S2_CASE_E(PP) /* P/2 not a multiple of four: element-wise tile loads only */ \
+  case PP:                                                                          \
+    if (terms == 3) S2_GO(PP, 3, false);                                            \
+    S2_GO(PP, 1, false)
   switch (P) {
+    S2_CASE_E(5);
+    S2_CASE_E(7);
     S2_CASE(9);
-    S2_CASE(13);
+    S2_CASE_E(11);
+    S2_CASE_E(13);
+    S2_CASE_E(15);
     S2_CASE(17);
-    S2_CASE(21);
+    S2_CASE_E(19);
+    S2_CASE_E(21);
+    S2_CASE_E(23);
     S2_CASE(25);
   }
+#undef S2_CASE_E
 #undef S2_CASE
 #undef S2_GO
   origin_set_error("spatial MFMA kernel: PSF size %d not supported", P);

@@ -173,7 +173,7 @@ class GLRPlan:
         # mirrors origin_spatial_mfma_ok (csrc/glr_spatial_mfma.hip): which spatial kernel runs
         # (weighted mosaics included: per-field accumulation on the matrix cores; their spectral
         # stage convolves the norm cube next to the data and stays in fp32)
-        self.spatial_on_matrix_cores = self.precision != "f32" and self.P in (9, 13, 17, 21, 25)
+        self.spatial_on_matrix_cores = self.precision != "f32" and 5 <= self.P <= 25
         self.spectral_on_matrix_cores = self.precision != "f32" and w is None
 
     def close(self):

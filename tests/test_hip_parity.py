@@ -318,9 +318,11 @@ def test_glr_golden_both_arithmetics(ctx, name, precision):
 
 @pytest.mark.parametrize("shape,P", [((70, 67, 132), 25), ((40, 30, 20), 25), ((50, 26, 140), 9),
                                       ((33, 130, 260), 17), ((45, 70, 131), 25),
-                                      ((37, 65, 66), 9), ((41, 66, 70), 13), ((36, 70, 133), 21)])
+                                      ((37, 65, 66), 9), ((41, 66, 70), 13), ((36, 70, 133), 21),
+                                      ((30, 66, 69), 5), ((32, 40, 72), 7), ((31, 67, 64), 11),
+                                      ((33, 64, 130), 15), ((30, 70, 66), 19), ((34, 66, 71), 23)])
 def test_glr_matrix_core_spatial_stage(ctx, shape, P):
-    """Shapes that take the matrix-core spatial kernel (P in 9/13/17/21/25): several 64x64 regions,
+    """Shapes that take the matrix-core spatial kernel (odd P from 5 to 25): several 64x64 regions,
     partial regions, fields narrower than a region, row lengths that are not multiples of four
     (element-wise tile loads and stores), against the float64 oracle and against the fp32
     kernels."""
