@@ -53,6 +53,7 @@ struct origin_glr_plan {
   int NzP;
   uint4 *d_atab;   // matrix-core spectral stage: shifted hi/lo f16 tap copies (glr_tables.h)
   uint4 *d_atab_bf16;  // the same with bf16 taps (precision 2)
+  uint4 *d_atab2;      // the squared taps in the same layout (plans with an explicit norm cube)
   int *d_pwide;    // [K] processing order, narrow first: original index | (half width > 16) << 8
   int n_narrow;    // number of narrow profiles (the first n_narrow slots)
   float *d_rdi_s;  // interior-class 1/sqrt(den) in processing order [slot][NzP]
@@ -854,7 +855,8 @@ int origin_glr_plan_destroy(origin_glr_plan *plan) {
                   (void *)plan->d_taps2, (void *)plan->d_tap_off, (void *)plan->d_rden,
                   (void *)plan->d_htaps, (void *)plan->d_htap_off, (void *)plan->d_rows,
                   (void *)plan->d_border, (void *)plan->d_atab, (void *)plan->d_atab_bf16,
-                  (void *)plan->d_pwide, (void *)plan->d_rdi_s, (void *)plan->d_normc})
+                  (void *)plan->d_pwide, (void *)plan->d_rdi_s, (void *)plan->d_normc,
+                  (void *)plan->d_atab2})
     if (p) (void)hipFree(p);
   delete plan->h_order;
   delete plan;
@@ -971,13 +973,14 @@ int origin_glr_plan_create(origin_ctx *ctx, int Nz, int Ny, int Nx, int nfields,
   // by 0..7 elements (glr_tables.h), profiles in processing order (narrow ones -- half width
   // <= 16: window blocks 1..4 -- first, so that the kernel's profile pairs are narrow/narrow,
   // at most one narrow/wide, wide/wide); f16 hi + lo (times 2^MF_TAP_SCALE_LOG2) and bf16
-  if (lwmax <= 32 && K <= MF_MAX_K && pl->mode == 0) {
+  if (lwmax <= 32 && K <= MF_MAX_K && (pl->mode == 0 || h_weights)) {
     std::vector<int> order(K), pinfo(K, 0);
     for (int kk = 0; kk < K; ++kk) order[kk] = kk;
     auto lw_of = [&](int kk) { return (off[kk + 1] - off[kk] - 1) / 2; };
     std::stable_sort(order.begin(), order.end(),
                      [&](int a, int b) { return (lw_of(a) > 16) < (lw_of(b) > 16); });
     std::vector<_Float16> at((size_t)K * MF_PROF_BYTES / 2, (_Float16)0.0f);
+    std::vector<_Float16> at2(pl->mode == 1 ? at.size() : 0, (_Float16)0.0f);
     std::vector<unsigned short> ab((size_t)K * MF_PROF_BYTES / 2, 0);
     const float tscale = (float)(1 << MF_TAP_SCALE_LOG2);
     auto to_bf16 = [](float v) -> unsigned short {  // round to nearest even
@@ -1003,10 +1006,17 @@ int origin_glr_plan_create(origin_ctx *ctx, int Nz, int Ny, int Nx, int nfields,
             at[base] = gh;
             at[base + 8 * (MF_COPY_BYTES / 2)] = gl;
             ab[base] = to_bf16(t);
+            if (!at2.empty()) {  // squared taps (float32 squares, as d_taps2) for the denominator
+              const float g2 = (t * t) * tscale;
+              const _Float16 g2h = (_Float16)g2;
+              at2[base] = g2h;
+              at2[base + 8 * (MF_COPY_BYTES / 2)] = (_Float16)(g2 - (float)g2h);
+            }
           }
     }
     TRY(upload(ctx, at, (_Float16 **)&pl->d_atab, &pl->bytes));
     TRY(upload(ctx, ab, (unsigned short **)&pl->d_atab_bf16, &pl->bytes));
+    if (!at2.empty()) TRY(upload(ctx, at2, (_Float16 **)&pl->d_atab2, &pl->bytes));
     TRY(upload(ctx, pinfo, &pl->d_pwide, &pl->bytes));
     pl->n_narrow = 0;
     for (int slot = 0; slot < K; ++slot) pl->n_narrow += (pinfo[slot] >> 8) == 0;
@@ -1084,9 +1094,11 @@ int origin_glr_plan_create(origin_ctx *ctx, int Nz, int Ny, int Nx, int nfields,
 int origin_glr_plan_set_precision(origin_glr_plan *plan, int precision) {
   ORIGIN_CHECK_ARG(plan && precision >= 0 && precision <= 2, "precision must be 0, 1 or 2");
   // the matrix-core stages need the plan's tap tables (weights=None, half widths <= 32)
-  plan->precision = (plan->d_atab || (plan->d_w && origin_spatial_mfma_ok(plan->Ny, plan->Nx, plan->P)))
-                        ? precision
-                        : 0;
+  // (mode 1 without weight maps -- a field smaller than the PSF -- stays on the fp32 kernels)
+  const bool eligible = plan->mode == 0 ? plan->d_atab != nullptr
+                                        : plan->d_w && (plan->d_atab2 ||
+                                                        origin_spatial_mfma_ok(plan->Ny, plan->Nx, plan->P));
+  plan->precision = eligible ? precision : 0;
   return ORIGIN_OK;
 }
 
@@ -1128,12 +1140,15 @@ int origin_glr_run(origin_ctx *ctx, origin_glr_plan *pl, const float *d_cube,
   float *part = fsf + cube + (size_t)MF_PAD_BACK * S;
   // mode 1: norm_fsf depends on the PSFs and the weight maps only -- the first run computes it
   // into a cube the plan keeps
+  // (padded like cube_fsf: MF_PAD_FRONT zero channels in front, MF_PAD_BACK behind)
   if (pl->mode == 1 && !pl->d_normc) {
-    ORIGIN_HIP(hipMalloc((void **)&pl->d_normc, cube * sizeof(float)));
-    pl->bytes += cube * sizeof(float);
+    const size_t padded = cube + (size_t)(MF_PAD_FRONT + MF_PAD_BACK) * S;
+    ORIGIN_HIP(hipMalloc((void **)&pl->d_normc, padded * sizeof(float)));
+    ORIGIN_HIP(hipMemsetAsync(pl->d_normc, 0, padded * sizeof(float), ctx->stream));
+    pl->bytes += padded * sizeof(float);
     pl->normc_ready = 0;
   }
-  float *norm = pl->mode == 1 ? pl->d_normc : nullptr;
+  float *norm = pl->mode == 1 ? pl->d_normc + (size_t)MF_PAD_FRONT * S : nullptr;
   ORIGIN_HIP(hipMemsetAsync(d_work, 0, (size_t)MF_PAD_FRONT * S * sizeof(float), ctx->stream));
   ORIGIN_HIP(hipMemsetAsync(fsf + cube, 0, (size_t)MF_PAD_BACK * S * sizeof(float), ctx->stream));
 
@@ -1216,8 +1231,16 @@ int origin_glr_run(origin_ctx *ctx, origin_glr_plan *pl, const float *d_cube,
   {
   ProfScope ps(ctx, K_GLR_SPECTRAL);
   const bool mfma = !gen && pl->precision >= 1 && pl->d_atab && pl->d_rdi;
+  // explicit norm cube: second Toeplitz product on the matrix cores (f16 split only: precision 1)
+  const bool mfma_norm = gen && pl->precision == 1 && pl->d_atab && pl->d_atab2 &&
+                         K <= origin_spectral_norm_mfma_max_k();
   const bool packed = !mfma && !gen && (S & 1) == 0 && pl->lwt;
-  if (mfma) {
+  if (mfma_norm) {
+    int rc = origin_spectral_norm_mfma_launch(ctx, fsf, norm, pl->d_atab, pl->d_atab2, pl->d_pwide, K,
+                                              Nz, Ny, Nx, d_mask, d_correl, d_profile, d_correl_min,
+                                              part, want_maps, &nzc, &pmax, &pmin);
+    if (rc) return rc;
+  } else if (mfma) {
     int rc = origin_spectral_mfma_launch(
         ctx, pl->precision == 2 ? 1 : 3, fsf, pl->d_rden, pl->d_rdi_s, pl->NzP,
         pl->precision == 2 ? pl->d_atab_bf16 : pl->d_atab, pl->d_pwide, K, pl->n_narrow, Nz, Ny, Nx,

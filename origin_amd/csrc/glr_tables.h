@@ -26,3 +26,12 @@ int origin_spectral_mfma_launch(origin_ctx *ctx, int terms, const float *fsf, co
                                 int nN, int Nz, int Ny, int Nx, int P, const uint8_t *mask, float *correl,
                                 uint8_t *profile, float *correl_min, float *part, bool want_maps,
                                 int *nzc_out, float **pmax_out, float **pmin_out);
+
+// glr_spectral_norm_mfma.hip: the same stage for plans with an explicit norm cube (weighted fields)
+int origin_spectral_norm_mfma_max_k();
+int origin_spectral_norm_mfma_launch(origin_ctx *ctx, const float *fsf, const float *norm,
+                                     const uint4 *atab, const uint4 *atab2, const int *pinfo, int K,
+                                     int Nz, int Ny, int Nx, const uint8_t *mask, float *correl,
+                                     uint8_t *profile, float *correl_min, float *part,
+                                     bool want_maps, int *nzc_out, float **pmax_out,
+                                     float **pmin_out);

@@ -174,7 +174,11 @@ class GLRPlan:
         # (weighted mosaics included: per-field accumulation on the matrix cores; their spectral
         # stage convolves the norm cube next to the data and stays in fp32)
         self.spatial_on_matrix_cores = self.precision != "f32" and 5 <= self.P <= 25
-        self.spectral_on_matrix_cores = self.precision != "f32" and w is None
+        # (a weighted plan's spectral stage -- second Toeplitz product for the denominator,
+        # csrc/glr_spectral_norm_mfma.hip -- exists for the f16 split only)
+        self.spectral_on_matrix_cores = self.precision != "f32" and (
+            w is None or (self.precision == "f16x2" and len(self.tap_lengths) <= 26
+                          and max(self.tap_lengths) <= 65))
 
     def close(self):
         if self._h is not None and self._h.value:

@@ -353,14 +353,16 @@ def test_glr_matrix_core_spatial_stage(ctx, shape, P):
     assert np.max(np.abs(got["f16x2"] - got["f32"])) <= 1e-4
 
 
-@pytest.mark.parametrize("shape,P,nf", [((60, 70, 132), 9, 2), ((40, 66, 67), 25, 3),
-                                         ((48, 30, 140), 17, 2)])
-def test_glr_weighted_fields_on_matrix_cores(ctx, shape, P, nf):
+@pytest.mark.parametrize("shape,P,nf,nprof", [((60, 70, 132), 9, 2, 3), ((40, 66, 67), 25, 3, 3),
+                                               ((48, 30, 140), 17, 2, 3), ((150, 34, 45), 9, 2, 20),
+                                               ((130, 33, 40), 7, 2, 15)])
+def test_glr_weighted_fields_on_matrix_cores(ctx, shape, P, nf, nprof):
     """A mosaic: several fields, each with its PSF and weight map (origin.py:600-609,
     lib_origin.py:1029-1031, :1134-1147).  The spatial stage runs per field on the matrix cores
     (weight map multiplied in while the tile is staged, fields accumulated), the norm cube is a
     constant of the plan (computed by the first run), the spectral stage convolves it next to
-    the data in fp32.  Against the float64 oracle, against the fp32 plan, and a second run of
+    the data -- a second Toeplitz product on the matrix cores, two launches over the halves of
+    the dictionary when it has more than 13 profiles.  Against the float64 oracle, against the fp32 plan, and a second run of
     the same plan (cached norm cube) against the first."""
     from origin_amd import kernels
     rng = np.random.default_rng(P + shape[2] + nf)
@@ -379,7 +381,9 @@ def test_glr_weighted_fields_on_matrix_cores(ctx, shape, P, nf):
         psfs.append(p)
         ws.append((raww[f] / tot).astype(np.float32).astype(np.float64))
     ws[0][:5, :7] = 0.0                     # a corner one field does not cover
-    prof = synth.dico_fwhm(3)
+    if nf == 2:
+        ws[1][-4:, -6:] = 0.0               # and a corner NO field covers: den = 0 -> T = 0
+    prof = synth.dico_fwhm(nprof)           # (more than 13 profiles: two launches, merged)
     ref = cpu_ref.Correlation_GLR_test(cube.astype(np.float64), psfs, ws, prof, nthreads=1,
                                        pcut=1e-8, pmeansub=True)
     d = ctx.to_device(cube)
@@ -388,7 +392,7 @@ def test_glr_weighted_fields_on_matrix_cores(ctx, shape, P, nf):
         plan = kernels.GLRPlan(ctx, shape, psfs, ws, prof, 1e-8, True, precision=prec)
         assert plan.precision == prec
         assert plan.spatial_on_matrix_cores == (prec == "f16x2")
-        assert not plan.spectral_on_matrix_cores
+        assert plan.spectral_on_matrix_cores == (prec == "f16x2")
         for rep in range(2):
             out = plan.run(d, mask=None, want_maps=True)
             c = out["correl"].to_host()
