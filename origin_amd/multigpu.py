@@ -354,7 +354,10 @@ def exchange_halo_host(comm, tiling, rank, tile):
 class TiledGLR:
     """GLR of one tile of a tiled field: halo exchange + plan on the extended tile + crop."""
 
-    def __init__(self, ctx, comm, tiling, rank, Nz, PSF, profiles, pcut=1e-8, pmeansub=True):
+    def __init__(self, ctx, comm, tiling, rank, Nz, PSF, profiles, pcut=1e-8, pmeansub=True,
+                 weights=None):
+        """``weights``: None or the mosaic's weight maps (one (Ny, Nx) array per field of the WHOLE
+        field, origin.py:600-609): every rank crops them to its halo-extended tile, no exchange."""
         self.ctx, self.comm, self.tiling, self.rank, self.Nz = ctx, comm, tiling, rank, Nz
         # a kept spaxel must see real neighbour data over the whole PSF footprint, and a strip
         # must come from ONE neighbour: halo >= P//2 and every tile at least a halo wide
@@ -369,7 +372,11 @@ class TiledGLR:
                                  f"the halo {tiling.halo}")
         (y0, y1, x0, x1), self.halos = tiling.extended(rank)
         self.eshape = (Nz, y1 - y0, x1 - x0)
-        self.plan = kernels.GLRPlan(ctx, self.eshape, PSF, None, profiles, pcut, pmeansub)
+        wext = None
+        if weights is not None:
+            wext = [np.ascontiguousarray(np.asarray(w, dtype=np.float64)[y0:y1, x0:x1])
+                    for w in weights]
+        self.plan = kernels.GLRPlan(ctx, self.eshape, PSF, wext, profiles, pcut, pmeansub)
         t = tiling.tile(rank)
         self.shape = (Nz, t.y1 - t.y0, t.x1 - t.x0)
         self.ext = ctx.empty(self.eshape, np.float32)

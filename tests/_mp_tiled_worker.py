@@ -31,8 +31,18 @@ def field():
     return f, raw, var, mask
 
 
+def mosaic(f):
+    """Two fields over the test field: PSFs and weight maps (TILED_WEIGHTS=1)."""
+    Nz, Ny, Nx = 96, 40, 60
+    x = np.linspace(0, 1, Nx)[None, :] * np.ones((Ny, 1))
+    w0 = (0.15 + 0.7 * x).astype(np.float32).astype(np.float64)
+    psfs = [f.PSF.astype(float), synth.moffat_psf(Nz, f.PSF.shape[1], fwhm0=3.0, fwhm1=3.4).astype(float)]
+    return psfs, [w0, 1.0 - w0]
+
+
 def main():
     mode, out = sys.argv[1], sys.argv[2]
+    weighted = os.environ.get("TILED_WEIGHTS") == "1"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     comm = multigpu.init_comm(rank, world, rank if mode == "rccl" else 0,
                               backend=None if mode == "rccl" else "gloo")
@@ -64,7 +74,12 @@ def main():
         (_, _, _, _), (top, bot, left, right) = tiling.extended(rank)
         emask = np.zeros(ext.shape, bool)
         emask[:, top:top + tmask.shape[1], left:left + tmask.shape[2]] = tmask
-        g = cpu_ref.compute_TGLR(ext, f.PSF.astype(float), None, f.profiles, emask, pcut=1e-8)
+        psf_, wts_ = (f.PSF.astype(float), None)
+        if weighted:
+            psf_, wfull = mosaic(f)
+            (ey0, ey1, ex0, ex1), _ = tiling.extended(rank)
+            wts_ = [w_[ey0:ey1, ex0:ex1] for w_ in wfull]
+        g = cpu_ref.compute_TGLR(ext, psf_, wts_, f.profiles, emask, pcut=1e-8)
         crop = (slice(None), slice(top, top + tmask.shape[1]), slice(left, left + tmask.shape[2]))
         res = dict(cube_std=data, cube_faint=faint, correl=g["cube_correl"][crop],
                    correl_min=g["cube_correl_min"][crop], mapO2=mapO2,
@@ -87,8 +102,11 @@ def main():
         thr = pipeline.pca_threshold(pre["o2"].to_host(), lmap, len(labels), 0.01, spx=spx)
         faint, mapO2, nstop, _ = pipeline.greedy_pca(ctx, pre["cube_std"], lmap, len(labels),
                                                      thr["thresO2"], thr["testO2"], spx=spx)
-        glr = multigpu.TiledGLR(ctx, comm, tiling, rank, Nz, f.PSF.astype(float), f.profiles,
-                                pcut=1e-8)
+        psf_, wts_ = (f.PSF.astype(float), None)
+        if weighted:
+            psf_, wts_ = mosaic(f)
+        glr = multigpu.TiledGLR(ctx, comm, tiling, rank, Nz, psf_, f.profiles, pcut=1e-8,
+                                weights=wts_)
         shape = d_raw.shape
         correl = ctx.empty(shape, np.float32)
         cmin = ctx.empty(shape, np.float32)

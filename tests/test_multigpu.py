@@ -24,12 +24,13 @@ def free_port():
     return p
 
 
-def run_ranks(mode, world, out):
+def run_ranks(mode, world, out, weighted=False):
     port = free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0",
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2",
+                   TILED_WEIGHTS="1" if weighted else "0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests",
                                                                     "_mp_tiled_worker.py"),
                                        mode, out], env=env, stdout=subprocess.PIPE,
@@ -87,6 +88,42 @@ def test_tiled_oracle_equals_untiled_oracle(tmp_path, world):
         assert np.max(np.abs(got - ref[rk])) <= 1e-9 * max(1.0, np.max(np.abs(ref[rk]))), key
     assert np.array_equal(stitch(tiles, "mapO2", shape[1:]), ref["mapO2"])
     assert np.max(np.abs(stitch(tiles, "maxmap", shape[1:]) - ref["maxmap"])) <= 1e-9
+
+
+def test_tiled_weighted_mosaic_oracle_equals_untiled_oracle(tmp_path):
+    """A mosaic of two weighted fields over two tiles: every rank crops the weight maps to its
+    halo-extended tile (no exchange); the tiled oracle equals the untiled one."""
+    from _mp_tiled_worker import field, mosaic
+    from oracle import cpu_ref
+    f, raw, var, mask = field()
+    psfs, wts = mosaic(f)
+    tiles = run_ranks("cpu", 2, str(tmp_path / "cpuw"), weighted=True)
+    ref = cpu_ref.run_chain(raw.astype(float), var.astype(float), mask, psfs, wts, f.profiles,
+                            f.areamap, f.nbAreas)
+    shape = raw.shape
+    for key, rk in (("correl", "cube_correl"), ("correl_min", "cube_correl_min")):
+        got = stitch(tiles, key, shape)
+        assert np.max(np.abs(got - ref[rk])) <= 1e-9 * max(1.0, np.max(np.abs(ref[rk]))), key
+    assert np.max(np.abs(stitch(tiles, "maxmap", shape[1:]) - ref["maxmap"])) <= 1e-9
+
+
+@pytest.mark.gpu
+def test_tiled_weighted_mosaic_hip(tmp_path):
+    """The same through the HIP path (both GLR stages of the weighted plan on the matrix cores),
+    two tiles against one and against the oracle."""
+    from _mp_tiled_worker import field, mosaic
+    from oracle import cpu_ref
+    f, raw, var, mask = field()
+    psfs, wts = mosaic(f)
+    tiles = run_ranks("gpu", 2, str(tmp_path / "gpuw"), weighted=True)
+    single = run_ranks("gpu", 1, str(tmp_path / "onew"), weighted=True)
+    shape = raw.shape
+    for key in ("correl", "correl_min"):
+        assert np.max(np.abs(stitch(tiles, key, shape) - stitch(single, key, shape))) <= 1e-4, key
+    ref = cpu_ref.run_chain(raw.astype(float), var.astype(float), mask, psfs, wts, f.profiles,
+                            f.areamap, f.nbAreas)
+    assert np.max(np.abs(stitch(tiles, "correl", shape) - ref["cube_correl"])) <= 2e-4
+    assert np.max(np.abs(stitch(tiles, "maxmap", shape[1:]) - ref["maxmap"])) <= 2e-4
 
 
 @pytest.mark.gpu
