@@ -287,12 +287,17 @@ int origin_glr_plan_create(origin_ctx *ctx, int Nz, int Ny, int Nx, int nfields,
                            origin_glr_plan **out);
 int origin_glr_plan_destroy(origin_glr_plan *plan);
 /* bytes of device memory the plan holds */
-/* Arithmetic of the GLR stages when the plan is eligible for the matrix cores (weights == NULL,
- * one field, profile half widths <= 32, K <= 26): 1 (default) = two-term f16 split of data and
- * taps, three MFMAs per product, fp32 accumulation (~3e-7 of sum |p x| from float64: fp32 class);
- * 2 = bf16 operands, one MFMA per product in the spectral stage (BASELINE config 4 "bf16 GLR";
- * |dT| ~1e-2); 0 = fp32 FMA chain (~1e-7).  Plans that are not eligible always run 0; get
- * returns what will run. */
+/* Arithmetic of the GLR stages when the plan is eligible for the matrix cores: 1 (default) =
+ * two-term f16 split of data and taps, three MFMAs per product, fp32 accumulation (~3e-7 of
+ * sum |p x| from float64: fp32 class); 2 = bf16 operands, one MFMA per product (BASELINE config 4
+ * "bf16 GLR"; |dT| ~1e-2); 0 = fp32 FMA chain (~1e-7).  Eligible: the spatial stage for odd PSF
+ * sizes 5..25 (one field, or a mosaic of weighted fields: per-field accumulation); the spectral
+ * stage for profile half widths <= 32 and K <= 26 -- through the border-class table without
+ * weight maps, through a second Toeplitz product on the plan's norm cube with them (precision 1
+ * only; that cube, [Nz + 96][Ny][Nx] float32, is allocated and filled by the plan's first run).
+ * A stage that is not eligible runs the fp32 kernels; plans where neither stage is (a field
+ * smaller than the PSF without weight maps, longer / more profiles) always report 0.  get
+ * returns the plan's setting. */
 int origin_glr_plan_set_precision(origin_glr_plan *plan, int precision);
 int origin_glr_plan_get_precision(origin_glr_plan *plan, int *precision);
 int origin_glr_plan_bytes(origin_glr_plan *plan, size_t *bytes);
