@@ -92,6 +92,12 @@ struct CtabGuard {  // the table is cached in the context; nothing to release pe
 // bytes.  Tried and measured slower or equal: an LDS-DMA ring (`global_load_lds_*` eight rows
 // ahead: M0 / SALU overhead per row), batches of 2, 4 and 16 rows, the table row pinned in the
 // scalar cache (-4 %: the scalar loads are not the limit on their own).
+__device__ __forceinline__ double wave_sum_d64(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
 #ifndef MOM_BATCH
 #define MOM_BATCH 8
 #endif
@@ -131,11 +137,17 @@ __global__ __launch_bounds__(512) void dct_moments_kernel(const float *__restric
 #pragma unroll
   for (int a = 0; a < NA; ++a) Rw[a] = 0.0;
   int anymask = 0;
-  int nrows = 0;  // rows of this wave so far (row i is channel zc0 + wave + i ZS)
-  // blockIdx.y: a chunk of channels.  The partial moments of the chunks are summed by the solve
-  // kernel; the split gives several times more blocks than the chip holds at once, so that the
-  // last round of blocks is a small part of the run (5625 waves on 4096 slots were two rounds)
-  const int zc0 = blockIdx.y * zchunk, zc1 = min(Nz, zc0 + zchunk);
+  // MIRROR PAIRS.  theta_z = (z + 1/2) pi / Nz, so channel z' = Nz - 1 - z has cos(k theta_z') =
+  // (-1)^k cos(k theta_z): the pair (z, z') shares ONE table row, and with e = w_z + w_z',
+  // o = w_z - w_z' the 21 + 11 moment updates of the two channels are 32 FMAs instead of 64 (even
+  // k take e, odd k take o) -- the kernel was bound by float64 issue.  A wave owns the pairs
+  // p = pc0 + wave + i ZS of its chunk (blockIdx.y: a chunk of pairs; partial moments of the
+  // chunks are summed by the solve kernel, and the split gives several times more blocks than the
+  // chip holds at once, so that the last round of blocks is a small part of the run).  With odd
+  // Nz the middle channel is its own mirror image and is added by the last chunk's first wave.
+  const int npair = Nz / 2;
+  const int pc0 = blockIdx.y * zchunk, pc1 = min(npair, pc0 + zchunk);
+  int nrows = 0;  // rows buffered so far: pair i of the wave fills slots 2 i (front), 2 i + 1 (back)
 
   // buffered rows [i0, i0 + cnt) -> part[group][z].  Every lane ends with the sum of its row: the
   // four lanes of a row store the same value (no branch for a full buffer: a block boundary here
@@ -155,57 +167,82 @@ __global__ __launch_bounds__(512) void dct_moments_kernel(const float *__restric
     }
     acc += __shfl_xor(acc, 16, 64);
     acc += __shfl_xor(acc, 32, 64);
-    double *dst = part + (long)blockIdx.x * Nz + zc0 + wave + (long)(i0 + rrow) * ZS;
+    const int pr = pc0 + wave + ((i0 + rrow) >> 1) * ZS;  // the pair of this buffered row
+    const int zz = (rrow & 1) ? Nz - 1 - pr : pr;
+    double *dst = part + (long)blockIdx.x * Nz + zz;
     if (cnt == 16)
       *dst = acc;
     else if (rrow < cnt)
       *dst = acc;
   };
-  auto row = [&](int z, float r, float v, int mk) {
+  // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division: the weight is a float32
+  // quantity either way.  var = inf (masked) -> weight 0
+  auto pair = [&](int p, float rf, float vf, int mf, float rb, float vb, int mb) {
+    anymask |= mf | mb;
+    const double *ct = ctab + (long)p * NK;  // wave-uniform -> scalar loads
+    const double wf = (double)__builtin_amdgcn_rcpf(vf), wb = (double)__builtin_amdgcn_rcpf(vb);
+    const double xf = wf * (double)rf, xb = wb * (double)rb;
+    const double we = wf + wb, wo = wf - wb, xe = xf + xb, xo = xf - xb;
+    if constexpr (FOLD) {
+      tr[(nrows & 15) * MOM_PITCH + lane] = (mf || !live) ? 0.0f : rf;
+      tr[((nrows + 1) & 15) * MOM_PITCH + lane] = (mb || !live) ? 0.0f : rb;
+    }
+#pragma unroll
+    for (int k = 0; k < NK; ++k) M[k] = fma((k & 1) ? wo : we, ct[k], M[k]);
+#pragma unroll
+    for (int a = 0; a < NA; ++a) Rw[a] = fma((a & 1) ? xo : xe, ct[a], Rw[a]);
+    nrows += 2;
+  };
+
+  constexpr int B = MOM_BATCH / 2;  // pairs per batch: MOM_BATCH rows requested back to back
+  static_assert(8 % B == 0, "a transpose buffer (8 pairs) is a whole number of batches");
+  auto batch = [&](int p) {
+    float rf[B], vf[B], rb[B], vb[B];
+    int mf[B], mb[B];
+#pragma unroll
+    for (int u = 0; u < B; ++u) {
+      const int pp = p + u * ZS;
+      const long i0 = (long)pp * S + sc, i1 = (long)(Nz - 1 - pp) * S + sc;
+      rf[u] = raw[i0], vf[u] = var[i0], mf[u] = mask[i0];
+      rb[u] = raw[i1], vb[u] = var[i1], mb[u] = mask[i1];
+    }
+#pragma unroll
+    for (int u = 0; u < B; ++u) {
+      __builtin_amdgcn_sched_barrier(0);  // pairs in order: pair u waits for ITS six loads only
+      pair(p + u * ZS, rf[u], vf[u], mf[u], rb[u], vb[u], mb[u]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  int p = pc0 + wave;
+  for (; p + 7 * ZS < pc1; p += 8 * ZS) {  // trips of 8 pairs = 16 rows = one transpose buffer
+#pragma unroll
+    for (int b = 0; b < 8 / B; ++b) batch(p + b * B * ZS);
+    if constexpr (FOLD) flush(nrows - 16, std::integral_constant<int, 16>{});
+  }
+  for (; p < pc1; p += ZS) {  // the last, incomplete trip, pair by pair
+    const long i0 = (long)p * S + sc, i1 = (long)(Nz - 1 - p) * S + sc;
+    pair(p, raw[i0], var[i0], mask[i0], raw[i1], var[i1], mask[i1]);
+  }
+  if constexpr (FOLD) {
+    if (nrows & 15) flush(nrows & ~15, nrows & 15);
+  }
+  if ((Nz & 1) && blockIdx.y == gridDim.y - 1 && wave == 0) {  // the middle channel
+    const int zm = npair;
+    const long idx = (long)zm * S + sc;
+    const float r = raw[idx], v = var[idx];
+    const int mk = mask[idx];
     anymask |= mk;
-    const double *ct = ctab + (long)z * NK;  // wave-uniform -> scalar loads
-    // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division: the weight is a float32
-    // quantity either way.  var = inf (masked) -> weight 0
+    const double *ct = ctab + (long)zm * NK;
     const double wd = (double)__builtin_amdgcn_rcpf(v);
     const double wr = wd * (double)r;
-    if constexpr (FOLD) tr[(nrows & 15) * MOM_PITCH + lane] = (mk || !live) ? 0.0f : r;
 #pragma unroll
     for (int k = 0; k < NK; ++k) M[k] = fma(wd, ct[k], M[k]);
 #pragma unroll
     for (int a = 0; a < NA; ++a) Rw[a] = fma(wr, ct[a], Rw[a]);
-    ++nrows;
-  };
-
-  constexpr int B = MOM_BATCH;
-  static_assert(16 % B == 0, "a transpose buffer is a whole number of batches");
-  // one batch: B rows requested back to back, then used in order
-  auto batch = [&](int z) {
-    float r[B], v[B];
-    int mk[B];
-#pragma unroll
-    for (int u = 0; u < B; ++u) {
-      const long idx = (long)(z + u * ZS) * S + sc;
-      r[u] = raw[idx], v[u] = var[idx], mk[u] = mask[idx];
+    if constexpr (FOLD) {
+      const double sum = wave_sum_d64((mk || !live) ? 0.0 : (double)r);
+      if (lane == 0) part[(long)blockIdx.x * Nz + zm] = sum;
     }
-#pragma unroll
-    for (int u = 0; u < B; ++u) {
-      __builtin_amdgcn_sched_barrier(0);  // rows in order: row u waits for ITS three loads only
-      row(z + u * ZS, r[u], v[u], mk[u]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  int z = zc0 + wave;
-  for (; z + 15 * ZS < zc1; z += 16 * ZS) {  // trips of 16 rows = one transpose buffer
-#pragma unroll
-    for (int b = 0; b < 16 / B; ++b) batch(z + b * B * ZS);
-    if constexpr (FOLD) flush(nrows - 16, std::integral_constant<int, 16>{});
-  }
-  for (; z < zc1; z += ZS) {  // the last, incomplete trip, row by row
-    const long idx = (long)z * S + sc;
-    row(z, raw[idx], var[idx], mask[idx]);
-  }
-  if constexpr (FOLD) {
-    if (nrows & 15) flush(nrows & ~15, nrows & 15);
   }
 
   // cross-wave reduction (fixed order -> deterministic)
@@ -820,8 +857,10 @@ static int dct_fit_impl(origin_ctx *ctx, const float *d_raw, const float *d_var,
   // rows (measured at 3681 x 600 x 600: 2 chunks 3.55 ms, 4: 3.47, 8: 3.21, 12: 3.17)
   int nzc = (int)((10L * ctx->num_cu * 16 + waves * ZS - 1) / (waves * ZS));
   nzc = std::max(1, std::min(std::min(nzc, 16), Nz / 256));
-  const int zchunk = cdiv(cdiv(Nz, nzc), 16 * ZS) * 16 * ZS;  // whole 16-row trips of every wave
-  nzc = cdiv(Nz, zchunk);
+  // (chunks of mirror PAIRS of channels: whole trips of 8 pairs = 16 rows of every wave)
+  const int npair = std::max(1, Nz / 2);
+  const int zchunk = cdiv(cdiv(npair, nzc), 8 * ZS) * 8 * ZS;
+  nzc = cdiv(npair, zchunk);
   dim3 grid((unsigned)waves), gridm((unsigned)waves, nzc), block(64, ZS);
   const size_t mom_bytes = (size_t)nzc * (NACC + 1) * S * sizeof(double);
   const size_t need_bytes = ((size_t)S + 7) & ~(size_t)7;
