@@ -420,6 +420,26 @@ __device__ __forceinline__ double eval_cont(const double (&c)[ORDER + 1], const 
   return acc;
 }
 
+// The continuum of a MIRROR PAIR of channels (z, Nz - 1 - z) from the table row of z:
+// cos(a theta) is even about the middle of the cube for even a and odd for odd a, so with
+// E = sum_{a even} c_a cos(a theta_z), O = sum_{a odd} c_a cos(a theta_z) the two values are
+// E + O and E - O -- one table row and ORDER + 1 FMAs for two voxels.
+template <int ORDER>
+__device__ __forceinline__ void eval_cont_pair(const double (&c)[ORDER + 1], const double *ct,
+                                               double &front, double &back) {
+  double E = c[0] * ct[0], O = 0.0;
+  if constexpr (ORDER >= 1) O = c[1] * ct[1];
+#pragma unroll
+  for (int a = 2; a <= ORDER; ++a) {
+    if (a & 1)
+      O = fma(c[a], ct[a], O);
+    else
+      E = fma(c[a], ct[a], E);
+  }
+  front = E + O;
+  back = E - O;
+}
+
 template <int ORDER>
 __global__ __launch_bounds__(256) void dct_continuum_kernel(const double *__restrict__ coef,
                                                             const double *__restrict__ ctab,
@@ -656,21 +676,19 @@ __global__ __launch_bounds__(256) void dct_standardize_kernel(
   double c[NA];
 #pragma unroll
   for (int a = 0; a < NA; ++a) c[a] = coef[(long)a * S + s];
-  const int z0 = blockIdx.y * zchunk;
-  const int z1 = min(Nz, z0 + zchunk);
+  // blockIdx.y: a chunk of mirror pairs of channels (eval_cont_pair); the middle channel of an
+  // odd Nz goes with the last chunk
+  const int npair = Nz / 2;
+  const int p0 = blockIdx.y * zchunk, p1 = min(npair, p0 + zchunk);
   double a_std = 0.0, a_dct = 0.0, a_o2 = 0.0;
-#pragma unroll 2
-  for (int z = z0; z < z1; ++z) {
-    const long idx = (long)z * S + s;
+  auto voxel = [&](long idx, double cont, double mean) {
     const float r = raw[idx];
     const float v = var[idx];
     const bool mk = mask[idx] != 0;
-    const double cont = eval_cont<ORDER>(c, ctab + (long)z * NK);
-    const double mean = zmean[z];           // nanmean over unmasked spaxels (steps.py:442)
     // std = sqrt(var) (steps.py:439); both quotients share one reciprocal (float32 results
     // within 2 ulp of the reference's float64 quotient cast to float32)
     const float rs = 1.0f / sqrtf(v);
-    const float t = (float)(((double)r - cont) - mean);
+    const float t = (float)(((double)r - cont) - mean);  // nanmean over unmasked spaxels (:442)
     const float o = mk ? 0.0f : t * rs;     // data[mask] = 0                (steps.py:446)
     const float cd = (float)cont * rs;      // cont_dct /= std ; astype(f32) (:440, :463)
     cube_std[idx] = o;
@@ -678,7 +696,17 @@ __global__ __launch_bounds__(256) void dct_standardize_kernel(
     a_std += (double)o;
     a_dct += (double)cd;
     a_o2 = fma((double)o, (double)o, a_o2);
+  };
+#pragma unroll 2
+  for (int p = p0; p < p1; ++p) {
+    const int zb = Nz - 1 - p;
+    double cf, cb;
+    eval_cont_pair<ORDER>(c, ctab + (long)p * NK, cf, cb);
+    voxel((long)p * S + s, cf, zmean[p]);
+    voxel((long)zb * S + s, cb, zmean[zb]);
   }
+  if ((Nz & 1) && blockIdx.y == gridDim.y - 1)
+    voxel((long)npair * S + s, eval_cont<ORDER>(c, ctab + (long)npair * NK), zmean[npair]);
   if (part) {
     double *p = part + (long)blockIdx.y * 3 * S + s;
     p[0] = a_std;
@@ -705,18 +733,24 @@ __global__ __launch_bounds__(256) void dct_cont_std_kernel(const float *__restri
   double c[NA];
 #pragma unroll
   for (int a = 0; a < NA; ++a) c[a] = coef[(long)a * S + s];
-  const int z0 = blockIdx.y * zchunk;
-  const int z1 = min(Nz, z0 + zchunk);
+  const int npair = Nz / 2;  // (mirror pairs, as dct_standardize_kernel: identical values)
+  const int p0 = blockIdx.y * zchunk, p1 = min(npair, p0 + zchunk);
   double a_dct = 0.0;
-#pragma unroll 2
-  for (int z = z0; z < z1; ++z) {
-    const long idx = (long)z * S + s;
-    const double cont = eval_cont<ORDER>(c, ctab + (long)z * NK);
+  auto voxel = [&](long idx, double cont) {
     const float rs = 1.0f / sqrtf(var[idx]);
     const float cd = (float)cont * rs;
     cont_dct[idx] = cd;
     a_dct += (double)cd;
+  };
+#pragma unroll 2
+  for (int p = p0; p < p1; ++p) {
+    double cf, cb;
+    eval_cont_pair<ORDER>(c, ctab + (long)p * NK, cf, cb);
+    voxel((long)p * S + s, cf);
+    voxel((long)(Nz - 1 - p) * S + s, cb);
   }
+  if ((Nz & 1) && blockIdx.y == gridDim.y - 1)
+    voxel((long)npair * S + s, eval_cont<ORDER>(c, ctab + (long)npair * NK));
   if (part) part[(long)blockIdx.y * S + s] = a_dct;
 }
 
@@ -1010,8 +1044,9 @@ int origin_dct_standardize(origin_ctx *ctx, const float *d_raw, const float *d_v
   rc = make_ctab(ctx, Nz, order, &tab.p);
   if (rc) return rc;
   const int nzc0 = pick_zchunks(ctx, S, Nz);
-  const int zchunk = cdiv(Nz, nzc0);
-  const int nzc = cdiv(Nz, zchunk);
+  const int npair = std::max(1, Nz / 2);  // the kernel's chunks are of mirror PAIRS of channels
+  const int zchunk = cdiv(npair, nzc0);
+  const int nzc = cdiv(npair, zchunk);
   const bool want = d_ima_std || d_ima_dct || d_o2;
   double *part = nullptr, *zmean = nullptr;
   {
@@ -1052,8 +1087,9 @@ static int dct_cont_std_on(origin_ctx *ctx, bool aux, const float *d_var, const 
   rc = make_ctab(ctx, Nz, order, &tab.p);
   if (rc) return rc;
   const int nzc0 = pick_zchunks(ctx, S, Nz);
-  const int zchunk = cdiv(Nz, nzc0);
-  const int nzc = cdiv(Nz, zchunk);
+  const int npair = std::max(1, Nz / 2);  // (chunks of mirror pairs of channels)
+  const int zchunk = cdiv(npair, nzc0);
+  const int nzc = cdiv(npair, zchunk);
   double *part = nullptr;
   if (d_ima_dct) {
     void *scr = nullptr;  // (the aux stream has a scratch of its own: the PCA uses the main one)
