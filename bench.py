@@ -160,6 +160,11 @@ def main():
     from origin_amd.pca import GreedyPCA
     pca_driver = GreedyPCA(ctx)
 
+    # (outputs of --local-max, allocated once: a 5 GB hipMalloc / hipFree per step is slower than
+    # the kernel)
+    lmax_buf = ctx.empty(correl.shape, np.float32) if args.local_max else None
+    lmin_buf = ctx.empty(correl.shape, np.float32) if args.local_max else None
+
     def one_step():
         t0 = time.perf_counter()
         ctx.aux_join()  # (coef_buf / cont_dct of the previous step: idle after its closing sync)
@@ -188,7 +193,7 @@ def main():
             out = plan.run(cube_faint, mask=mask, correl=correl, profile=profile,
                            correl_min=correl_min, want_maps=True)
         if args.local_max:
-            kernels.local_max(ctx, correl, correl_min, mask, 3)
+            kernels.local_max(ctx, correl, correl_min, mask, 3, out_max=lmax_buf, out_min=lmin_buf)
         ctx.sync()
         t4 = time.perf_counter()
         for k, v in (("dct_std", t1 - t0), ("threshold_fit_host", t2 - t1),

@@ -30,63 +30,57 @@ __global__ __launch_bounds__(256) void local_max_kernel(const float *__restrict_
   out[idx] = keep ? m : 0.0f;  // local_max *= local_mask                  (lib :1247)
 }
 
-// size == 3: a block owns a 64 x 16 tile of spaxels and marches z.  Per channel the tile (with a
-// one-spaxel rim, clamped at the field border) goes through LDS once, every thread forms the 3x3
-// spatial maximum of its 4 outputs, and the 3x3x3 maximum of channel z is the maximum of the three
-// most recent plane maxima, kept in registers: each plane is read once (+16 % rim) instead of 27
-// times.  Exact: a maximum does not depend on the order of its operands.
-constexpr int LM_TX = 64, LM_TY = 16;
+// size == 3: a thread owns 4 consecutive rows of one image column and marches z.  Per channel it
+// loads the 6 x 3 samples around its outputs (clamped at the field border; the neighbours'
+// loads hit the same cache lines), forms the row maxima over x, the 3 x 3 maxima over y, and the
+// 3 x 3 x 3 maximum of channel z as the maximum of the three most recent plane maxima kept in
+// registers.  No LDS, no barrier: the tile-through-LDS form of round 1 (three block barriers per
+// channel) ran at 2.5 TB/s of algorithmic bytes.  Exact: a maximum does not depend on the order
+// of its operands.
+constexpr int LM_ROWS = 4;
 __global__ __launch_bounds__(256) void local_max3_kernel(const float *__restrict__ a,
                                                          const uint8_t *__restrict__ mask, int Nz,
                                                          int Ny, int Nx, int zper, float sign,
                                                          float *__restrict__ out) {
-  __shared__ float tile[LM_TY + 2][LM_TX + 2];
-  const int x0 = blockIdx.x * LM_TX, y0 = blockIdx.y * LM_TY;
+  const int x = blockIdx.x * 64 + threadIdx.x;
+  const int yb = (blockIdx.y * 4 + threadIdx.y) * LM_ROWS;
+  if (x >= Nx || yb >= Ny) return;
   const int z0 = blockIdx.z * zper, z1 = min(Nz, z0 + zper);
-  const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
   const long S = (long)Ny * Nx;
-  const int x = x0 + tx;
-  auto load_plane = [&](int z) {  // plane z (clamped) -> LDS, sign applied
+  const int xl = max(x - 1, 0), xr = min(x + 1, Nx - 1);
+  long roff[LM_ROWS + 2];  // rows yb - 1 .. yb + LM_ROWS, clamped
+#pragma unroll
+  for (int r = 0; r < LM_ROWS + 2; ++r) roff[r] = (long)min(max(yb - 1 + r, 0), Ny - 1) * Nx;
+  auto plane = [&](int z, float (&p)[LM_ROWS], float (&c)[LM_ROWS]) {  // 3x3 maxima, centre values
     const float *pz = a + (long)min(max(z, 0), Nz - 1) * S;
-    for (int e = tid; e < (LM_TY + 2) * (LM_TX + 2); e += 256) {
-      const int ry = e / (LM_TX + 2), rx = e - ry * (LM_TX + 2);
-      const int yy = min(max(y0 - 1 + ry, 0), Ny - 1), xx = min(max(x0 - 1 + rx, 0), Nx - 1);
-      tile[ry][rx] = sign * pz[(long)yy * Nx + xx];
+    float l[LM_ROWS + 2], m[LM_ROWS + 2], rr[LM_ROWS + 2];
+#pragma unroll
+    for (int r = 0; r < LM_ROWS + 2; ++r) {
+      const float *row = pz + roff[r];
+      l[r] = sign * row[xl], m[r] = sign * row[x], rr[r] = sign * row[xr];
+    }
+    float xm[LM_ROWS + 2];
+#pragma unroll
+    for (int r = 0; r < LM_ROWS + 2; ++r) xm[r] = fmaxf(fmaxf(l[r], m[r]), rr[r]);
+#pragma unroll
+    for (int r = 0; r < LM_ROWS; ++r) {
+      p[r] = fmaxf(fmaxf(xm[r], xm[r + 1]), xm[r + 2]);
+      c[r] = m[r + 1];
     }
   };
-  auto plane_max = [&](float (&p)[4], float (&c)[4]) {  // 3x3 maxima and centre values
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int ry = ty + 4 * r + 1;  // row in the tile
-      float m = -INFINITY;
-#pragma unroll
-      for (int dy = -1; dy <= 1; ++dy)
-        m = fmaxf(m, fmaxf(fmaxf(tile[ry + dy][tx], tile[ry + dy][tx + 1]), tile[ry + dy][tx + 2]));
-      p[r] = m;
-      c[r] = tile[ry][tx + 1];
-    }
-  };
-  float pa[4], pb[4], pc[4], ca[4], cb[4], cc[4];  // planes z-1, z, z+1
-  load_plane(z0 - 1);
-  __syncthreads();
-  plane_max(pa, ca);
-  __syncthreads();
-  load_plane(z0);
-  __syncthreads();
-  plane_max(pb, cb);
+  float pa[LM_ROWS], pb[LM_ROWS], pc[LM_ROWS], ca[LM_ROWS], cb[LM_ROWS], cc[LM_ROWS];
+  plane(z0 - 1, pa, ca);
+  plane(z0, pb, cb);
   for (int z = z0; z < z1; ++z) {
-    __syncthreads();
-    load_plane(z + 1);
-    __syncthreads();
-    plane_max(pc, cc);
+    plane(z + 1, pc, cc);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int y = y0 + ty + 4 * r;
-      if (x < Nx && y < Ny) {
+    for (int r = 0; r < LM_ROWS; ++r) {
+      const int y = yb + r;
+      if (y < Ny) {
         const long idx = (long)z * S + (long)y * Nx + x;
-        const float m = fmaxf(fmaxf(pa[r], pb[r]), pc[r]);
-        const bool keep = (cb[r] == m) && !(mask && mask[idx]);
-        out[idx] = keep ? m : 0.0f;  // local_max *= local_mask                (lib :1247)
+        const float mx = fmaxf(fmaxf(pa[r], pb[r]), pc[r]);
+        const bool keep = (cb[r] == mx) && !(mask && mask[idx]);
+        out[idx] = keep ? mx : 0.0f;  // local_max *= local_mask                (lib :1247)
       }
       pa[r] = pb[r], pb[r] = pc[r], ca[r] = cb[r], cb[r] = cc[r];
     }
@@ -107,11 +101,11 @@ extern "C" int origin_local_max(origin_ctx *ctx, const float *d_correl,
   dim3 grid(cdiv(Nx, 64), cdiv(Ny, 4), Nz), block(64, 4);
   ProfScope ps(ctx, K_LOCAL_MAX);
   if (size == 3) {  // the reference's default (steps.py:453, :796)
-    const long tiles = (long)cdiv(Nx, LM_TX) * cdiv(Ny, LM_TY);
-    int nzb = (int)(((long)ctx->num_cu * 16 + tiles - 1) / tiles);
+    const long tiles = (long)cdiv(Nx, 64) * cdiv(Ny, 4 * LM_ROWS);
+    int nzb = (int)(((long)ctx->num_cu * 32 + tiles - 1) / tiles);  // ~32 blocks per CU
     nzb = nzb < 1 ? 1 : (nzb > Nz ? Nz : nzb);
     const int zper = cdiv(Nz, nzb);
-    dim3 g3(cdiv(Nx, LM_TX), cdiv(Ny, LM_TY), cdiv(Nz, zper));
+    dim3 g3(cdiv(Nx, 64), cdiv(Ny, 4 * LM_ROWS), cdiv(Nz, zper));
     if (d_correl && d_local_max)
       hipLaunchKernelGGL(local_max3_kernel, g3, block, 0, ctx->stream, d_correl, d_mask, Nz, Ny, Nx,
                          zper, 1.0f, d_local_max);
