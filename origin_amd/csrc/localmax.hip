@@ -37,11 +37,19 @@ __global__ __launch_bounds__(256) void local_max_kernel(const float *__restrict_
 // registers.  No LDS, no barrier: the tile-through-LDS form of round 1 (three block barriers per
 // channel) ran at 2.5 TB/s of algorithmic bytes.  Exact: a maximum does not depend on the order
 // of its operands.
-constexpr int LM_ROWS = 4;
-__global__ __launch_bounds__(256) void local_max3_kernel(const float *__restrict__ a,
+#ifndef LM_ROWS_N
+#define LM_ROWS_N 4
+#endif
+constexpr int LM_ROWS = LM_ROWS_N;
+// NC = 2: correl (local maxima) and correl_min (local maxima of its negative) in one march: the
+// mask is read once and the index arithmetic is shared.
+template <int NC>
+__global__ __launch_bounds__(256) void local_max3_kernel(const float *__restrict__ a0,
+                                                         const float *__restrict__ a1,
                                                          const uint8_t *__restrict__ mask, int Nz,
-                                                         int Ny, int Nx, int zper, float sign,
-                                                         float *__restrict__ out) {
+                                                         int Ny, int Nx, int zper, float sign0,
+                                                         float *__restrict__ out0,
+                                                         float *__restrict__ out1) {
   const int x = blockIdx.x * 64 + threadIdx.x;
   const int yb = (blockIdx.y * 4 + threadIdx.y) * LM_ROWS;
   if (x >= Nx || yb >= Ny) return;
@@ -51,7 +59,7 @@ __global__ __launch_bounds__(256) void local_max3_kernel(const float *__restrict
   long roff[LM_ROWS + 2];  // rows yb - 1 .. yb + LM_ROWS, clamped
 #pragma unroll
   for (int r = 0; r < LM_ROWS + 2; ++r) roff[r] = (long)min(max(yb - 1 + r, 0), Ny - 1) * Nx;
-  auto plane = [&](int z, float (&p)[LM_ROWS], float (&c)[LM_ROWS]) {  // 3x3 maxima, centre values
+  auto plane = [&](const float *a, float sign, int z, float (&p)[LM_ROWS], float (&c)[LM_ROWS]) {
     const float *pz = a + (long)min(max(z, 0), Nz - 1) * S;
     float l[LM_ROWS + 2], m[LM_ROWS + 2], rr[LM_ROWS + 2];
 #pragma unroll
@@ -68,21 +76,32 @@ __global__ __launch_bounds__(256) void local_max3_kernel(const float *__restrict
       c[r] = m[r + 1];
     }
   };
-  float pa[LM_ROWS], pb[LM_ROWS], pc[LM_ROWS], ca[LM_ROWS], cb[LM_ROWS], cc[LM_ROWS];
-  plane(z0 - 1, pa, ca);
-  plane(z0, pb, cb);
+  float pa[NC][LM_ROWS], pb[NC][LM_ROWS], pc[NC][LM_ROWS], cb[NC][LM_ROWS], cc[NC][LM_ROWS];
+  float dummy[LM_ROWS];
+  plane(a0, sign0, z0 - 1, pa[0], dummy);
+  plane(a0, sign0, z0, pb[0], cb[0]);
+  if constexpr (NC == 2) {
+    plane(a1, -1.0f, z0 - 1, pa[1], dummy);
+    plane(a1, -1.0f, z0, pb[1], cb[1]);
+  }
   for (int z = z0; z < z1; ++z) {
-    plane(z + 1, pc, cc);
+    plane(a0, sign0, z + 1, pc[0], cc[0]);
+    if constexpr (NC == 2) plane(a1, -1.0f, z + 1, pc[1], cc[1]);
 #pragma unroll
     for (int r = 0; r < LM_ROWS; ++r) {
       const int y = yb + r;
       if (y < Ny) {
         const long idx = (long)z * S + (long)y * Nx + x;
-        const float mx = fmaxf(fmaxf(pa[r], pb[r]), pc[r]);
-        const bool keep = (cb[r] == mx) && !(mask && mask[idx]);
-        out[idx] = keep ? mx : 0.0f;  // local_max *= local_mask                (lib :1247)
+        const bool unmasked = !(mask && mask[idx]);
+        const float m0 = fmaxf(fmaxf(pa[0][r], pb[0][r]), pc[0][r]);
+        out0[idx] = (cb[0][r] == m0 && unmasked) ? m0 : 0.0f;  // local_max *= local_mask (lib :1247)
+        if constexpr (NC == 2) {
+          const float m1 = fmaxf(fmaxf(pa[1][r], pb[1][r]), pc[1][r]);
+          out1[idx] = (cb[1][r] == m1 && unmasked) ? m1 : 0.0f;
+        }
       }
-      pa[r] = pb[r], pb[r] = pc[r], ca[r] = cb[r], cb[r] = cc[r];
+#pragma unroll
+      for (int q = 0; q < NC; ++q) pa[q][r] = pb[q][r], pb[q][r] = pc[q][r], cb[q][r] = cc[q][r];
     }
   }
 }
@@ -106,12 +125,17 @@ extern "C" int origin_local_max(origin_ctx *ctx, const float *d_correl,
     nzb = nzb < 1 ? 1 : (nzb > Nz ? Nz : nzb);
     const int zper = cdiv(Nz, nzb);
     dim3 g3(cdiv(Nx, 64), cdiv(Ny, 4 * LM_ROWS), cdiv(Nz, zper));
-    if (d_correl && d_local_max)
-      hipLaunchKernelGGL(local_max3_kernel, g3, block, 0, ctx->stream, d_correl, d_mask, Nz, Ny, Nx,
-                         zper, 1.0f, d_local_max);
-    if (d_correl_min && d_local_min)
-      hipLaunchKernelGGL(local_max3_kernel, g3, block, 0, ctx->stream, d_correl_min, d_mask, Nz, Ny,
-                         Nx, zper, -1.0f, d_local_min);
+    if (d_correl && d_local_max && d_correl_min && d_local_min)
+      hipLaunchKernelGGL(local_max3_kernel<2>, g3, block, 0, ctx->stream, d_correl, d_correl_min,
+                         d_mask, Nz, Ny, Nx, zper, 1.0f, d_local_max, d_local_min);
+    else if (d_correl && d_local_max)
+      hipLaunchKernelGGL(local_max3_kernel<1>, g3, block, 0, ctx->stream, d_correl,
+                         (const float *)nullptr, d_mask, Nz, Ny, Nx, zper, 1.0f, d_local_max,
+                         (float *)nullptr);
+    else if (d_correl_min && d_local_min)
+      hipLaunchKernelGGL(local_max3_kernel<1>, g3, block, 0, ctx->stream, d_correl_min,
+                         (const float *)nullptr, d_mask, Nz, Ny, Nx, zper, -1.0f, d_local_min,
+                         (float *)nullptr);
     ORIGIN_LAUNCH_CHECK();
     return ORIGIN_OK;
   }
