@@ -172,13 +172,22 @@ def main():
                                                 zsum=zsum_buf, zcnt=zcnt_buf)
         if comm is not None:
             comm.allreduce_sum_device(ctx, [zsum, zcnt])
+        # cont_dct: written by the standardisation pass itself ("fused", default: var is read once),
+        # or by a pass of its own after the O2 map has left -- on the main stream ("sync") or on
+        # the auxiliary low-priority stream ("aux").  Measured at 3681 x 600 x 600: 54.5 / 54.3 /
+        # 54.9 ms per step -- the side pass overlaps the host's threshold fit but takes its
+        # 10.6 GB of traffic out of the PCA's first, HBM-bound iterations
+        cont_mode = os.environ.get("ORIGIN_BENCH_CONT", "fused")
         pre = kernels.dct_standardize(ctx, raw, var, mask, coef, zsum, zcnt, cube_std=cube_std,
-                                      want_cont=False, o2=o2_buf, ima_std=ima_std)
+                                      cont_dct=cont_dct if cont_mode == "fused" else None,
+                                      want_cont=cont_mode == "fused", o2=o2_buf, ima_std=ima_std)
         o2 = pre["o2"].to_host()
         # the continuum cube is not needed by anything below: it runs on the auxiliary
         # low-priority stream, under the host's threshold fit and the latency-bound kernels of the
         # greedy PCA (same step: the closing synchronisation waits for both streams)
-        kernels.dct_cont_std(ctx, var, coef, cont_dct=cont_dct, ima_dct=ima_dct, aux=True)
+        if cont_mode != "fused":
+            kernels.dct_cont_std(ctx, var, coef, cont_dct=cont_dct, ima_dct=ima_dct,
+                                 aux=cont_mode == "aux")
         t1 = time.perf_counter()
         thr = pipeline.pca_threshold(o2, local_map, nb_local, 0.01, spx=spx)
         t2 = time.perf_counter()

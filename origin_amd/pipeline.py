@@ -30,13 +30,12 @@ def preprocess(ctx, raw, var, mask, dct_order=10, dct_approx=False, allreduce=No
         n = zsum.size
         zsum.upload(both[:n])
         zcnt.upload(both[n:])
-    # cube_std and the O2 map first; the continuum cube, which nothing downstream of the O2 map
-    # waits for, is enqueued after the O2 map has been fetched, so that it runs while the host
-    # works on the thresholds
-    out = kernels.dct_standardize(ctx, raw, var, mask, coef, zsum, zcnt, want_cont=False)
+    # cube_std, cont_dct (var is read once for both) and the O2 map in one pass.  (A continuum
+    # pass of its own after the O2 map has left -- kernels.dct_cont_std, optionally on the
+    # auxiliary stream -- overlaps the host's threshold fit but costs the PCA's first iterations
+    # its 10.6 GB of traffic: measured equal within noise, bench.py ORIGIN_BENCH_CONT.)
+    out = kernels.dct_standardize(ctx, raw, var, mask, coef, zsum, zcnt, want_cont=want_cont)
     out["o2_host"] = out["o2"].to_host()
-    if want_cont:
-        out.update(kernels.dct_cont_std(ctx, var, coef))
     out["coef"] = coef  # (freeing it here would wait for the pass just enqueued)
     return out
 
