@@ -89,6 +89,19 @@ int origin_zmax_map(origin_ctx *ctx, const float *d_cube, const uint8_t *d_keep,
 int origin_count_above(origin_ctx *ctx, const float *d_cube, const uint8_t *d_keep, int Nz, long S,
                        int nthr, const double *h_thr, long *h_counts);
 
+/* ---- detection thresholding (the consumer of the local-maximum cubes) -------------------
+ * Detection.run, steps.py:956-974 (and det_correl_min, :935-939):
+ *     z, y, x = np.where(cube > thr);  T_GLR = cube[z, y, x];  profile = cube_profile[z, y, x]
+ * as an ordered stream compaction on the device: positions in C order (z slowest, x fastest, the
+ * order np.where returns), compared in float64 (NaN is never above).  d_aux: uint8 cube gathered at
+ * the same positions (cube_profile) or NULL.  *h_count receives the TOTAL number of voxels above
+ * thr; the first min(cap, total) of them are written to d_z / d_y / d_x (int32) and, where given,
+ * d_val (float32) and d_auxout (uint8) -- call again with a larger cap when total > cap; cap = 0
+ * only counts.  d_cube must be 16-byte aligned.  Synchronises the stream. */
+int origin_where_above(origin_ctx *ctx, const float *d_cube, const uint8_t *d_aux, int Nz, int Ny,
+                       int Nx, double thr, long cap, int *d_z, int *d_y, int *d_x, float *d_val,
+                       uint8_t *d_auxout, long *h_count);
+
 /* ---- FITS data units ------------------------------------------------
  * Step.dump / Step.load (steps.py:301-352) write and reload every cube / image of a step as a
  * FITS image extension through mpdaf (Cube.write(convert_float32=False) -> float64; lazy

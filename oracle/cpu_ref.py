@@ -541,6 +541,43 @@ def Compute_threshold_purity(purity, cube_local_max, cube_local_min, segmap=None
 
 
 # --------------------------------------------------------------------------
+# Thresholding of step 7  (steps.py:935-939, :956-994: the inline NumPy of Detection.run, no
+# lib_origin function -- nothing to import there, so this restatement is pinned by construction:
+# it IS the reference's expression)
+# --------------------------------------------------------------------------
+def detection_threshold(cube_local_max, cube_profile, cube_std_local_max, threshold_correl,
+                        threshold_std, maxdist_lines=2.5):
+    """Cat0 columns of Detection.run (steps.py:956-981) as a dict of arrays in vstack order
+    (correl detections, then std detections), and the indices of the std detections that
+    survive the merging of :983-994 (those farther than maxdist_lines from every correl
+    detection), sorted."""
+    from scipy.spatial import cKDTree
+
+    z, y, x = np.where(cube_local_max > threshold_correl)                      # :958
+    t_glr = cube_local_max[z, y, x]                                            # :962
+    prof = cube_profile[z, y, x]                                               # :963
+    zs, ys, xs = np.where(cube_std_local_max > threshold_std)                  # :968
+    std = cube_std_local_max[zs, ys, xs]                                       # :971
+    n, m = len(z), len(zs)
+    cat0 = dict(
+        x0=np.concatenate([x, xs]), y0=np.concatenate([y, ys]), z0=np.concatenate([z, zs]),
+        comp=np.concatenate([np.zeros(n, int), np.ones(m, int)]),              # :960, :970
+        STD=np.concatenate([np.full(n, np.nan), std]),                         # :961, :971
+        T_GLR=np.concatenate([t_glr, np.full(m, np.nan)]),                     # :962, :972
+        profile=np.concatenate([prof, np.zeros(m, prof.dtype)]))               # :963, :973
+    if n and m:                                                                # :984-992
+        kdt_cor = cKDTree(np.array([x, y, z]).T)
+        kdt_std = cKDTree(np.array([xs, ys, zs]).T)
+        matched = set()
+        for lst in kdt_cor.query_ball_tree(kdt_std, maxdist_lines):
+            matched.update(lst)
+    else:
+        matched = set()
+    unmatched = sorted(set(range(m)) - matched)
+    return cat0, np.array(unmatched, dtype=int)
+
+
+# --------------------------------------------------------------------------
 # Whole chain in Step order (substitute for BASELINE config 0, SURVEY G7)
 # --------------------------------------------------------------------------
 def run_chain(cube_raw, var, mask, PSF, wfields, profiles, areamap, nbAreas,

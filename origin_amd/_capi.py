@@ -39,6 +39,7 @@ SIGNATURES = {
     "origin_copy_box": [vp, i32, vp, i64, i64, vp, i64, i64, i32, i32, i32, i32],
     "origin_zmax_map": [vp, vp, vp, i32, i64, vp],
     "origin_count_above": [vp, vp, vp, i32, i64, i32, vp, vp],
+    "origin_where_above": [vp, vp, vp, i32, i32, i32, C.c_double, i64, vp, vp, vp, vp, vp, vp],
     "origin_fits_encode": [vp, vp, i32, i64, i32, vp],
     "origin_fits_decode": [vp, vp, i32, i64, i32, vp],
     "origin_fits_write_data": [vp, vp, i32, i64, i32, i32],

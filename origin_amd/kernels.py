@@ -230,6 +230,41 @@ def zmax_map(ctx, cube, keep=None):
     return m.to_host().astype(np.float64)
 
 
+def where_above(ctx, cube, threshold, aux=None, cap=1 << 20):
+    """``z, y, x = np.where(cube > threshold)`` on a float32 device cube, in NumPy's order, with
+    the values there (and those of the uint8 device cube ``aux``): Detection.run's thresholding
+    (steps.py:956-974).  Only the detections cross PCIe.  Returns a dict of host arrays
+    ``z, y, x`` (int64), ``value`` (float64) and, with ``aux``, ``aux`` (uint8)."""
+    Nz, Ny, Nx = cube.shape
+    if cube.dtype != np.float32:
+        raise TypeError("where_above needs a float32 device cube")
+    if aux is not None and (aux.dtype != np.uint8 or aux.shape != cube.shape):
+        raise ValueError("aux must be a uint8 device cube of the same shape")
+    count = C.c_long(0)
+    cap = max(int(cap), 1)
+    while True:
+        idx = ctx.empty((3, cap), np.int32)
+        val = ctx.empty((cap,), np.float32)
+        ax = ctx.empty((cap,), np.uint8) if aux is not None else None
+        _capi.call("origin_where_above", ctx.handle, cube.p, _p(aux), Nz, Ny, Nx,
+                   float(threshold), cap, idx.view(0, (cap,)).p, idx.view(cap, (cap,)).p,
+                   idx.view(2 * cap, (cap,)).p, val.p, _p(ax), C.byref(count))
+        n = count.value
+        if n <= cap:
+            break
+        cap = n   # more detections than expected: once more with room for all of them
+    def head(a, off, dtype):   # the first n entries only
+        if n == 0:
+            return np.empty(0, dtype=dtype)
+        return a.view(off, (n,)).to_host().astype(dtype)
+
+    out = dict(z=head(idx, 0, np.int64), y=head(idx, cap, np.int64),
+               x=head(idx, 2 * cap, np.int64), value=head(val, 0, np.float64))
+    if aux is not None:
+        out["aux"] = head(ax, 0, np.uint8)
+    return out
+
+
 def count_above(ctx, cube, thresholds, keep=None):
     """counts[t] = #{voxels of cube (x keep) with value > thresholds[t]} (int64, host)."""
     Nz, Ny, Nx = cube.shape

@@ -674,6 +674,100 @@ def test_purity_step_on_device_cubes(ctx):
     assert np.array_equal(np.asarray(pv["Det_m"]), cols["Det_m"])
 
 
+@pytest.mark.parametrize("shape", [(1, 1, 1), (3, 5, 7), (16, 16, 16), (17, 31, 29),
+                                   (64, 64, 65), (130, 47, 53)])
+def test_where_above_is_numpy_where(ctx, shape):
+    """origin_where_above against np.where on the same float32 cube: positions in C order, the
+    values and the gathered uint8 cube there -- bit exact (index work).  Shapes below one
+    4096-voxel chunk, an exact multiple of it and ragged tails; sparse hits, no hit, every voxel a
+    hit, NaN / inf entries, a threshold equal to values of the cube (strict >), and more hits
+    than the caller's capacity (second call with room for all)."""
+    from origin_amd import kernels
+    rng = np.random.default_rng(sum(shape))
+    cube = rng.standard_normal(shape).astype(np.float32)
+    cube[rng.random(shape) < 0.6] = 0.0                       # mostly zeros, like a local-max cube
+    if cube.size > 8:
+        flat = cube.reshape(-1)
+        flat[rng.integers(0, flat.size, 3)] = np.nan
+        flat[rng.integers(0, flat.size, 2)] = np.inf
+        flat[rng.integers(0, flat.size, 2)] = -np.inf
+        flat[-1] = 5.0                                        # a hit in the last (ragged) voxel
+        flat[0] = 4.0
+    aux = rng.integers(0, 255, shape).astype(np.uint8)
+    d_cube, d_aux = ctx.to_device(cube), ctx.to_device(aux)
+    some = float(np.float32(cube[np.isfinite(cube)].max())) if np.isfinite(cube).any() else 0.0
+    for thr in (1.5, 0.0, -1e30, 1e30, some, float(np.float32(0.7)) + 1e-12):
+        for cap in (1 << 20, 3):
+            got = kernels.where_above(ctx, d_cube, thr, aux=d_aux, cap=cap)
+            with np.errstate(invalid="ignore"):
+                z, y, x = np.where(cube.astype(np.float64) > thr)
+            assert np.array_equal(got["z"], z) and np.array_equal(got["y"], y)
+            assert np.array_equal(got["x"], x)
+            assert np.array_equal(got["value"], cube[z, y, x].astype(np.float64))
+            assert np.array_equal(got["aux"], aux[z, y, x])
+    only = kernels.where_above(ctx, d_cube, 1.5)              # without the gathered cube
+    assert "aux" not in only and np.array_equal(only["z"], np.where(cube > 1.5)[0])
+
+
+def test_where_above_large_cube_properties(ctx):
+    """3681 x 200 x 200 (BASELINE config 1's shape; 36 000 chunks, several rounds of the prefix
+    scan): planted detections come back exactly, in order; the count agrees with
+    origin_count_above; every returned voxel is above the threshold and the flat indices are
+    strictly increasing (C order, no duplicates)."""
+    from origin_amd import kernels
+    Nz, Ny, Nx = 3681, 200, 200
+    rng = np.random.default_rng(7)
+    cube = np.zeros((Nz, Ny, Nx), np.float32)
+    n = 50000
+    flat = np.unique(rng.integers(0, cube.size, n))
+    cube.reshape(-1)[flat] = rng.uniform(0.5, 30.0, flat.size).astype(np.float32)
+    d = ctx.to_device(cube)
+    thr = 8.25
+    got = kernels.where_above(ctx, d, thr, cap=1000)          # forces the second call
+    want = flat[cube.reshape(-1)[flat].astype(np.float64) > thr]
+    gi = (got["z"] * Ny + got["y"]) * Nx + got["x"]
+    assert np.array_equal(gi, want)
+    assert np.all(np.diff(gi) > 0) and np.all(got["value"] > thr)
+    assert np.array_equal(got["value"], cube.reshape(-1)[want].astype(np.float64))
+    assert kernels.count_above(ctx, d, [thr])[0] == want.size
+
+
+def test_step7_thresholding_after_the_chain(ctx):
+    """Detection.run's first half (steps.py:956-994) on the device cubes the chain left in HBM,
+    against the oracle's restatement on their host copies: Cat0 identical column by column, the
+    same std detections survive the merging."""
+    from origin_amd import detection
+    from origin_amd.steps import SimpleOrig
+    f, raw, var, mask = synth.small_case(Nz=160, Ny=48, Nx=52, seed=3, psf_size=9, nprof=3,
+                                         area_size=24)
+    orig = SimpleOrig(raw, var, mask, f.PSF.astype(float), f.profiles)
+    orig.step01_preprocessing()
+    orig.step02_areas.set_areamap(f.areamap)
+    orig.step03_compute_PCA_threshold()
+    orig.step04_compute_greedy_PCA()
+    orig.step05_compute_TGLR()
+    lmax = orig.cube_local_max._data
+    prof = orig.cube_profile._data
+    smax = orig.cube_std_local_max._data
+    d_lmax = orig._hip_cache["cube_local_max"]                 # what step 5 left in HBM
+    # thresholds that give a few hundred detections of each kind on this small field
+    t_cor = float(np.sort(lmax[lmax > 0])[-300])
+    t_std = float(np.sort(smax[smax > 0])[-400])
+    cat0, cat, cat_std = detection.from_session(orig, threshold=t_cor, threshold_std=t_std)
+    ref0, keep = cpu_ref.detection_threshold(lmax.astype(np.float32).astype(float), prof,
+                                             smax.astype(np.float32).astype(float), t_cor, t_std)
+    assert 250 <= len(cat["z0"]) <= 350 and len(cat0["z0"]) > len(cat["z0"])
+    for k in detection.CAT0_COLUMNS:
+        assert np.array_equal(np.asarray(cat0[k], float), np.asarray(ref0[k], float),
+                              equal_nan=True), k
+    n = len(cat["z0"])
+    for k in ("x0", "y0", "z0", "STD"):
+        assert np.array_equal(cat_std[k], ref0[k][n:][keep]), k
+    assert 0 < len(keep) <= len(ref0["z0"]) - n
+    zm, ym, xm = detection.det_correl_min(ctx, d_lmax, t_cor)          # steps.py:935-939
+    assert np.array_equal(zm, cat["z0"]) and np.array_equal(xm, cat["x0"])
+
+
 def test_graft_entry_smoke():
     """The driver's smoke(): small Step chain on the GPU against the oracle."""
     import __graft_entry__

@@ -140,3 +140,34 @@ def test_native_clipped_histogram_is_bit_identical_to_numpy():
         b = thresholds.clipped_histogram_numpy(t)
         np.testing.assert_array_equal(h, b[0])
         np.testing.assert_array_equal(e, b[1])
+
+
+def test_step7_merging_of_std_detections():
+    """Host half of Detection.run's opening (steps.py:983-994): std detections within
+    maxdist_lines of a correl detection are dropped.  detection.unmatched_std against a brute
+    force distance matrix, and the oracle's restatement of :956-994 on a hand-made cube."""
+    from origin_amd import detection
+    rng = np.random.default_rng(5)
+    for n, m in ((0, 7), (9, 0), (40, 60), (300, 500)):
+        cor = {k: rng.integers(0, 30, n) for k in ("x0", "y0", "z0")}
+        std = {k: rng.integers(0, 30, m) for k in ("x0", "y0", "z0")}
+        got = detection.unmatched_std(cor, std, 2.5)
+        if n and m:
+            d2 = sum((std[k][:, None] - cor[k][None, :]) ** 2 for k in ("x0", "y0", "z0"))
+            want = np.flatnonzero(~(d2 <= 2.5 ** 2).any(axis=1))
+        else:
+            want = np.arange(m)
+        np.testing.assert_array_equal(got, want)
+    lmax = np.zeros((4, 3, 5))
+    prof = np.arange(60, dtype=np.uint8).reshape(4, 3, 5)
+    smax = np.zeros((4, 3, 5))
+    lmax[2, 1, 3], lmax[0, 2, 4], lmax[3, 0, 0] = 9.0, 7.5, 7.0       # 7.0 is not > 7.0
+    smax[2, 1, 4], smax[0, 0, 0], smax[1, 1, 1] = 5.0, 6.0, 2.0       # first one is 1 px from a line
+    cat0, keep = cpu_ref.detection_threshold(lmax, prof, smax, 7.0, 3.0)
+    np.testing.assert_array_equal(cat0["z0"], [0, 2, 0, 2])           # np.where order, then std rows
+    np.testing.assert_array_equal(cat0["x0"], [4, 3, 0, 4])
+    np.testing.assert_array_equal(cat0["comp"], [0, 0, 1, 1])
+    np.testing.assert_array_equal(cat0["T_GLR"], [7.5, 9.0, np.nan, np.nan])
+    np.testing.assert_array_equal(cat0["STD"], [np.nan, np.nan, 6.0, 5.0])
+    np.testing.assert_array_equal(cat0["profile"], [prof[0, 2, 4], prof[2, 1, 3], 0, 0])
+    np.testing.assert_array_equal(keep, [0])                          # (0,0,0) survives
