@@ -53,6 +53,18 @@ constexpr int S2_R = 64;           // region side (outputs) of a block
 constexpr int S2_TAP_LOG2 = 12;    // f16 taps are stored times 2^12
 constexpr int S2_ENTRY = 80;       // bytes of one (row, copy) table entry: 40 taps, 5 groups of 8
 
+// -DS2_TIMING: clock64 stamps of block (1, 1, 0), phases 10..25, every wave
+// (tools/s2_phase_times.py; each stamp costs an s_memtime round trip and drains the LDS queue:
+// read the numbers as shares, not as cycle counts)
+#ifdef S2_TIMING
+__device__ long long s2_tim[16 * 8 * 8];
+#define S2_STAMP(k)                                                                             \
+  if (blockIdx.x == 1 && blockIdx.y == 1 && blockIdx.z == 0 && lane == 0 && p >= 10 && p < 26) \
+  s2_tim[((p - 10) * 8 + wave) * 8 + (k)] = clock64()
+#else
+#define S2_STAMP(k)
+#endif
+
 template <int P>
 struct S2Geom {
   static constexpr int H = P - 1;                       // halo
@@ -175,6 +187,7 @@ __global__ __launch_bounds__(512, 1) void spatial2_kernel(const float *__restric
   };
 
   // ---- conversion phase: staged tile -> f16 hi / lo (or bf16) image; taps -> fragment table
+  int p = 0;  // phase counter (kernel scope: the timing stamps inside the lambdas name it)
   auto convert = [&](int slot, float &inv_out) {
     float scale = 1.f, inv = 1.f;
     if constexpr (TERMS == 3) {
@@ -185,6 +198,7 @@ __global__ __launch_bounds__(512, 1) void spatial2_kernel(const float *__restric
       if (gt == 0) maxw[slot ^ 1] = 0u;  // the word the NEXT publish of this group adds to
     }
     inv_out = inv;
+    S2_STAMP(4);
 #pragma unroll
     for (int q = 0; q < G::NQ; ++q) {
       const int e = gt + 256 * q;
@@ -211,6 +225,7 @@ __global__ __launch_bounds__(512, 1) void spatial2_kernel(const float *__restric
         }
       }
     }
+    S2_STAMP(5);
     // table entry (row t = dy + 3, copy cp): G_dy[e + cp], e = 0..39, G_dy[e] = k[dy][e - 7]
     for (int ent = gt; ent < P * 8; ent += 256) {
       const int dy = ent >> 3, cp = ent & 7;
@@ -336,18 +351,22 @@ __global__ __launch_bounds__(512, 1) void spatial2_kernel(const float *__restric
   __syncthreads();
   float inv_cur = 1.f;
   const int nphase = 2 * ((nch + 1) / 2) + 2;
-  for (int p = 0; p < nphase; ++p) {
+  for (p = 0; p < nphase; ++p) {
     const int q = p - grp;
+    S2_STAMP(0);
     if (q >= 0) {
       const int i = q >> 1;
       if ((q & 1) == 0) {
         if (i < ng) convert(i & 1, inv_cur);
       } else if (i < ng) {
         if (i + 1 < ng) prefetch(z0 + grp + 2 * (i + 1));
+        S2_STAMP(1);
         mfma_phase(z0 + grp + 2 * i, inv_cur);
+        S2_STAMP(2);
         if (i + 1 < ng) publish((i + 1) & 1);
       }
     }
+    S2_STAMP(3);
     __syncthreads();
   }
 }
@@ -437,3 +456,9 @@ int origin_spatial_mfma_launch(origin_ctx *ctx, int terms, const float *A, const
   origin_set_error("spatial MFMA kernel: PSF size %d not supported", P);
   return ORIGIN_E_ARG;
 }
+
+#ifdef S2_TIMING
+extern "C" int origin_debug_s2_timing(long long *out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(s2_tim), sizeof(long long) * 16 * 8 * 8);
+}
+#endif
