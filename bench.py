@@ -316,7 +316,10 @@ def main():
                 ex = mfma_per_vox * 32768.0 * vox / avg_s / 1e12
                 extra = dict(executed=round(ex, 1), executed_frac=round(ex / peak, 4),
                              fp32_frac=round(ach / FP32_PEAK_TFLOPS, 4),
-                             arithmetic=glr_precision + " MFMA")
+                             arithmetic=glr_precision + " MFMA",
+                             peak_note="dense f16/bf16 MFMA peak at 2.4 GHz; a bare MFMA chain with "
+                                       "non-zero operands holds 1.98-2.11 GHz = 2.07-2.17 PFLOP/s on "
+                                       "this part (power-managed clock, tools/mfma_clock_probe.hip)")
         # HBM traffic of the dominant kernel: bench.py cannot read PMC counters itself, so it
         # takes the per-launch FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 --pmc passes
         # of this very command (profiles/, tools/summarize_rocprof.py) when the workload is the
