@@ -7,10 +7,14 @@
 // The reference scans three full cubes on the host for what are 10^3..10^5 voxels.  Here the
 // cubes stay in HBM and only the detections leave it: an ordered stream compaction in three
 // launches --
-//   count : one coalesced pass, the number of hits of every 4096-voxel chunk      (HBM bound)
-//   scan  : exclusive prefix over the chunk counts (one block, 64-bit running sum)
+//   count : one coalesced pass, the number of hits of every 4096-voxel chunk and (integer
+//           atomics: exact in any order) of every group of 32 chunks            (HBM bound)
+//   scan  : exclusive prefix over the GROUP counts (one block, 64-bit running sum; scanning the
+//           323 000 chunk counts of a 3681 x 600 x 600 cube in one block took 0.31 ms of a
+//           1.2 ms call, profiles/r02_detect_kernel_stats.csv)
 //   emit  : chunks that hold a hit are read again, a lane owning 16 CONSECUTIVE voxels, so that a
-//           block-wide prefix over the lanes' counts gives the C-order rank of every hit
+//           block-wide prefix over the lanes' counts gives the C-order rank of every hit; the
+//           chunk's own offset is its group's plus the counts of the chunks before it in the group
 // The comparison is made in float64 like the reference's (its threshold is a Python float, the
 // cubes widen exactly); NaN compares false.
 #include <algorithm>
@@ -21,6 +25,7 @@ namespace {
 
 constexpr int WA_EPT = 16;                // voxels per lane
 constexpr int WA_CHUNK = 256 * WA_EPT;    // voxels per block
+constexpr int WA_GROUP = 32;              // chunks per scanned group
 
 typedef float f32x4w __attribute__((ext_vector_type(4)));
 
@@ -33,7 +38,8 @@ __device__ __forceinline__ int wa_block_sum(int v, int *red) {
 }
 
 __global__ __launch_bounds__(256) void where_count_kernel(const float *__restrict__ cube, long n,
-                                                          double thr, int *__restrict__ counts) {
+                                                          double thr, int *__restrict__ counts,
+                                                          int *__restrict__ gcounts) {
   __shared__ int red[4];
   const long base = (long)blockIdx.x * WA_CHUNK;
   int c = 0;
@@ -50,10 +56,13 @@ __global__ __launch_bounds__(256) void where_count_kernel(const float *__restric
     for (long i = base + threadIdx.x; i < n; i += 256) c += (double)cube[i] > thr;
   }
   c = wa_block_sum(c, red);
-  if (threadIdx.x == 0) counts[blockIdx.x] = c;
+  if (threadIdx.x == 0) {
+    counts[blockIdx.x] = c;
+    if (c) atomicAdd(&gcounts[blockIdx.x / WA_GROUP], c);
+  }
 }
 
-// offs[b] = sum of counts[0..b), offs[nblk] = total           one block of 1024 lanes
+// offs[g] = sum of counts[0..g), offs[nblk] = total (here: the group counts)  one block of 1024 lanes
 __global__ __launch_bounds__(1024) void where_scan_kernel(const int *__restrict__ counts,
                                                           long nblk, long *__restrict__ offs) {
   __shared__ long wtot[16];
@@ -100,7 +109,15 @@ __global__ __launch_bounds__(256) void where_emit_kernel(
     int *__restrict__ oz, int *__restrict__ oy, int *__restrict__ ox, float *__restrict__ oval,
     uint8_t *__restrict__ oaux) {
   __shared__ int wsum[4];
+  __shared__ int before_s;  // hits of the chunks before this one in its group
   if (counts[blockIdx.x] == 0) return;  // (uniform: the cubes are mostly zeros)
+  if (threadIdx.x < 64) {
+    const int g0 = (int)(blockIdx.x / WA_GROUP) * WA_GROUP, j = (int)threadIdx.x;
+    int v = (j < WA_GROUP && g0 + j < (int)blockIdx.x) ? counts[g0 + j] : 0;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (threadIdx.x == 0) before_s = v;
+  }
   const long base = (long)blockIdx.x * WA_CHUNK + (long)threadIdx.x * WA_EPT;
   float v[WA_EPT];
   if (base + WA_EPT <= n) {
@@ -128,7 +145,7 @@ __global__ __launch_bounds__(256) void where_emit_kernel(
   }
   if (lane == 63) wsum[wave] = incl;
   __syncthreads();
-  long pos = offs[blockIdx.x] + (incl - mine);
+  long pos = offs[blockIdx.x / WA_GROUP] + before_s + (incl - mine);
   for (int w = 0; w < wave; ++w) pos += wsum[w];
 #pragma unroll
   for (int e = 0; e < WA_EPT; ++e) {
@@ -163,18 +180,21 @@ int origin_where_above(origin_ctx *ctx, const float *d_cube, const uint8_t *d_au
   const long S = (long)Ny * Nx, n = (long)Nz * S;
   const long nblk = (n + WA_CHUNK - 1) / WA_CHUNK;
   ORIGIN_CHECK_ARG(nblk < (1L << 31), "cube too large");
-  // [offs: (nblk + 1) x int64 | counts: nblk x int32]
+  const long ngrp = (nblk + WA_GROUP - 1) / WA_GROUP;
+  // [offs: (ngrp + 1) x int64 | group counts: ngrp x int32 | counts: nblk x int32]
   void *scr = nullptr;
-  const size_t ob = (size_t)(nblk + 1) * sizeof(long);
-  int rc = origin_scratch(ctx, ob + (size_t)nblk * sizeof(int), &scr);
+  const size_t ob = (size_t)(ngrp + 1) * sizeof(long), gb = (size_t)ngrp * sizeof(int);
+  int rc = origin_scratch(ctx, ob + gb + (size_t)nblk * sizeof(int), &scr);
   if (rc) return rc;
   long *d_offs = (long *)scr;
-  int *d_counts = (int *)((char *)scr + ob);
+  int *d_gcounts = (int *)((char *)scr + ob);
+  int *d_counts = (int *)((char *)scr + ob + gb);
+  ORIGIN_HIP(hipMemsetAsync(d_gcounts, 0, gb, ctx->stream));
   {
     ProfScope ps(ctx, K_SMALL);
     hipLaunchKernelGGL(where_count_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, d_cube,
-                       n, thr, d_counts);
-    hipLaunchKernelGGL(where_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_counts, nblk,
+                       n, thr, d_counts, d_gcounts);
+    hipLaunchKernelGGL(where_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_gcounts, ngrp,
                        d_offs);
     if (cap > 0)
       hipLaunchKernelGGL(where_emit_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream,
@@ -182,7 +202,7 @@ int origin_where_above(origin_ctx *ctx, const float *d_cube, const uint8_t *d_au
                          d_auxout);
   }
   ORIGIN_LAUNCH_CHECK();
-  ORIGIN_HIP(hipMemcpyAsync(h_count, d_offs + nblk, sizeof(long), hipMemcpyDeviceToHost,
+  ORIGIN_HIP(hipMemcpyAsync(h_count, d_offs + ngrp, sizeof(long), hipMemcpyDeviceToHost,
                             ctx->stream));
   ORIGIN_HIP(hipStreamSynchronize(ctx->stream));
   return ORIGIN_OK;
