@@ -2,6 +2,7 @@
 """Benchmark of the ORIGIN hot path on MI355X:  voxels/s through DCT + PCA + GLR.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus N ...            # starts its own N ranks (one process per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one pass of the whole hot path (Preprocessing -> ComputePCAThreshold ->
@@ -41,12 +42,60 @@ def _gen_chunk(args):
 _gen_chunk.cache = {}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh interpreters of this
+    script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, one GPU each), relay rank 0's JSON
+    line, exit non-zero as soon as any rank fails.  This parent never touches the GPU (no HIP
+    call, no library load) and never replaces itself: the ranks are ordinary children."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    base = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                ORIGIN_RDV_KEY=f"bench{os.getpid()}", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                      env=env, stdout=subprocess.PIPE if r == 0 else
+                                      subprocess.DEVNULL))
+    failed = None
+    live = set(range(n))
+    while live and failed is None:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0:
+                failed = (r, rc)
+                break
+        else:
+            time.sleep(0.05)
+        if procs[0].stdout is not None and 0 not in live and failed is None and live:
+            pass   # rank 0 is done; its pipe is read below
+    if failed is not None:
+        for r in live:          # exactly the children started above
+            procs[r].terminate()
+        for r in live:
+            try:
+                procs[r].wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+        sys.stderr.write(f"bench.py: rank {failed[0]} exited with code {failed[1]}; "
+                         "the other ranks were stopped\n")
+        raise SystemExit(1)
+    out = procs[0].stdout.read().decode()
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    if len(lines) != 1:
+        sys.stderr.write("bench.py: rank 0 did not print exactly one JSON line\n" + out[-2000:])
+        raise SystemExit(1)
+    print(lines[0], flush=True)
+
+
 def main():
-    # stdout must carry exactly ONE JSON line: anything libraries print there (gloo/RCCL
-    # banners) is diverted to stderr until the line is written
-    sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -71,11 +120,18 @@ def main():
                     help="side of the square PCA areas (development: 128 makes area rows "
                          "cache-line aligned)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus)
+    # stdout must carry exactly ONE JSON line: anything libraries print there (RCCL banners) is
+    # diverted to stderr until the line is written
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     Nz, N = args.nz, args.size
@@ -84,16 +140,25 @@ def main():
     nworkers = max(1, min(12, (os.cpu_count() or 8) // max(1, min(world, 8)) - 1))
     pool = mp.get_context("fork").Pool(nworkers)
 
-    # rehearsal on a 1-GPU box: every rank on GPU 0, strips host-staged over gloo
+    # rehearsal on a 1-GPU box (ORIGIN_BENCH_SHARE_GPU=1): every rank on GPU 0, strips staged
+    # through the host -- the line then says n_gpus 1 and names the transport.  Otherwise every
+    # rank owns a device of its own and the strips go over RCCL, or the run fails.
     share_gpu = os.environ.get("ORIGIN_BENCH_SHARE_GPU") == "1"
     comm = None
     if world > 1:
         from origin_amd import multigpu
-        comm = multigpu.init_comm(rank, world, local_rank, backend="gloo" if share_gpu else None)
+        comm = multigpu.init_comm(rank, world, local_rank, backend="host" if share_gpu else "rccl")
 
     from origin_amd import kernels, pipeline
-    from origin_amd.device import Context
+    from origin_amd.device import Context, device_count
 
+    if world > 1 and not share_gpu:
+        ndev = device_count()
+        enough = comm.group.allreduce(np.array([float(ndev >= world)]), "min")[0] == 1.0
+        if not enough:
+            raise SystemExit(f"bench.py --gpus {world}: rank {rank} sees {ndev} device(s); every "
+                             "rank needs a GPU of its own (ORIGIN_BENCH_SHARE_GPU=1 rehearses "
+                             "the tiling on one card over host-staged strips)")
     ctx = Context(local_rank if (world > 1 and not share_gpu) else 0)
     field = synth.SyntheticField(*field_args)
 
@@ -138,7 +203,10 @@ def main():
                                field.profiles, pcut=1e-8, pmeansub=True,
                                precision=args.glr_precision)
     if comm is not None:
-        comm.attach(ctx)  # RCCL communicator on this context (collective)
+        comm.attach(ctx)  # RCCL communicator on this context (collective; raises on every rank
+        #                   if any rank cannot create it)
+        if not share_gpu and not (comm.backend == "rccl" and comm.device_p2p):
+            raise SystemExit("bench.py: the strips would not go over RCCL")
 
     cube_std = ctx.empty((Nz, ny, nx), np.float32)
     cont_dct = ctx.empty((Nz, ny, nx), np.float32)
@@ -490,7 +558,7 @@ def main():
             "metric": "voxels/s through DCT+PCA+GLR (ORIGIN hot path)",
             "value": round(value, 1),
             "unit": "voxels/s",
-            "n_gpus": world,
+            "n_gpus": 1 if share_gpu else world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),

@@ -314,6 +314,16 @@ int origin_glr_plan_destroy(origin_glr_plan *plan);
 int origin_glr_plan_set_precision(origin_glr_plan *plan, int precision);
 int origin_glr_plan_get_precision(origin_glr_plan *plan, int *precision);
 int origin_glr_plan_bytes(origin_glr_plan *plan, size_t *bytes);
+/* Matrix-core instructions (v_mfma_f32_32x32x16_{f16,bf16}: 32768 flop each) ONE run of the plan
+ * issues in its spatial / spectral stage -- what rocprofv3's SQ_INSTS_MFMA counts per launch
+ * (partial edge tiles included); 0 for a stage that runs the fp32 kernels or the weighted forms.
+ * bench.py prices `roofline.executed` with it (measurement). */
+int origin_glr_plan_mfma_count(origin_glr_plan *plan, long *spatial, long *spectral);
+/* The same arithmetic without a plan or a device (host only: num_cu compute units, `terms` = 3
+ * for the f16 split, 1 for bf16; n_narrow = profiles of half width <= 16): lets the CPU tests
+ * check bench.py's `executed` against the counter passes committed under profiles/. */
+int origin_glr_mfma_count_model(int num_cu, int terms, int K, int n_narrow, int Nz, int Ny, int Nx,
+                                int P, long *spatial, long *spectral);
 
 /* correl = max_k T_k, profile = first argmax_k, correl_min = min_k T_k (lib :1205-1212).
  * If d_mask != NULL the ComputeTGLR glue is fused: correl[mask] = 0, profile[mask] = 0

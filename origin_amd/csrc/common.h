@@ -114,6 +114,7 @@ int origin_spatial_mfma_ok(int Ny, int Nx, int P);
 int origin_spatial_mfma_launch(origin_ctx *ctx, int terms, const float *A, const float *W,
                                const float *taps, int Nz, int Ny, int Nx, int P, int accf,
                                float *out);
+long origin_spatial_mfma_count(int terms, int Nz, int Ny, int Nx, int P);
 
 #define ORIGIN_CHECK_ARG(cond, ...)       \
   do {                                    \

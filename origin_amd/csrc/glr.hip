@@ -1108,6 +1108,30 @@ int origin_glr_plan_get_precision(origin_glr_plan *plan, int *precision) {
   return ORIGIN_OK;
 }
 
+int origin_glr_plan_mfma_count(origin_glr_plan *plan, long *spatial, long *spectral) {
+  ORIGIN_CHECK_ARG(plan && spatial && spectral, "null argument");
+  const origin_glr_plan *pl = plan;
+  *spatial = *spectral = 0;
+  // the same conditions as origin_glr_run
+  if (pl->precision >= 1 && pl->mode == 0 && pl->nfields == 1 &&
+      origin_spatial_mfma_ok(pl->Ny, pl->Nx, pl->P))
+    *spatial = origin_spatial_mfma_count(pl->precision == 2 ? 1 : 3, pl->Nz, pl->Ny, pl->Nx, pl->P);
+  if (pl->precision >= 1 && pl->mode == 0 && pl->d_atab && pl->d_rdi)
+    *spectral = origin_spectral_mfma_count(pl->ctx->num_cu, pl->precision == 2 ? 1 : 3, pl->K,
+                                           pl->n_narrow, pl->Nz, pl->Ny, pl->Nx);
+  return ORIGIN_OK;
+}
+
+int origin_glr_mfma_count_model(int num_cu, int terms, int K, int n_narrow, int Nz, int Ny, int Nx,
+                                int P, long *spatial, long *spectral) {
+  ORIGIN_CHECK_ARG(spatial && spectral && num_cu > 0 && (terms == 1 || terms == 3) && K > 0 &&
+                       n_narrow >= 0 && n_narrow <= K && Nz > 0 && Ny > 0 && Nx > 0 && P > 0,
+                   "bad arguments");
+  *spatial = origin_spatial_mfma_ok(Ny, Nx, P) ? origin_spatial_mfma_count(terms, Nz, Ny, Nx, P) : 0;
+  *spectral = origin_spectral_mfma_count(num_cu, terms, K, n_narrow, Nz, Ny, Nx);
+  return ORIGIN_OK;
+}
+
 int origin_glr_plan_bytes(origin_glr_plan *plan, size_t *bytes) {
   ORIGIN_CHECK_ARG(plan && bytes, "null argument");
   *bytes = plan->bytes;

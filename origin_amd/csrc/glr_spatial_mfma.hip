@@ -457,6 +457,15 @@ int origin_spatial_mfma_launch(origin_ctx *ctx, int terms, const float *A, const
   return ORIGIN_E_ARG;
 }
 
+// MFMA instructions one launch issues (what SQ_INSTS_MFMA counts): every 64 x 64 region of the
+// field (partial ones at the edges included) runs, per channel, four waves of
+// (4 + P - 1) x ceil((8 + P - 1) / 16) k-steps with `terms` MFMAs each.
+long origin_spatial_mfma_count(int terms, int Nz, int Ny, int Nx, int P) {
+  const long regions = (long)cdiv(Nx, S2_R) * cdiv(Ny, S2_R);
+  const long nks = (long)(4 + P - 1) * ((8 + P - 1 + 15) / 16);
+  return regions * Nz * 4 * nks * terms;
+}
+
 #ifdef S2_TIMING
 extern "C" int origin_debug_s2_timing(long long *out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(s2_tim), sizeof(long long) * 16 * 8 * 8);

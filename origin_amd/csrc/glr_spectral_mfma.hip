@@ -584,21 +584,14 @@ __global__ __launch_bounds__(64 * MF_WAVES, 1) void spectral_mfma2_kernel(
 
 }  // namespace
 
-// Launch: a wave = 32 spaxels x 32-channel tiles (two 16-channel halves); z chunks sized to give every CU several blocks
-// (one block per CU at a time: K * (4.5 KiB + MF_WAVES * 128 B) of LDS).  Returns the number of z
-// chunks (rows of part_max / part_min) in *nzc.  nN: number of narrow profiles (the first nN
-// slots of the processing order).
-int origin_spectral_mfma_launch(origin_ctx *ctx, int terms, const float *fsf, const float *rden,
-                                const float *rdi_s, int NzP, const uint4 *atab, const int *pinfo,
-                                int K, int nN, int Nz, int Ny, int Nx, int P, const uint8_t *mask,
-                                float *correl, uint8_t *profile, float *correl_min, float *part,
-                                bool want_maps, int *nzc_out, float **pmax_out, float **pmin_out) {
-  const long S = (long)Ny * Nx;
+// Grid of the spectral kernel: bx blocks of MF_WAVES waves (32 spaxels each) x nzm chunks of zcm
+// channels.  One block per CU at a time (LDS): the number of z chunks is picked so that the
+// blocks fill whole rounds of the chip -- useful channel slots / (rounds x CUs x (chunk length +
+// ~one tile of start-up per block)); chunks are whole 32-channel tiles, at most 64 of them
+// (partial maps).  Shared by the launch and by origin_spectral_mfma_count.
+static void sm_geometry(int num_cu, int Nz, long S, long *bx_out, int *nzm_out, int *zcm_out) {
   const long bx = cdiv(S, 32 * MF_WAVES);
-  // One block per CU at a time (LDS): pick the number of z chunks so that the blocks fill whole
-  // rounds of the chip -- useful channel slots / (rounds x CUs x (chunk length + ~one tile of
-  // start-up per block)); chunks are whole 32-channel tiles, at most 64 of them (partial maps)
-  const int ncu = std::max(1, ctx->num_cu);
+  const int ncu = std::max(1, num_cu);
   int nzm = 1;
   double best_eff = 0.0;
   for (int n = 1; n <= std::min(64, std::max(1, cdiv(Nz, 64))); ++n) {
@@ -609,7 +602,45 @@ int origin_spectral_mfma_launch(origin_ctx *ctx, int terms, const float *fsf, co
     if (eff > best_eff * 1.0001) best_eff = eff, nzm = n;
   }
   const int zcm = (cdiv(Nz, nzm) + 31) / 32 * 32;
-  nzm = cdiv(Nz, zcm);
+  *bx_out = bx;
+  *nzm_out = cdiv(Nz, zcm);
+  *zcm_out = zcm;
+}
+
+// MFMA instructions one launch issues (what SQ_INSTS_MFMA counts): every wave that holds a
+// spaxel walks all 32-channel tiles of its chunk; a tile is two 16-channel halves, a half runs
+// every profile pair (slots 2p, 2p+1 of the processing order, narrow profiles first) with 3
+// k-steps (both narrow: window blocks 1..3) or 5, `terms` MFMAs per k-step.
+long origin_spectral_mfma_count(int num_cu, int terms, int K, int n_narrow, int Nz, int Ny,
+                                int Nx) {
+  const long S = (long)Ny * Nx;
+  long bx;
+  int nzm, zcm;
+  sm_geometry(num_cu, Nz, S, &bx, &nzm, &zcm);
+  long tiles = 0;  // 32-channel tiles per wave, over all chunks
+  for (int c = 0; c < nzm; ++c) tiles += cdiv(std::min(zcm, Nz - c * zcm), 32);
+  long ksteps = 0;
+  for (int p = 0; p < (K + 1) / 2; ++p) {
+    const int sb = std::min(2 * p + 1, K - 1);
+    ksteps += sb >= n_narrow ? 5 : 3;  // (slot sb is the wider of the pair)
+  }
+  const long waves = cdiv(S, 32);
+  return waves * tiles * 2 * ksteps * terms;
+}
+
+// Launch: a wave = 32 spaxels x 32-channel tiles (two 16-channel halves); z chunks sized to give every CU several blocks
+// (one block per CU at a time: K * (4.5 KiB + MF_WAVES * 128 B) of LDS).  Returns the number of z
+// chunks (rows of part_max / part_min) in *nzc.  nN: number of narrow profiles (the first nN
+// slots of the processing order).
+int origin_spectral_mfma_launch(origin_ctx *ctx, int terms, const float *fsf, const float *rden,
+                                const float *rdi_s, int NzP, const uint4 *atab, const int *pinfo,
+                                int K, int nN, int Nz, int Ny, int Nx, int P, const uint8_t *mask,
+                                float *correl, uint8_t *profile, float *correl_min, float *part,
+                                bool want_maps, int *nzc_out, float **pmax_out, float **pmin_out) {
+  const long S = (long)Ny * Nx;
+  long bx;
+  int nzm, zcm;
+  sm_geometry(ctx->num_cu, Nz, S, &bx, &nzm, &zcm);
   float *pmax = want_maps ? part : nullptr;
   float *pmin = want_maps ? part + (size_t)nzm * S : nullptr;
   const size_t lds = (size_t)K * (MF_PROF_BYTES + MF_WAVES * MF_RD_BYTES);

@@ -1344,7 +1344,8 @@ __global__ __launch_bounds__(1024) void lanczos_kernel(const double *__restrict_
                                                        double *__restrict__ info,
                                                        const double *__restrict__ slab,
                                                        long slab_stride, int ksplit,
-                                                       int power_nmax) {
+                                                       int power_nmax,
+                                                       double *__restrict__ dbg = nullptr) {
   __shared__ double alpha[LANCZOS_M], beta[LANCZOS_M], h[LANCZOS_M + 1];
   __shared__ TriWork ws;
   __shared__ double red[16];
@@ -1356,6 +1357,8 @@ __global__ __launch_bounds__(1024) void lanczos_kernel(const double *__restrict_
   const int n = (int)n_[k], ld = (int)ld_[k];
   if (n < 1) return;  // (n == 1 is a valid 1 x 1 problem for origin_pca_eig; the PCA loop never
                       // sends fewer than two columns except for areas that have just finished)
+  const unsigned long long t_dbg = dbg ? wall_clock64() : 0ull;  // 100 MHz
+  int steps_dbg = 0;
   const double *Gk = G + g_off[k];
   double *Qk;  // (LANCZOS_M + 2) rows of length ld; last row = Ritz vector
   if constexpr (QLDS) Qk = lz_dyn;
@@ -1398,10 +1401,12 @@ __global__ __launch_bounds__(1024) void lanczos_kernel(const double *__restrict_
       __syncthreads();
     }
     eig_small_power(n, ld, sw, v, info ? info + 3 * k : nullptr);
+    if (dbg && threadIdx.x == 0) dbg[2 * k] = -1.0, dbg[2 * k + 1] = (double)(wall_clock64() - t_dbg) * 0.01;
     return;
   }
   if (n <= power_nmax) {  // mid-size matrix: repeated squaring with both buffers in LDS
     eig_mid_power(Gk, n, ld, lz_dyn, v, info ? info + 3 * k : nullptr);
+    if (dbg && threadIdx.x == 0) dbg[2 * k] = -2.0, dbg[2 * k + 1] = (double)(wall_clock64() - t_dbg) * 0.01;
     return;
   }
   const int mfull = min(LANCZOS_M, n);
@@ -1539,6 +1544,7 @@ __global__ __launch_bounds__(1024) void lanczos_kernel(const double *__restrict_
       y[e] = acc;
     }
     resid = fabs(beta_last * svec[m - 1]);
+    steps_dbg += m;
     __syncthreads();
     if (m >= n || resid <= tol * fabs(theta)) break;
   }
@@ -1554,6 +1560,7 @@ __global__ __launch_bounds__(1024) void lanczos_kernel(const double *__restrict_
     info[3 * k + 1] = resid;
     info[3 * k + 2] = (double)restarts;
   }
+  if (tid == 0 && dbg) dbg[2 * k] = (double)steps_dbg, dbg[2 * k + 1] = (double)(wall_clock64() - t_dbg) * 0.01;
 }
 
 // ------------------------------------------------------------------------------------
@@ -1881,7 +1888,7 @@ struct PcaWorkspace {
 int eig_launch(origin_ctx *ctx, int nmat, long ldmax, const double *d_G, const long *d_g_off,
                const long *d_ld, const long *d_n, double *d_q, const long *d_q_off, double *d_v,
                const long *d_v_off, double *d_info, const double *d_slab = nullptr,
-               long slab_stride = 0, int ksplit = 0) {
+               long slab_stride = 0, int ksplit = 0, double *d_dbg = nullptr) {
   static bool attr_done = false;
   if (!attr_done) {
     // dynamic + static LDS must stay within the 160 KB of a CU: ask for exactly what is used
@@ -1901,12 +1908,12 @@ int eig_launch(origin_ctx *ctx, int nmat, long ldmax, const double *d_G, const l
     if (mid) lds = std::max(lds, PW_BYTES);
     hipLaunchKernelGGL(lanczos_kernel<true>, dim3(nmat), dim3(1024), lds, ctx->stream, d_G, d_g_off,
                        d_ld, d_n, d_q, d_q_off, d_v, d_v_off, 60, 1e-14, d_info, d_slab, slab_stride,
-                       ksplit, mid ? PW_N : 0);
+                       ksplit, mid ? PW_N : 0, d_dbg);
   } else {
     hipLaunchKernelGGL(lanczos_kernel<false>, dim3(nmat), dim3(1024),
                        std::max(sizeof(SmallWork), PW_BYTES), ctx->stream, d_G, d_g_off, d_ld, d_n,
                        d_q, d_q_off, d_v, d_v_off, 60, 1e-14, d_info, d_slab, slab_stride, ksplit,
-                       PW_N);
+                       PW_N, d_dbg);
   }
   ORIGIN_LAUNCH_CHECK();
   return ORIGIN_OK;
@@ -2381,20 +2388,28 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
       scr = b_part.p;
       double *d_info = nullptr;
       if (debug) {
-        if ((rc = b_info.reserve(ctx, (size_t)3 * nw * sizeof(double)))) return rc;
+        if ((rc = b_info.reserve(ctx, (size_t)5 * nw * sizeof(double)))) return rc;
         d_info = (double *)b_info.p;
       }
       {
         ProfScope ps(ctx, K_PCA_EIG, 2);
         if ((rc = eig_launch(ctx, nw, ldmax, d_G, dG, dLD, dN, (double *)scr, dQ, d_v, dC, d_info,
-                             all_small ? d_slab : nullptr, g, gram_ksplit)))
+                             all_small ? d_slab : nullptr, g, gram_ksplit,
+                             debug ? d_info + (size_t)3 * nw : nullptr)))
           return rc;
       }
       if (debug) {
-        std::vector<double> info((size_t)3 * nw);
+        std::vector<double> info((size_t)5 * nw);
         ORIGIN_HIP(hipMemcpyAsync(info.data(), d_info, info.size() * sizeof(double),
                                   hipMemcpyDeviceToHost, st));
         ORIGIN_HIP(hipStreamSynchronize(st));
+        if (getenv("ORIGIN_PCA_DEBUG_EIG")) {  // per matrix: n:steps:restarts:us
+          fprintf(stderr, "[pca-eig] iter %d:", iters);
+          for (int w = 0; w < nw; ++w)
+            fprintf(stderr, " %d:%.0f:%.0f:%.0f", (int)D[(size_t)DF_N * nw + w], info[3 * nw + 2 * w],
+                    info[3 * w + 2], info[3 * nw + 2 * w + 1]);
+          fprintf(stderr, "\n");
+        }
         double rmax = 0, rsum = 0, resmax = 0;
         int nmax = 0;
         for (int w = 0; w < nw; ++w) {

@@ -6,6 +6,13 @@ import numpy as np
 from . import _capi
 
 
+def device_count():
+    """Number of GPUs this process can see (origin_device_count)."""
+    n = C.c_int(0)
+    _capi.call("origin_device_count", C.byref(n))
+    return n.value
+
+
 class Context:
     """One GPU, one stream (include/origin_hip.h: origin_ctx)."""
 
@@ -219,8 +226,7 @@ class DeviceArray:
     def copy(self):
         return DeviceArray(self.ctx, self.shape, self.dtype).copy_from(self)
 
-    # interop: lets torch.as_tensor / cupy view the buffer without a copy (used for RCCL
-    # collectives through torch.distributed; never needed on a single GPU)
+    # interop: any consumer of the array-interface protocol can view the buffer without a copy
     @property
     def __cuda_array_interface__(self):
         return dict(shape=self.shape, typestr=self.dtype.str, data=(self.ptr, False), version=3,

@@ -180,6 +180,13 @@ class GLRPlan:
             w is None or (self.precision == "f16x2" and len(self.tap_lengths) <= 26
                           and max(self.tap_lengths) <= 65))
 
+    def mfma_count(self):
+        """(spatial, spectral): matrix-core instructions (32768 flop each) one run issues per
+        stage -- rocprofv3's SQ_INSTS_MFMA per launch; 0 for a stage on the fp32 kernels."""
+        a, b = C.c_long(), C.c_long()
+        _capi.call("origin_glr_plan_mfma_count", self._h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
     def close(self):
         if self._h is not None and self._h.value:
             _capi.load().origin_glr_plan_destroy(self._h)

@@ -17,9 +17,8 @@ with respect to the *true* field border because kept spaxels are at least P//2 a
 internal cut.  Only the interior tile is kept.
 
 Strips and the all-reduce go through RCCL called natively on the library's own stream
-(``origin_comm_*``, csrc/comm.hip); ``torch.distributed`` (gloo) is only the host-side
-rendezvous that carries the RCCL unique id, barriers and a few scalars -- see ``TileComm``.
-torch is imported only here and only when more than one rank exists.
+(``origin_comm_*``, csrc/comm.hip); the host-side rendezvous that carries the RCCL unique id,
+barriers and a few scalars is ``rendezvous.HostGroup`` (plain sockets) -- see ``TileComm``.
 """
 import os
 from collections import namedtuple
@@ -89,35 +88,35 @@ class Tiling:
 class TileComm:
     """Exchange layer of the tiled path.
 
-    Host side: a ``torch.distributed`` **gloo** group (rendezvous, barrier, a handful of host
-    scalars).  torch's GPU runtime is never touched: the wheel bundles its own ROCr/HIP, and
-    two ROCr instances cannot both acquire the GPU VM in one process -- whichever initialises
-    second reports "no GPU".  The cubes are this library's, so the device side is this
-    library's too:
+    Host side: a ``rendezvous.HostGroup`` (plain sockets: the RCCL unique id from rank 0,
+    barriers, a handful of host scalars) -- or any object with the same five methods
+    (``broadcast, allreduce, barrier, exchange, close``; the tests also run a
+    gloo adaptor of their own through here).  The package itself has no such dependency.
+    The cubes are this library's, so the device side is this library's too:
 
     * ``backend="rccl"`` (default): a native RCCL communicator on the context's stream
-      (``origin_comm_*`` in include/origin_hip.h), created lazily at the first device
-      operation (the context exists only then); its unique id travels over the gloo group.
-      Strips go GPU to GPU over xGMI; nothing is synchronised on the host.
-    * ``backend="gloo"``: strips are staged through host memory (CPU tests; one-GPU
-      rehearsal with several ranks on the same card, which RCCL refuses; fallback when the
-      RCCL communicator cannot be created on *any* rank -- all ranks then switch together).
+      (``origin_comm_*`` in include/origin_hip.h), created at the first device operation (the
+      context exists only then); its unique id travels over the host group.  Strips go GPU to
+      GPU over xGMI; nothing is synchronised on the host.  If the communicator cannot be
+      created on ANY rank, EVERY rank raises: there is no silent change of transport.
+    * ``backend="host"``: strips are staged through host memory and the host group (CPU
+      tests; one-GPU rehearsal with several ranks on the same card, which RCCL refuses).
+      Only on request.  (``"gloo"``, the name rounds 1-2 used, is accepted as an alias.)
     """
 
-    def __init__(self, rank, world, local_rank, backend=None):
-        import torch
-        import torch.distributed as dist
-        self.torch, self.dist = torch, dist
+    def __init__(self, rank, world, local_rank, backend=None, group=None):
         self.rank, self.world, self.local_rank = rank, world, local_rank
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL
-        backend = backend or "rccl"
-        if backend not in ("rccl", "gloo"):
-            raise ValueError(f"backend must be 'rccl' or 'gloo', not {backend!r}")
+        backend = {None: "rccl", "gloo": "host"}.get(backend, backend)
+        if backend not in ("rccl", "host"):
+            raise ValueError(f"backend must be 'rccl' or 'host', not {backend!r}")
         self.note = ""
-        if not dist.is_initialized():
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        if group is None:
+            from . import rendezvous
+            group = rendezvous.HostGroup(rank, world)
+        self.group = group
         self._want_rccl = backend == "rccl"
         self._native = None          # origin_comm* once attached
         self._ctx = None
@@ -129,64 +128,52 @@ class TileComm:
 
     # -- native communicator -----------------------------------------------------
     def attach(self, ctx):
-        """Create the RCCL communicator on ``ctx`` (collective; no-op for gloo or when
-        already attached).  If any rank fails, every rank falls back to host staging."""
+        """Create the RCCL communicator on ``ctx`` (collective; no-op for the host backend or
+        when already attached).  If any rank fails, every rank raises."""
         if not self._want_rccl or self._native is not None:
             return
         import ctypes as C
-        torch, dist = self.torch, self.dist
-        ident = torch.zeros(_capi.COMM_ID_BYTES + 1, dtype=torch.uint8)
         err = ""
         # ncclCommInitRank is collective: a rank that cannot even load librccl would leave the
         # others waiting inside it.  Every rank first proves it can reach the library (a
         # throw-away unique id); only if all can is the communicator created.
-        probe = 1
+        probe = 1.0
         try:
             _capi.call("origin_comm_unique_id", C.create_string_buffer(_capi.COMM_ID_BYTES))
-        except Exception as exc:  # noqa: BLE001 -- reported through `note`
-            probe, err = 0, str(exc)
-        pflag = torch.tensor([probe], dtype=torch.int32)
-        dist.all_reduce(pflag, op=dist.ReduceOp.MIN)
-        if int(pflag[0]) != 1:
-            self._want_rccl = False
-            self.backend = "gloo"
-            self.note = "rccl unavailable (" + (err or "failed on another rank") + \
-                        "); host staging over gloo"
-            return
+        except Exception as exc:  # noqa: BLE001 -- re-raised on every rank below
+            probe, err = 0.0, str(exc)
+        if self.group.allreduce(np.array([probe]), "min")[0] != 1.0:
+            raise _capi.OriginHipError(-5, "RCCL is not reachable on every rank (" +
+                                       (err or "failed on another rank") + ")")
+        ident = b""
         if self.rank == 0:
             buf = C.create_string_buffer(_capi.COMM_ID_BYTES)
             try:
                 _capi.call("origin_comm_unique_id", buf)
-                ident[:-1] = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8)
-                ident[-1] = 1
-            except Exception as exc:  # noqa: BLE001 -- reported through `note`
-                err = str(exc)
-        dist.broadcast(ident, src=0)
-        handle, ok = C.c_void_p(), 0
-        if int(ident[-1]) == 1:
-            try:
-                _capi.call("origin_comm_create", ctx.handle, bytes(ident[:-1].numpy().tobytes()),
-                           self.rank, self.world, C.byref(handle))
-                ok = 1
+                ident = bytes(buf.raw)
             except Exception as exc:  # noqa: BLE001
                 err = str(exc)
-        flag = torch.tensor([ok], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag[0]) == 1:
+        ident = self.group.broadcast(ident, src=0)
+        handle, ok = C.c_void_p(), 0.0
+        if len(ident) == _capi.COMM_ID_BYTES:
+            try:
+                _capi.call("origin_comm_create", ctx.handle, ident, self.rank, self.world,
+                           C.byref(handle))
+                ok = 1.0
+            except Exception as exc:  # noqa: BLE001
+                err = str(exc)
+        if self.group.allreduce(np.array([ok]), "min")[0] == 1.0:
             self._native, self._ctx = handle, ctx
-        else:
-            if ok:
-                _capi.call("origin_comm_destroy", handle)
-            self._want_rccl = False
-            self.backend = "gloo"
-            self.note = "rccl unavailable (" + (err or "failed on another rank") + \
-                        "); host staging over gloo"
+            return
+        if ok:
+            _capi.call("origin_comm_destroy", handle)
+        raise _capi.OriginHipError(-5, "the RCCL communicator could not be created on every rank (" +
+                                   (err or "failed on another rank") + "); host-staged strips "
+                                   "are only used when asked for (backend='host')")
 
     # -- small host collectives ------------------------------------------------
     def allreduce_sum(self, arr):
-        t = self.torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64).copy())
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        return t.numpy()
+        return self.group.allreduce(arr, "sum")
 
     def allreduce_sum_device(self, ctx, arrays):
         """In-place sum over ranks of float64 DeviceArrays (per-channel sum and count)."""
@@ -202,19 +189,18 @@ class TileComm:
             o += a.size
 
     def max_float(self, x):
-        t = self.torch.tensor([float(x)], dtype=self.torch.float64)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t[0])
+        return float(self.group.allreduce(np.array([float(x)]), "max")[0])
 
     def barrier(self):
-        self.dist.barrier()
+        self.group.barrier()
 
     def close(self):
         if self._native is not None:
             _capi.call("origin_comm_destroy", self._native)
             self._native = None
-        if self.dist.is_initialized():
-            self.dist.destroy_process_group()
+        if self.group is not None:
+            self.group.close()
+            self.group = None
 
     # -- strip exchange ----------------------------------------------------------
     def exchange(self, ctx, sends, recvs):
@@ -235,24 +221,15 @@ class TileComm:
             nr, rp, rb, rl = pack(recvs)
             _capi.call("origin_comm_exchange", self._native, ns, sp, sb, sl, nr, rp, rb, rl)
             return
-        torch, dist = self.torch, self.dist
-        ops, host_recv = [], []
-        for peer, buf in recvs:
-            t = torch.empty(buf.shape, dtype=torch.float32)
-            host_recv.append((t, buf))
-            ops.append(dist.P2POp(dist.irecv, t, peer))
-        for peer, buf in sends:
-            ops.append(dist.P2POp(dist.isend, torch.from_numpy(buf.to_host()), peer))
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
-        for t, buf in host_recv:
-            buf.upload(t.numpy())
+        host_recv = [(peer, np.empty(buf.shape, np.float32), buf) for peer, buf in recvs]
+        self.group.exchange([(peer, buf.to_host()) for peer, buf in sends],
+                            [(peer, h) for peer, h, _ in host_recv])
+        for _, h, buf in host_recv:
+            buf.upload(h)
 
 
-
-
-def init_comm(rank, world, local_rank, backend=None):
-    return TileComm(rank, world, local_rank, backend)
+def init_comm(rank, world, local_rank, backend=None, group=None):
+    return TileComm(rank, world, local_rank, backend, group)
 
 
 # ------------------------------------------------------------------------------- halo
@@ -324,9 +301,8 @@ def exchange_halo(ctx, comm, tiling, rank, cube, ext=None, bufs=None):
 
 
 def exchange_halo_host(comm, tiling, rank, tile):
-    """Same exchange on host ndarrays (float64 allowed) -- used by the CPU (gloo) tests to
-    check the tiling arithmetic against the untiled oracle."""
-    torch, dist = comm.torch, comm.dist
+    """Same exchange on host ndarrays (float64 allowed) -- used by the CPU tests to check the
+    tiling arithmetic against the untiled oracle."""
     Nz, ny, nx = tile.shape
     (_, _, _, _), (top, bot, left, right) = tiling.extended(rank)
     ext = np.zeros((Nz, ny + top + bot, nx + left + right), dtype=tile.dtype)
@@ -334,20 +310,18 @@ def exchange_halo_host(comm, tiling, rank, tile):
     plan = halo_plan(tiling, rank, ny, nx)
     for phase in (0, 1):
         src = tile if phase == 0 else ext
-        ops, pending = [], []
+        sends, recvs, pending = [], [], []
         for ph, peer, (sy, sx), (dy, dx), (by, bx) in plan:
             if ph != phase:
                 continue
-            sbuf = torch.from_numpy(np.ascontiguousarray(src[:, sy: sy + by, sx: sx + bx]))
-            rbuf = torch.empty((Nz, by, bx), dtype=sbuf.dtype)
+            sends.append((peer, np.ascontiguousarray(src[:, sy: sy + by, sx: sx + bx])))
+            rbuf = np.empty((Nz, by, bx), dtype=tile.dtype)
+            recvs.append((peer, rbuf))
             pending.append((rbuf, dy, dx, by, bx))
-            ops.append(dist.P2POp(dist.irecv, rbuf, peer))
-            ops.append(dist.P2POp(dist.isend, sbuf, peer))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
+        if sends:
+            comm.group.exchange(sends, recvs)
         for rbuf, dy, dx, by, bx in pending:
-            ext[:, dy: dy + by, dx: dx + bx] = rbuf.numpy()
+            ext[:, dy: dy + by, dx: dx + bx] = rbuf
     return ext
 
 

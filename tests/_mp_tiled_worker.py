@@ -1,10 +1,12 @@
-"""Worker of the multi-process tiling tests (one process per rank, torch.distributed).
+"""Worker of the multi-process tiling tests (one process per rank).  The host group is the
+package's socket rendezvous, or torch.distributed/gloo behind the same methods
+(TILED_GROUP=gloo, tests/_gloo_group.py).
 
-mode 'cpu' : host arrays + the CPU oracle per tile (gloo) -- checks the tiling arithmetic
+mode 'cpu' : host arrays + the CPU oracle per tile -- checks the tiling arithmetic
              (area-aligned tiles, global per-channel mean, two-phase halo exchange, border
              classes of the extended tile) against the untiled oracle, bit-for-bit level.
 mode 'gpu' : the same decomposition through the HIP path (all ranks share GPU 0, strips are
-             host-staged over gloo) against the single-context HIP result.
+             host-staged through the host group) against the single-context HIP result.
 mode 'rccl': one GPU per rank, native RCCL communicator on the library's stream: device
              all-reduce of the per-channel sums and GPU-to-GPU halo strips (what bench.py --gpus N
              runs); needs as many devices as ranks.
@@ -44,8 +46,13 @@ def main():
     mode, out = sys.argv[1], sys.argv[2]
     weighted = os.environ.get("TILED_WEIGHTS") == "1"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    group = None
+    if os.environ.get("TILED_GROUP") == "gloo":
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from _gloo_group import GlooGroup
+        group = GlooGroup(rank, world)
     comm = multigpu.init_comm(rank, world, rank if mode == "rccl" else 0,
-                              backend=None if mode == "rccl" else "gloo")
+                              backend="rccl" if mode == "rccl" else "host", group=group)
     f, raw, var, mask = field()
     Nz, Ny, Nx = raw.shape
     tiling = multigpu.Tiling(Ny, Nx, world, area_size=20, halo=f.PSF.shape[1] // 2)

@@ -1,4 +1,5 @@
-"""Tiling / halo-exchange tests: world_size 2 and 4 over gloo.
+"""Tiling / halo-exchange tests: world_size 2 and 4, over the package's own socket rendezvous
+and over torch.distributed's gloo (tests/_gloo_group.py).
 
 CPU (always): the decomposition run with the CPU oracle per tile equals the untiled oracle.
 GPU (-m gpu): the same decomposition through the HIP kernels (ranks share GPU 0, host-staged
@@ -24,13 +25,13 @@ def free_port():
     return p
 
 
-def run_ranks(mode, world, out, weighted=False):
+def run_ranks(mode, world, out, weighted=False, group="rdv"):
     port = free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0",
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2",
-                   TILED_WEIGHTS="1" if weighted else "0")
+                   TILED_WEIGHTS="1" if weighted else "0", TILED_GROUP=group)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests",
                                                                     "_mp_tiled_worker.py"),
                                        mode, out], env=env, stdout=subprocess.PIPE,
@@ -73,12 +74,12 @@ def test_tiling_follows_area_grid():
         Tiling(100, 100, 4, area_size=100)
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_tiled_oracle_equals_untiled_oracle(tmp_path, world):
+@pytest.mark.parametrize("world,group", [(2, "rdv"), (4, "rdv"), (2, "gloo"), (4, "gloo")])
+def test_tiled_oracle_equals_untiled_oracle(tmp_path, world, group):
     from _mp_tiled_worker import field
     from oracle import cpu_ref
     f, raw, var, mask = field()
-    tiles = run_ranks("cpu", world, str(tmp_path / "cpu"))
+    tiles = run_ranks("cpu", world, str(tmp_path / "cpu"), group=group)
     ref = cpu_ref.run_chain(raw.astype(float), var.astype(float), mask, f.PSF.astype(float), None,
                             f.profiles, f.areamap, f.nbAreas)
     shape = raw.shape
@@ -178,18 +179,32 @@ def test_tiled_hip_native_rccl_one_gpu_per_rank(tmp_path, world):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("order", ["torch-first", "lib-first"])
-def test_native_rccl_communicator_world1(order):
+def test_native_rccl_communicator_world1():
     """The RCCL path of TileComm at world size 1 (all a one-GPU box allows): communicator from
-    a broadcast unique id, device all-reduce, grouped send/recv to self, on the library's own
-    stream and buffers -- with torch loaded before and after liborigin_hip.so (the two load
-    orders bind different HIP runtimes, see csrc/comm.hip)."""
+    a unique id that went through the host group, device all-reduce, grouped send/recv to
+    self, on the library's own stream and buffers."""
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                MASTER_PORT=str(free_port()))
     cmd = [sys.executable, os.path.join(ROOT, "tools", "rccl_self_check.py")]
-    if order == "lib-first":
-        cmd.append("--lib-first")
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     out = r.stdout.decode()
     assert r.returncode == 0, out[-3000:]
     assert "backend rccl device_p2p True" in out, out[-3000:]
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_card_refuse_rccl_loudly():
+    """RCCL cannot put two ranks on one device: the communicator must fail on EVERY rank with an
+    error (rounds 1-2 switched to host staging silently, which would have produced a scaling
+    curve of the wrong transport with rc 0)."""
+    port = free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NCCL_DEBUG="WARN")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tools",
+                                                                    "rccl_self_check.py")],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode != 0 for p in procs), outs
+    assert all("RCCL" in o for o in outs), outs

@@ -1,14 +1,12 @@
 """Rehearsal of the RCCL path of origin_amd.multigpu on a ONE-GPU box.
 
     python tools/rccl_self_check.py            # world size 1: native communicator, self send
-    python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 \
-        tools/rccl_self_check.py               # 2 ranks on ONE card: RCCL refuses, all ranks
-                                               # must fall back to host staging together
 
-What it can prove: librccl.so opens next to the library's HIP context while torch (gloo
-only) is loaded, the communicator initialises from a broadcast unique id, all-reduce and
-grouped send/recv run on the library's stream on its own buffers.  What it cannot prove: a
-transfer over xGMI between two devices.
+What it can prove: librccl.so opens next to the library's HIP context, the communicator
+initialises from a unique id that went through the host group, all-reduce and grouped
+send/recv run on the library's stream on its own buffers.  What it cannot prove: a transfer
+over xGMI between two devices.  (Two ranks on ONE card: RCCL refuses, and every rank raises
+-- there is no silent change of transport.)
 """
 import os
 import sys
@@ -26,12 +24,8 @@ from origin_amd.device import Context  # noqa: E402
 def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if "--lib-first" in sys.argv:  # liborigin_hip (system ROCm) initialises before torch loads
-        ctx = Context(0)
-        comm = multigpu.init_comm(rank, world, 0, backend="rccl")
-    else:
-        comm = multigpu.init_comm(rank, world, 0, backend="rccl")
-        ctx = Context(0)
+    comm = multigpu.init_comm(rank, world, 0, backend="rccl")
+    ctx = Context(0)
     comm.attach(ctx)
     print(rank, "backend", comm.backend, "device_p2p", comm.device_p2p, comm.note, flush=True)
     a = ctx.to_device(np.arange(5.0) + rank)
