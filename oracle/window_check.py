@@ -37,8 +37,17 @@ def _valid(lo, hi, N, c):
 
 
 def check_glr_window(faint, dev_out, mask, psf, profiles, window, pcut=1e-8, pmeansub=True,
-                     nthreads=1, tol=1e-4, tol_argmax=1e-4, tol_rms=None):
+                     nthreads=1, tol=1e-4, tol_argmax=1e-4, tol_rms=None, tol_scale_T=None):
     """Oracle GLR on one window of the device's input cube against the device's outputs.
+
+    tol_scale_T : None, or the largest |T| of a window up to which ``tol`` is an absolute bound;
+              for a window with a brighter source the bound grows in proportion,
+              ``|dT| <= tol * max(1, max_window |T_ref| / tol_scale_T)``.  Used for the bf16
+              arithmetic only: its rounding error is relative to the SUMMANDS (inputs rounded to
+              8 significant bits: 0.2 % of the brightest line around, also at voxels where a
+              mismatched profile makes the sum itself moderate), and SURVEY 8c's 5e-2 was set
+              on a field with T in [-3.6, 19.5] (2.5e-3 of its maximum); the synthetic fields
+              reach T = 28-45 on their brightest sources.
 
     faint   : DeviceArray (Nz, Ny, Nx), the cube the device GLR ran on
     dev_out : dict of DeviceArrays correl / correl_min / profile (+ maxmap, minmap or None)
@@ -61,12 +70,24 @@ def check_glr_window(faint, dev_out, mask, psf, profiles, window, pcut=1e-8, pme
     got = {k: dev_out[k].window(y0, y1, x0, x1)[sl] for k in ("correl", "correl_min", "profile")}
     res = dict(window=name, box=[int(v) for v in (y0 + a0, y0 + a1, x0 + b0, x0 + b1)],
                voxels=int(got["correl"].size))
+    tmax = float(max(np.max(np.abs(correl[sl])), np.max(np.abs(correl_min[sl]))))
+    tol_w = tol if tol_scale_T is None else tol * max(1.0, tmax / tol_scale_T)
+    res["bound"] = float(tol_w)
+
+    def bound(ref):
+        return tol_w
+
     res["correl"] = float(np.max(np.abs(got["correl"] - correl[sl])))
     res["correl_min"] = float(np.max(np.abs(got["correl_min"] - correl_min[sl])))
     res["correl_rms"] = float(np.sqrt(np.mean((got["correl"] - correl[sl]) ** 2)))
     res["argmax_mismatch"] = float(np.mean(got["profile"] != profile[sl]))
     res["T_range"] = [float(correl_min[sl].min()), float(correl[sl].max())]
-    ok = res["correl"] <= tol and res["correl_min"] <= tol and res["argmax_mismatch"] <= tol_argmax
+    # worst error in units of the window's bound (<= 1 passes)
+    res["correl_over_bound"] = float(np.max(np.abs(got["correl"] - correl[sl]) / bound(correl[sl])))
+    res["correl_min_over_bound"] = float(np.max(np.abs(got["correl_min"] - correl_min[sl]) /
+                                                bound(correl_min[sl])))
+    ok = (res["correl_over_bound"] <= 1.0 and res["correl_min_over_bound"] <= 1.0
+          and res["argmax_mismatch"] <= tol_argmax)
     if tol_rms is not None:
         ok = ok and res["correl_rms"] <= tol_rms
     for key, ref_map in (("maxmap", correl[sl].max(axis=0)), ("minmap", correl_min[sl].min(axis=0))):
@@ -74,7 +95,7 @@ def check_glr_window(faint, dev_out, mask, psf, profiles, window, pcut=1e-8, pme
         if d is not None:
             dm = d.to_host()[y0 + a0:y0 + a1, x0 + b0:x0 + b1]
             res[key] = float(np.max(np.abs(dm - ref_map)))
-            ok = ok and res[key] <= tol
+            ok = ok and bool(np.all(np.abs(dm - ref_map) <= bound(ref_map)))
     res["ok"] = bool(ok)
     return res
 

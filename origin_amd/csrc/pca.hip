@@ -33,6 +33,7 @@
 // A block never straddles two areas, so per-area vectors (b, u) are wave-uniform.
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <chrono>
 #include <vector>
 
@@ -981,9 +982,12 @@ __device__ __forceinline__ int sturm_count(const double *a, const double *bb, in
 // The shift of the inverse iteration lies just above the largest eigenvalue, so T - sigma I is
 // negative definite and its LDL^T factorisation needs no pivoting; it is formed once, with the
 // pivot reciprocals kept for both solves.
-struct TriWork {
-  double x[TRI_PAD], a[TRI_PAD], bb[TRI_PAD], l[TRI_PAD], rd[TRI_PAD];
+template <int PAD_>
+struct TriWorkT {
+  static constexpr int PAD = PAD_;
+  double x[PAD_], a[PAD_], bb[PAD_], l[PAD_], rd[PAD_];
 };
+typedef TriWorkT<TRI_PAD> TriWork;
 
 __device__ __forceinline__ double tridiag_top(const double *alpha, const double *beta, int m,
                                               int lane, TriWork &ws) {
@@ -1117,8 +1121,11 @@ struct SmallWork {
 // tridiagonal eigen-solve, took 50-70 us for n = 20 where this takes about 15).  All 1024 threads of the block take part; sw.G holds the matrix
 // (zero beyond n) and is kept for the residual.  B_k is symmetric by construction (both
 // operands are read as rows k of B_{k-1}: B^T B).
+// NW: waves of the calling block (16 in lanczos_kernel, 8 in lanczos_plain_kernel).
+template <int NW>
 __device__ void eig_small_power(int n, int ld, SmallWork &sw, double *__restrict__ v, double *info3) {
   __shared__ double s_tr, s_part[4];
+  constexpr int NT = 64 * NW, NS = (9 + NW - 1) / NW;  // at most nine tiles
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (wave == 0) {
     const double d = lane < n ? sw.G[lane][lane] : 0.0;
@@ -1128,44 +1135,54 @@ __device__ void eig_small_power(int n, int ld, SmallWork &sw, double *__restrict
   __syncthreads();
   const double tr0 = s_tr;
   if (!(tr0 > 0.0)) {  // G == 0: any unit vector
-    for (int e = tid; e < ld; e += 1024) v[e] = e == 0 ? 1.0 : 0.0;
+    for (int e = tid; e < ld; e += NT) v[e] = e == 0 ? 1.0 : 0.0;
     if (tid == 0 && info3) info3[0] = 0.0, info3[1] = 0.0, info3[2] = 0.0;
     return;
   }
   double (*cur)[LANCZOS_M + 1] = sw.Q, (*nxt)[LANCZOS_M + 1] = sw.P;
-  for (int i = tid; i < LANCZOS_M * (LANCZOS_M + 1); i += 1024) {
+  for (int i = tid; i < LANCZOS_M * (LANCZOS_M + 1); i += NT) {
     const int r = i / (LANCZOS_M + 1), c = i - r * (LANCZOS_M + 1);
     cur[r][c] = sw.G[r][c] / tr0;
   }
   __syncthreads();
   const int T = (n + 15) >> 4, ntile = T * T;
-  const int ti = wave / T, tj = wave - ti * T;
   const int l16 = lane & 15, l4 = lane >> 4;
   double t_prev = 0.0;
   bool last = false;
   int it = 0;
   for (; it < 64; ++it) {
-    double4_t acc = {0, 0, 0, 0};
-    if (wave < ntile) {
-      for (int k0 = 0; k0 < 16 * T; k0 += 4) {
-        const double a = cur[k0 + l4][ti * 16 + l16];
-        const double b = cur[k0 + l4][tj * 16 + l16];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-      }
-      if (ti == tj) {  // trace of the new matrix: D[row = l4 + 4r][col = l16]
-        double d = 0.0;
+    double4_t acc[NS];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) d += (l16 == l4 + 4 * r) ? acc[r] : 0.0;
-        d = wave_sum_d(d);
-        if (lane == 0) s_part[ti] = d;
+    for (int sidx = 0; sidx < NS; ++sidx) {
+      acc[sidx] = double4_t{0, 0, 0, 0};
+      const int tile = wave + NW * sidx;
+      if (tile < ntile) {
+        const int ti = tile / T, tj = tile - ti * T;
+        for (int k0 = 0; k0 < 16 * T; k0 += 4) {
+          const double a = cur[k0 + l4][ti * 16 + l16];
+          const double b = cur[k0 + l4][tj * 16 + l16];
+          acc[sidx] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[sidx], 0, 0, 0);
+        }
+        if (ti == tj) {  // trace of the new matrix: D[row = l4 + 4r][col = l16]
+          double d = 0.0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) d += (l16 == l4 + 4 * r) ? acc[sidx][r] : 0.0;
+          d = wave_sum_d(d);
+          if (lane == 0) s_part[ti] = d;
+        }
       }
     }
     __syncthreads();
     double t = 0.0;
     for (int i = 0; i < T; ++i) t += s_part[i];
-    if (wave < ntile) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) nxt[ti * 16 + l4 + 4 * r][tj * 16 + l16] = acc[r] / t;
+    for (int sidx = 0; sidx < NS; ++sidx) {
+      const int tile = wave + NW * sidx;
+      if (tile < ntile) {
+        const int ti = tile / T, tj = tile - ti * T;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) nxt[ti * 16 + l4 + 4 * r][tj * 16 + l16] = acc[sidx][r] / t;
+      }
     }
     __syncthreads();
     double (*sw_)[LANCZOS_M + 1] = cur;
@@ -1216,9 +1233,11 @@ __device__ void eig_small_power(int n, int ld, SmallWork &sw, double *__restrict
 // ~10 us for such a matrix; a squaring is ~6 us and a dozen of them suffice.
 constexpr int PW_N = 96, PW_LD = 97;
 constexpr size_t PW_BYTES = (size_t)2 * PW_N * PW_LD * sizeof(double);
+template <int NW>
 __device__ void eig_mid_power(const double *__restrict__ Gk, int n, int ld, double *lds,
                               double *__restrict__ v, double *info3) {
   __shared__ double s_tr, s_part[16], s_vec[PW_N];
+  constexpr int NT = 64 * NW, NS = (36 + NW - 1) / NW;  // at most 36 tiles
   double (*cur)[PW_LD] = reinterpret_cast<double (*)[PW_LD]>(lds);
   double (*nxt)[PW_LD] = cur + PW_N;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1231,11 +1250,11 @@ __device__ void eig_mid_power(const double *__restrict__ Gk, int n, int ld, doub
   __syncthreads();
   const double tr0 = s_tr;
   if (!(tr0 > 0.0)) {
-    for (int e = tid; e < ld; e += 1024) v[e] = e == 0 ? 1.0 : 0.0;
+    for (int e = tid; e < ld; e += NT) v[e] = e == 0 ? 1.0 : 0.0;
     if (tid == 0 && info3) info3[0] = 0.0, info3[1] = 0.0, info3[2] = 0.0;
     return;
   }
-  for (int i = tid; i < PW_N * PW_LD; i += 1024) {
+  for (int i = tid; i < PW_N * PW_LD; i += NT) {
     const int r = i / PW_LD, c = i - r * PW_LD;
     cur[r][c] = (r < n && c < n) ? Gk[(long)r * ld + c] / tr0 : 0.0;
   }
@@ -1246,12 +1265,12 @@ __device__ void eig_mid_power(const double *__restrict__ Gk, int n, int ld, doub
   bool last = false;
   int it = 0;
   for (; it < 64; ++it) {
-    double4_t acc[3];
+    double4_t acc[NS];
     double dsum = 0.0;
 #pragma unroll
-    for (int sidx = 0; sidx < 3; ++sidx) {
+    for (int sidx = 0; sidx < NS; ++sidx) {
       acc[sidx] = double4_t{0, 0, 0, 0};
-      const int tile = wave + 16 * sidx;
+      const int tile = wave + NW * sidx;
       if (tile < ntile) {
         const int ti = tile / T, tj = tile - ti * T;
         for (int k0 = 0; k0 < 16 * T; k0 += 4) {
@@ -1270,10 +1289,10 @@ __device__ void eig_mid_power(const double *__restrict__ Gk, int n, int ld, doub
     __syncthreads();
     double t = 0.0;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) t += s_part[w];
+    for (int w = 0; w < NW; ++w) t += s_part[w];
 #pragma unroll
-    for (int sidx = 0; sidx < 3; ++sidx) {
-      const int tile = wave + 16 * sidx;
+    for (int sidx = 0; sidx < NS; ++sidx) {
+      const int tile = wave + NW * sidx;
       if (tile < ntile) {
         const int ti = tile / T, tj = tile - ti * T;
 #pragma unroll
@@ -1400,12 +1419,12 @@ __global__ __launch_bounds__(1024) void lanczos_kernel(const double *__restrict_
         if (lane < n) sw.G[c][lane] = Gk[(long)c * ld + lane];
       __syncthreads();
     }
-    eig_small_power(n, ld, sw, v, info ? info + 3 * k : nullptr);
+    eig_small_power<16>(n, ld, sw, v, info ? info + 3 * k : nullptr);
     if (dbg && threadIdx.x == 0) dbg[2 * k] = -1.0, dbg[2 * k + 1] = (double)(wall_clock64() - t_dbg) * 0.01;
     return;
   }
   if (n <= power_nmax) {  // mid-size matrix: repeated squaring with both buffers in LDS
-    eig_mid_power(Gk, n, ld, lz_dyn, v, info ? info + 3 * k : nullptr);
+    eig_mid_power<16>(Gk, n, ld, lz_dyn, v, info ? info + 3 * k : nullptr);
     if (dbg && threadIdx.x == 0) dbg[2 * k] = -2.0, dbg[2 * k + 1] = (double)(wall_clock64() - t_dbg) * 0.01;
     return;
   }
@@ -1561,6 +1580,714 @@ __global__ __launch_bounds__(1024) void lanczos_kernel(const double *__restrict_
     info[3 * k + 2] = (double)restarts;
   }
   if (tid == 0 && dbg) dbg[2 * k] = (double)steps_dbg, dbg[2 * k + 1] = (double)(wall_clock64() - t_dbg) * 0.01;
+}
+
+// ------------------------------------------------------------------------------------
+// Plain Lanczos with the matrix resident on the CU  (round 3).
+//
+// What the per-matrix statistics of the round-2 kernel showed (ORIGIN_PCA_DEBUG_EIG, 3681 x 600 x 600
+// and 900 x 900): a Lanczos step cost 7-19 us (59 us once the basis of the launch's largest matrix
+// no longer fitted in LDS) of which the float64 arithmetic is a few hundred cycles -- the rest were
+// L2 round trips for G (re-read every step), two Gram-Schmidt passes over the whole basis and a
+// dozen block barriers; the Ritz pair was tested at 24 / 36 / 48 vectors only, so every matrix paid
+// at least 24 steps and 48 + 24 when 48 were not enough.  Measured on the Gram matrices of the
+// bench field (NumPy prototype): the leading pair converges to 1e-14 in 10-52 steps, and the
+// three-term recurrence WITHOUT re-orthogonalisation takes exactly as many steps and gives the
+// same vector -- orthogonality is only lost once a Ritz pair has converged (Paige), and the first
+// to converge is the one wanted here; the iteration stops there.
+//
+// So: one block of 512 threads (8 waves, 256 VGPRs each) per matrix, G loaded ONCE.  Lane l of wave
+// g keeps G[g + 8 i][l + 64 k] for its RS = 4 RC rows k and its column slots i: the first
+// LP_NREG / RS slots in registers, the next LP_NLDS / RS in LDS (a column of 512 doubles per
+// element: conflict free), slots beyond (n > 208) are streamed from L2 per step.  A mat-vec reads
+// q[g + 8 i] once per slot (wave-uniform: one LDS broadcast serves RS FMAs per lane), the eight
+// column groups are summed through LDS in a fixed order.  Per step: mat-vec, two block reductions
+// (alpha, beta), four barriers; the basis goes to global memory (written once, read once for
+// y = V s).  The Ritz pair is tested on a schedule that thins out (8, 12, .. 24, 32, .. 64, 80, ..);
+// the accepted vector is verified against G itself (true residual <= LP_VERIFY_TOL * theta),
+// otherwise -- and when LP_MAXS steps did not converge -- the recurrence restarts from it.
+// n <= 96 takes the repeated-squaring solvers; a launch with n > LP_NMAX is left to lanczos_kernel.
+// ------------------------------------------------------------------------------------
+constexpr int LP_NT = 512, LP_NW = LP_NT / 64;  // threads / waves (= column groups) per block
+constexpr int LP_NREG = 80, LP_NLDS = 24;       // doubles per thread in registers / in LDS
+constexpr int LP_MAXS = 192;                    // Lanczos vectors before a restart
+constexpr int LP_NMAX = 512;                    // eight rows per lane at most
+constexpr int LP_PAD = LP_MAXS + 8;
+constexpr int EIG_QROWS = LP_MAXS + 2;          // basis rows per matrix in the scratch (>= LANCZOS_M + 2)
+constexpr double LP_VERIFY_TOL = 1e-12;
+typedef TriWorkT<LP_PAD> TriWorkL;
+
+struct PlainLds {  // carved from the dynamic LDS of the block
+  double alpha[LP_MAXS], beta[LP_MAXS];
+  TriWorkL ws;
+  double qv[LP_NMAX + 16], qp[LP_NMAX];  // qv: zero beyond n, always
+  double psum[LP_NW][LP_NMAX];
+  double red[8];
+  double glds[LP_NLDS][LP_NT];
+};
+constexpr size_t LP_BYTES = sizeof(PlainLds);
+static_assert(LP_BYTES <= 156 * 1024, "plain Lanczos work area must fit the CU's LDS");
+
+// The tridiagonal solver of lanczos_kernel with a small register footprint (the matrix sits in
+// registers next to it): bounds and every row-independent quantity are computed lane-parallel,
+// the serial recurrences (Sturm chains, pivots of the LDL^T factorisation, the two triangular
+// solves) walk four rows per LDS round trip.  Same algorithm, same results to rounding; any m
+// up to the padded size of the work area.
+__device__ __forceinline__ int sturm_count4(const double *a, const double *bb, int m, double x) {
+  double p0 = 1.0, p1 = a[0] - x;
+  bool s1 = p1 < 0.0 || p1 == 0.0;
+  int cnt = s1;
+  for (int i0 = 0; i0 < m - 1; i0 += 4) {
+    double av[4], bv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) av[e] = a[i0 + 1 + e] - x, bv[e] = bb[i0 + e];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const double p2 = fma(av[e], p1, -bv[e] * p0);
+      const bool s2 = p2 < 0.0 || (p2 == 0.0 && !s1);
+      cnt += (i0 + 1 + e < m) && (s2 != s1);
+      p0 = p1, p1 = p2, s1 = s2;
+    }
+    if (fabs(p1) < 1e-100 && fabs(p0) < 1e-100) p0 *= 1e100, p1 *= 1e100;
+    if (fabs(p1) > 1e100 || fabs(p0) > 1e100) p0 *= 1e-100, p1 *= 1e-100;
+  }
+  return cnt;
+}
+
+__device__ __forceinline__ double wave_max_d(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+template <class TW>
+__device__ __forceinline__ double tridiag_top_lean(const double *alpha, const double *beta, int m,
+                                                   int lane, TW &ws) {
+  double lo = 1e300, hi = -1e300, tn = 0.0;
+  for (int i = lane; i < m; i += 64) {
+    const double r = (i > 0 ? fabs(beta[i - 1]) : 0.0) + (i < m - 1 ? fabs(beta[i]) : 0.0);
+    lo = fmin(lo, alpha[i] - r);
+    hi = fmax(hi, alpha[i] + r);
+    tn = fmax(tn, fabs(alpha[i]) + r);
+  }
+  lo = -wave_max_d(-lo);
+  hi = wave_max_d(hi);
+  tn = wave_max_d(tn);
+  if (!(tn > 0.0)) {  // T == 0
+    for (int i = lane; i < m; i += 64) ws.x[i] = i == 0 ? 1.0 : 0.0;
+    return 0.0;
+  }
+  const double itn = 1.0 / tn;
+  for (int i = lane; i < TW::PAD; i += 64) {  // scaled copy, zero padding behind row m - 1
+    ws.a[i] = i < m ? alpha[i] * itn : 0.0;
+    const double b = i < m - 1 ? beta[i] * itn : 0.0;
+    ws.bb[i] = b * b;
+  }
+  lo *= itn;
+  hi = hi * itn + 1e-14;
+  for (int it = 0; it < 10; ++it) {  // 65^10 > 2^53 * (hi - lo)
+    const double x = lo + (hi - lo) * (double)(lane + 1) / 65.0;
+    const bool above = sturm_count4(ws.a, ws.bb, m, x) >= m;
+    const unsigned long long bal = __ballot(above);
+    const int first = bal ? __ffsll((long long)bal) - 1 : 64;
+    const double nlo = first == 0 ? lo : lo + (hi - lo) * (double)first / 65.0;
+    const double nhi = first == 64 ? hi : lo + (hi - lo) * (double)(first + 1) / 65.0;
+    lo = nlo;
+    hi = nhi;
+  }
+  const double theta_s = 0.5 * (lo + hi);
+  const double sigma = theta_s + 4e-16;
+  // pivots of the LDL^T of (T - sigma I) / tn: d_0 = a_0 - sigma, d_{i+1} = a_{i+1} - sigma -
+  // bb_i / d_i (all negative; one that rounding pushed to zero or above becomes a tiny negative
+  // one); rd = 1 / d
+  if (lane == 0) {
+    double d = ws.a[0] - sigma;
+    for (int i0 = 0; i0 < m; i0 += 4) {
+      double an[4], bq[4], rr[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) an[e] = ws.a[i0 + e + 1] - sigma, bq[e] = ws.bb[i0 + e];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (!(d < -1e-30)) d = -1e-30;
+        rr[e] = 1.0 / d;
+        d = an[e] - bq[e] * rr[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ws.rd[i0 + e] = rr[e];
+    }
+  }
+  const double x0 = 1.0 / sqrt((double)m);
+  for (int i = lane; i < TW::PAD; i += 64) {
+    ws.l[i] = i < m - 1 ? beta[i] * itn * ws.rd[i] : 0.0;  // l_i = b_i / d_i
+    ws.x[i] = i < m ? x0 : 0.0;
+  }
+  for (int iter = 0; iter < 2; ++iter) {
+    double nx = 0.0;
+    if (lane == 0) {
+      // L y = x   (y_0 = x_0, y_i = x_i - l_{i-1} y_{i-1})
+      double y = ws.x[0];
+      for (int i0 = 1; i0 < m; i0 += 4) {
+        double lv[4], xv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lv[e] = ws.l[i0 + e - 1], xv[e] = ws.x[i0 + e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          y = fma(-lv[e], y, xv[e]);
+          xv[e] = y;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (i0 + e < m) ws.x[i0 + e] = xv[e];
+      }
+      // D z = y ; L^T w = z   (w_{m-1} = y_{m-1} / d_{m-1}, w_i = y_i / d_i - l_i w_{i+1})
+      double w = 0.0;
+      for (int i0 = (m - 1) & ~3; i0 >= 0; i0 -= 4) {
+        double lv[4], zv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          lv[e] = (i0 + e < m - 1) ? ws.l[i0 + e] : 0.0;
+          zv[e] = (i0 + e < m) ? ws.x[i0 + e] * ws.rd[i0 + e] : 0.0;
+        }
+#pragma unroll
+        for (int e = 3; e >= 0; --e) {
+          w = fma(-lv[e], w, zv[e]);  // rows >= m: lv = zv = 0 keep w = 0
+          zv[e] = w;
+          nx = fma(w, w, nx);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (i0 + e < m) ws.x[i0 + e] = zv[e];
+      }
+      nx = 1.0 / sqrt(nx);
+    }
+    nx = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(nx)),
+                          __builtin_amdgcn_readfirstlane(__double2loint(nx)));
+    for (int i = lane; i < m; i += 64) ws.x[i] *= nx;
+  }
+  return theta_s * tn;
+}
+
+// Top eigenpair of T for the convergence checks of lanczos_plain, by ONE wave with T in registers.
+//
+// Measured (ORIGIN_PCA_DEBUG_EIG phase timers, n = 204, 64 steps): mat-vecs 82 us, vector part
+// 58 us, and 278 us in twelve checks with the LDS-resident solver -- 0.74 us per row of T and
+// check: ten multisection rounds of a Sturm chain that waits for an LDS round trip every four
+// rows, then the serial LDL^T sweeps.  Here instead:
+//  * lane i of three register pairs holds row i (64 j + i) of the scaled T; a chain step takes its
+//    row through v_readlane (scalar operands, no memory at all);
+//  * the eigenvalue bracket starts at the previous check's Ritz value (Ritz values only grow with
+//    m) and its first round is GEOMETRIC towards that end -- theta_m - theta_{m'} is of the order of
+//    the previous residual squared --, so a check needs ~4-6 rounds instead of 10;
+//  * the eigenvector comes from the three-term recurrence run BOTTOM-UP (x_{m-1} = 1,
+//    x_{i-1} = ((theta - a_i) x_i - b_i x_{i+1}) / b_{i-1}): the twisted factorisation with the
+//    twist at row 0, x = (T - theta)^{-1} e_0 up to scale.  The top Ritz vector of a Lanczos
+//    tridiagonal is largest at the top and decays downwards as the pair converges, so the
+//    recurrence runs in its direction of growth (stable; NumPy prototype on the bench field's Gram
+//    matrices: estimate and vector equal LAPACK's to 1e-12 at every check).  Every lane runs the
+//    same chain on scalar operands and keeps "its" entries.
+// The vector a check accepts is verified against G itself afterwards; when that fails the LDL^T
+// solver (tridiag_top_lean) takes over.  m <= 192.
+__device__ __forceinline__ double readlane_d(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
+                          __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+struct TriRegs {
+  double a[3];    // a_i / tn
+  double b[3];    // b_i / tn      (couples rows i, i + 1; 0 for i >= m - 1)
+  double bbp[3];  // (b_{i-1} / tn)^2  at position i  (0 at i = 0)
+  double rb[3];   // tn / b_i      (0 for i >= m - 1)
+};
+
+// eigenvalues of T (scaled) below x: sign changes of the leading principal minors
+// p_i = (a_i - x) p_{i-1} - bb_{i-1} p_{i-2}.  A step is three float64 operations and one
+// v_alignbit that shifts the sign bit of p_i into a 32-bit history; the changes are counted per
+// 31 rows (popcount of history ^ history >> 1).  A minor that is exactly zero counts as positive:
+// the next one, -bb p_{i-2}, then has the sign opposite to p_{i-2}, which gives the same number
+// of changes as the "zero takes the sign opposite to its predecessor" rule of sturm_count for
+// every interior row, and makes the count that of the eigenvalues strictly below x.
+__device__ __forceinline__ int sturm_count_rl(const TriRegs &t, int m, double x) {
+  // hist: the signs of the last `held` minors, newest at bit 0; starts with p_{-1} = 1
+  unsigned hist = 0u;
+  int held = 1, cnt = 0;
+  double p0 = 1.0, p1 = readlane_d(t.a[0], 0) - x;
+  hist = __builtin_amdgcn_alignbit(hist, (unsigned)__double2hiint(p1), 31);  // hist << 1 | sign
+  held = 2;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int l0 = j == 0 ? 1 : 0, l1 = min(64, m - 64 * j);
+    for (int l = l0; l < l1; ++l) {
+      const double ai = readlane_d(t.a[j], l), bi = readlane_d(t.bbp[j], l);
+      const double p2 = fma(ai - x, p1, -bi * p0);
+      hist = __builtin_amdgcn_alignbit(hist, (unsigned)__double2hiint(p2), 31);
+      p0 = p1, p1 = p2;
+      if (++held == 32) {  // (uniform) 31 adjacent pairs; the newest sign seeds the next batch
+        cnt += __popc((hist ^ (hist >> 1)) & 0x7fffffffu);
+        hist &= 1u;
+        held = 1;
+      }
+      if ((l & 7) == 7) {
+        if (fabs(p1) < 1e-100 && fabs(p0) < 1e-100) p0 *= 1e100, p1 *= 1e100;
+        if (fabs(p1) > 1e100 || fabs(p0) > 1e100) p0 *= 1e-100, p1 *= 1e-100;
+      }
+    }
+  }
+  // the held - 1 pairs still in the history
+  cnt += __popc((hist ^ (hist >> 1)) & ((1u << (held - 1)) - 1u));
+  return cnt;
+}
+
+// theta_hint: a lower bound of the eigenvalue (the previous check's Ritz value) or -inf
+template <class TW>
+__device__ __forceinline__ double tridiag_top_fast(const double *alpha, const double *beta, int m,
+                                                   int lane, TW &ws, double theta_hint,
+                                                   double *tdbg = nullptr) {
+  unsigned long long tq = tdbg ? wall_clock64() : 0ull;
+  auto lap = [&](int slot) {
+    if (tdbg) {
+      const unsigned long long t = wall_clock64();
+      if (lane == 0) tdbg[slot] += (double)(t - tq);
+      tq = t;
+    }
+  };
+  double lo = 1e300, hi = -1e300, tn = 0.0;
+  for (int i = lane; i < m; i += 64) {
+    const double r = (i > 0 ? fabs(beta[i - 1]) : 0.0) + (i < m - 1 ? fabs(beta[i]) : 0.0);
+    lo = fmin(lo, alpha[i] - r);
+    hi = fmax(hi, alpha[i] + r);
+    tn = fmax(tn, fabs(alpha[i]) + r);
+  }
+  lo = -wave_max_d(-lo);
+  hi = wave_max_d(hi);
+  tn = wave_max_d(tn);
+  if (!(tn > 0.0) || m == 1) {
+    for (int i = lane; i < m; i += 64) ws.x[i] = i == 0 ? 1.0 : 0.0;
+    return m == 1 ? alpha[0] : 0.0;
+  }
+  const double itn = 1.0 / tn;
+  TriRegs t;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int i = 64 * j + lane;
+    t.a[j] = i < m ? alpha[i] * itn : 0.0;
+    const double b = i < m - 1 ? beta[i] * itn : 0.0;
+    t.b[j] = b;
+    t.rb[j] = i < m - 1 ? 1.0 / b : 0.0;  // (b_i > 0: the recurrence stops at breakdown)
+    const double bp = (i >= 1 && i < m) ? beta[i - 1] * itn : 0.0;
+    t.bbp[j] = bp * bp;
+  }
+  lo *= itn;
+  hi = hi * itn + 1e-14;
+  if (theta_hint * itn > lo) lo = theta_hint * itn - 1e-14;  // Ritz values grow with m
+  lap(0);
+  // first round geometric towards lo: x_l = lo + W rho^(63 - l), rho = 0.7 (x_0 = lo + 1.7e-10 W)
+  {
+    const double W = hi - lo;
+    const double x = lo + W * exp2(-0.5145731728297583 * (double)(63 - lane));
+    const bool above = sturm_count_rl(t, m, x) >= m;
+    const unsigned long long bal = __ballot(above);
+    const int first = bal ? __ffsll((long long)bal) - 1 : 64;
+    const double nhi = first == 64 ? hi : readlane_d(x, first & 63);
+    const double nlo = first == 0 ? lo : readlane_d(x, (first - 1) & 63);
+    lo = nlo, hi = nhi;
+  }
+  // uniform 65-way rounds down to three units in the last place of the scaled T (|theta| <= 1)
+  for (int it = 0; it < 11 && hi - lo > 6.7e-16; ++it) {
+    const double x = lo + (hi - lo) * (double)(lane + 1) / 65.0;
+    const bool above = sturm_count_rl(t, m, x) >= m;
+    const unsigned long long bal = __ballot(above);
+    const int first = bal ? __ffsll((long long)bal) - 1 : 64;
+    const double nlo = first == 0 ? lo : lo + (hi - lo) * (double)first / 65.0;
+    const double nhi = first == 64 ? hi : lo + (hi - lo) * (double)(first + 1) / 65.0;
+    lo = nlo;
+    hi = nhi;
+  }
+  const double th = 0.5 * (lo + hi);
+  lap(1);
+  // bottom-up recurrence: every lane runs the chain, lane (i & 63) keeps x_i in xr[i >> 6]
+  double xr[3] = {0.0, 0.0, 0.0};
+  double x1 = 1.0;  // x_{m-1}
+  double x0 = (th - readlane_d(t.a[(m - 1) >> 6], (m - 1) & 63)) * readlane_d(t.rb[(m - 2) >> 6], (m - 2) & 63);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    if (((m - 1) >> 6) == j && ((m - 1) & 63) == lane) xr[j] = x1;
+    if (((m - 2) >> 6) == j && ((m - 2) & 63) == lane) xr[j] = x0;
+  }
+#pragma unroll
+  for (int j = 2; j >= 0; --j) {  // rows i = 64 j + l give x_{i-1}
+    const int lhi = min(63, m - 2 - 64 * j);
+    for (int l = lhi; l >= (j == 0 ? 1 : 0); --l) {
+      const int im1 = 64 * j + l - 1;
+      const double ai = readlane_d(t.a[j], l), bi = readlane_d(t.b[j], l);
+      const double rbi = im1 >= 64 * j ? readlane_d(t.rb[j], l - 1)
+                                       : readlane_d(t.rb[j > 0 ? j - 1 : 0], 63);
+      const double xn = ((th - ai) * x0 - bi * x1) * rbi;
+      x1 = x0, x0 = xn;
+      const int jj = im1 >> 6;
+      if ((im1 & 63) == lane) {
+        if (jj == 0) xr[0] = xn;
+        else if (jj == 1) xr[1] = xn;
+        else xr[2] = xn;
+      }
+      if ((l & 7) == 0 && fabs(x0) > 1e100) {  // (uniform; growth <= 1e6 per row) scale the live
+                                                 // pair and everything stored so far
+        x0 *= 1e-100, x1 *= 1e-100;
+        xr[0] *= 1e-100, xr[1] *= 1e-100, xr[2] *= 1e-100;
+      }
+    }
+  }
+  double p = 0.0;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) p = fma(xr[j], xr[j], p);
+  p = wave_sum_d(p);
+  const double inv = p > 0.0 ? 1.0 / sqrt(p) : 0.0;
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+    if (64 * j + lane < m) ws.x[64 * j + lane] = xr[j] * inv;
+  lap(2);
+  return th * tn;
+}
+
+// When to test the Ritz pair next.  A test costs ~0.3 us per row of T, a step ~2 us, and the
+// residual estimate falls geometrically: after the tests at 8 and 12 vectors the next one goes
+// where the last two estimates (e_prev at m_prev, e at m; relative to theta) predict
+// e = tol, a little early (85 % of the way; 2..32 steps ahead, at most m / 2).  On the bench field's Gram
+// matrices this takes 2-6 tests per solve instead of 2-18 on a fixed schedule and stops within
+// two steps of the first converged m (NumPy prototype).
+__device__ __forceinline__ int lp_next_check(int m, double e, int m_prev, double e_prev, double tol) {
+  if (m_prev == 0 || !(e > 0.0) || !(e_prev > 0.0)) return m + 4;
+  const double rate = fmax(log10(e_prev / e) / (double)(m - m_prev), 0.05);  // decades per step
+  const double togo = log10(e / tol) / rate;
+  // (never more than half of what has been done: an estimate that has not started to fall yet
+  // -- a plateau before the Krylov space reaches the leading vector -- predicts nothing)
+  const double ahead = fmin(fmax(rint(0.85 * togo), 2.0), fmin(32.0, fmax(4.0, 0.5 * (double)m)));
+  return m + (int)ahead;
+}
+
+// sum over the four waves that hold the vector entries (threads 0..255); every thread of the
+// block gets the total.  Ends with a barrier; `slot` alternates so that a sum can be written
+// while stragglers still read the previous one.
+__device__ __forceinline__ double lp_vec_sum(double v, double *red, int slot) {
+  const int tid = threadIdx.x;
+  if (tid < 256) {
+    v = wave_sum_d(v);
+    if ((tid & 63) == 0) red[slot * 4 + (tid >> 6)] = v;
+  }
+  __syncthreads();
+  return (red[slot * 4] + red[slot * 4 + 1]) + (red[slot * 4 + 2] + red[slot * 4 + 3]);
+}
+
+template <int RC>
+__device__ void lanczos_plain(const double *__restrict__ Gk, int n, int ld, double *__restrict__ Vk,
+                              double *__restrict__ v, PlainLds &L, int max_restart, double tol,
+                              double *info3, int *steps_out, double *tph = nullptr) {
+  constexpr int RS = 4 * RC;                        // rows per lane
+  // (tph: optional per-phase times of thread 0 in 10 ns ticks -- ORIGIN_PCA_DEBUG_EIG)
+  unsigned long long tq = tph ? wall_clock64() : 0ull;
+  auto lap = [&](int slot) {
+    if (tph) {
+      const unsigned long long t = wall_clock64();
+      if (threadIdx.x == 0) tph[slot] += (double)(t - tq);
+      tq = t;
+    }
+  };
+  constexpr int NRC = LP_NREG / RS, NLC = LP_NLDS / RS;  // column slots in registers / in LDS
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int g = __builtin_amdgcn_readfirstlane(tid >> 6);  // column group = wave (uniform)
+  const int ncol8 = (n + 7) >> 3;
+  // ---- G: registers, LDS, the rest stays in global memory.  No bounds tests: rows and columns
+  // beyond n are clamped to n - 1 (valid memory); a clamped column meets q[c] = 0 (qv is zero
+  // beyond n, always), a clamped row produces a sum nobody reads.
+  int rows[RS];
+#pragma unroll
+  for (int k = 0; k < RS; ++k) rows[k] = min(lane + 64 * k, n - 1);
+  double greg[NRC][RS];
+#pragma unroll
+  for (int i = 0; i < NRC; ++i) {
+    const double *row = Gk + (long)min(g + 8 * i, n - 1) * ld;  // wave-uniform
+#pragma unroll
+    for (int k = 0; k < RS; ++k) greg[i][k] = row[rows[k]];
+  }
+#pragma unroll
+  for (int i = 0; i < NLC; ++i) {
+    const double *row = Gk + (long)min(g + 8 * (NRC + i), n - 1) * ld;
+#pragma unroll
+    for (int k = 0; k < RS; ++k) L.glds[i * RS + k][tid] = row[rows[k]];
+  }
+  for (int e = tid; e < LP_NMAX + 16; e += LP_NT) L.qv[e] = e < n ? 1.0 : 0.0;
+  for (int e = tid; e < LP_NMAX; e += LP_NT) L.qp[e] = 0.0;
+  __syncthreads();
+  // partial sums of G q over this wave's columns, for the lane's rows -> psum[g][row]; q = L.qv
+  auto matvec = [&]() {
+    double acc[RS];
+#pragma unroll
+    for (int k = 0; k < RS; ++k) acc[k] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NRC; ++i) {
+      const double q = L.qv[g + 8 * i];
+#pragma unroll
+      for (int k = 0; k < RS; ++k) acc[k] = fma(greg[i][k], q, acc[k]);
+    }
+#pragma unroll
+    for (int i = 0; i < NLC; ++i) {
+      const double q = L.qv[g + 8 * (NRC + i)];
+#pragma unroll
+      for (int k = 0; k < RS; ++k) acc[k] = fma(L.glds[i * RS + k][tid], q, acc[k]);
+    }
+    // column slots beyond the resident ones: from L2, SU slots (16 loads per lane) in flight --
+    // one slot at a time the loop is a chain of L2 round trips (measured: 18 us per step at
+    // n = 298).  A slot past the last one is clamped to column n - 1 and meets q = 0.
+    constexpr int SU = 16 / RS;
+    for (int i = NRC + NLC; i < ncol8; i += SU) {
+      double gl[SU][RS], qs[SU];
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int c = g + 8 * (i + u);  // (< LP_NMAX + 8 + 8 SU... clamped for q below)
+        qs[u] = L.qv[min(c, LP_NMAX + 15)];
+        const double *row = Gk + (long)min(c, n - 1) * ld;
+#pragma unroll
+        for (int k = 0; k < RS; ++k) gl[u][k] = row[rows[k]];
+      }
+#pragma unroll
+      for (int u = 0; u < SU; ++u)
+#pragma unroll
+        for (int k = 0; k < RS; ++k) acc[k] = fma(gl[u][k], qs[u], acc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < RS; ++k)
+      if (lane + 64 * k < LP_NMAX) L.psum[g][lane + 64 * k] = acc[k];
+    __syncthreads();
+  };
+  auto row_w = [&](int r) {  // fixed order over the eight column groups
+    return ((L.psum[0][r] + L.psum[1][r]) + (L.psum[2][r] + L.psum[3][r])) +
+           ((L.psum[4][r] + L.psum[5][r]) + (L.psum[6][r] + L.psum[7][r]));
+  };
+
+  // start vector: G * ones (a few power-like steps come for free in the Krylov space)
+  matvec();
+  double wr[RC];
+  {
+    double p = 0.0;
+    if (tid < 256) {
+#pragma unroll
+      for (int rc = 0; rc < RC; ++rc) {
+        const int r = tid + 256 * rc;
+        wr[rc] = r < n ? row_w(r) : 0.0;
+        p = fma(wr[rc], wr[rc], p);
+      }
+    }
+    const double nrm = sqrt(lp_vec_sum(p, L.red, 0));
+    if (tid < 256) {
+#pragma unroll
+      for (int rc = 0; rc < RC; ++rc) {
+        const int r = tid + 256 * rc;
+        if (r < n) L.qv[r] = nrm > 0.0 ? wr[rc] / nrm : (r == 0 ? 1.0 : 0.0);
+      }
+    }
+    __syncthreads();
+  }
+  double theta = 0.0, resid = 0.0;
+  int restarts = 0, steps = 0;
+  const int mmax = min(LP_MAXS, n);
+  lap(0);
+  for (;; ++restarts) {
+    // q_0 = L.qv (unit norm), q_{-1} = 0
+    if (tid < 256) {
+#pragma unroll
+      for (int rc = 0; rc < RC; ++rc) {
+        const int r = tid + 256 * rc;
+        if (r < n) {
+          L.qp[r] = 0.0;
+          Vk[r] = L.qv[r];
+        }
+      }
+    }
+    __syncthreads();
+    double beta_prev = 0.0;
+    int m = 0, m_checked = 0;  // m_checked: rows of the last check of THIS recurrence (0: none)
+    int next_check = 8;
+    double e_checked = 0.0;
+    bool solved = false;
+    for (int j = 0; j < mmax; ++j) {
+      matvec();
+      lap(1);
+      // w = G q_j - beta_{j-1} q_{j-1};  alpha_j = q_j . w
+      double a_loc = 0.0;
+      if (tid < 256) {
+#pragma unroll
+        for (int rc = 0; rc < RC; ++rc) {
+          const int r = tid + 256 * rc;
+          wr[rc] = r < n ? fma(-beta_prev, L.qp[r], row_w(r)) : 0.0;
+          a_loc = fma(r < n ? L.qv[r] : 0.0, wr[rc], a_loc);
+        }
+      }
+      const double aj = lp_vec_sum(a_loc, L.red, 0);
+      // w -= alpha_j q_j;  beta_j = |w|
+      double b_loc = 0.0;
+      if (tid < 256) {
+#pragma unroll
+        for (int rc = 0; rc < RC; ++rc) {
+          const int r = tid + 256 * rc;
+          if (r < n) wr[rc] = fma(-aj, L.qv[r], wr[rc]);
+          b_loc = fma(wr[rc], wr[rc], b_loc);
+        }
+      }
+      const double bj = sqrt(lp_vec_sum(b_loc, L.red, 1));
+      if (tid == 0) L.alpha[j] = aj, L.beta[j] = bj;
+      m = j + 1;
+      const bool invariant = bj <= 1e-300 || bj <= 1e-15 * fabs(aj);
+      if (!invariant && j + 1 < mmax && tid < 256) {
+        const double ib = 1.0 / bj;
+#pragma unroll
+        for (int rc = 0; rc < RC; ++rc) {
+          const int r = tid + 256 * rc;
+          if (r < n) {
+            const double qn = wr[rc] * ib;
+            L.qp[r] = L.qv[r];
+            L.qv[r] = qn;
+            Vk[(long)(j + 1) * ld + r] = qn;
+          }
+        }
+      }
+      beta_prev = bj;
+      __syncthreads();
+      lap(2);
+      if (invariant || m == mmax || m == next_check) {
+        if (tid < 64) {
+          // (the recurrence form needs b_i > 0 and a decaying vector: breakdown and the forced
+          // stop at mmax take the LDL^T solver)
+          const double th = (invariant || m == mmax)
+                                ? tridiag_top_lean(L.alpha, L.beta, m, lane, L.ws)
+                                : tridiag_top_fast(L.alpha, L.beta, m, lane, L.ws,
+                                                   theta > 0.0 && m_checked > 0 ? theta : -1e300,
+                                                   tph ? tph + 5 : nullptr);
+          if (lane == 0) L.red[0] = th;
+        }
+        __syncthreads();
+        theta = L.red[0];
+        resid = fabs(bj * L.ws.x[m - 1]);
+        solved = invariant || m >= n || resid <= tol * fabs(theta);
+        {
+          const double e = fabs(theta) > 0.0 ? resid / fabs(theta) : 0.0;
+          next_check = lp_next_check(m, e, m_checked, e_checked, tol);
+          m_checked = m, e_checked = e;
+        }
+        __syncthreads();  // (red[0] is reused by the next reduction)
+        lap(3);
+        if (solved || m == mmax) break;
+      }
+    }
+    steps += m;
+    // y = V s, normalised, into qv; then the true residual |G y - theta y| against G itself.  A
+    // vector from the recurrence form that fails the test is replaced by the LDL^T solver's.
+    bool robust = m == mmax || L.beta[m - 1] <= 1e-15 * fabs(L.alpha[m - 1]);
+    bool good = false;
+    double rtrue = 0.0, th2 = 0.0;
+    for (;;) {
+      double yr[RC], p = 0.0;
+      if (tid < 256) {
+#pragma unroll
+        for (int rc = 0; rc < RC; ++rc) {
+          const int r = tid + 256 * rc;
+          double acc = 0.0;
+          if (r < n) {
+#pragma unroll 8
+            for (int i = 0; i < m; ++i) acc = fma(L.ws.x[i], Vk[(long)i * ld + r], acc);
+          }
+          yr[rc] = acc;
+          p = fma(acc, acc, p);
+        }
+      }
+      const double ny = sqrt(lp_vec_sum(p, L.red, 0));
+      if (tid < 256) {
+#pragma unroll
+        for (int rc = 0; rc < RC; ++rc) {
+          const int r = tid + 256 * rc;
+          if (r < n) L.qv[r] = ny > 0.0 ? yr[rc] / ny : (r == 0 ? 1.0 : 0.0);
+        }
+      }
+      __syncthreads();
+      matvec();
+      double t_loc = 0.0;
+      if (tid < 256) {
+#pragma unroll
+        for (int rc = 0; rc < RC; ++rc) {
+          const int r = tid + 256 * rc;
+          wr[rc] = r < n ? row_w(r) : 0.0;
+          t_loc = fma(r < n ? L.qv[r] : 0.0, wr[rc], t_loc);
+        }
+      }
+      th2 = lp_vec_sum(t_loc, L.red, 1);
+      double r_loc = 0.0;
+      if (tid < 256) {
+#pragma unroll
+        for (int rc = 0; rc < RC; ++rc) {
+          const int r = tid + 256 * rc;
+          const double d = r < n ? fma(-th2, L.qv[r], wr[rc]) : 0.0;
+          r_loc = fma(d, d, r_loc);
+        }
+      }
+      rtrue = sqrt(lp_vec_sum(r_loc, L.red, 0));
+      good = rtrue <= LP_VERIFY_TOL * fabs(th2) || !(th2 > 0.0);
+      __syncthreads();
+      if (good || robust) break;
+      if (tid < 64) (void)tridiag_top_lean(L.alpha, L.beta, m, lane, L.ws);
+      robust = true;
+      __syncthreads();
+    }
+    theta = th2;
+    if (!solved || !good) resid = rtrue;
+    lap(4);
+    if ((solved && good) || restarts + 1 >= max_restart) break;
+  }
+  // the eigenvector is in qv (unit norm)
+  for (int e = tid; e < ld; e += LP_NT) v[e] = e < n ? L.qv[e] : 0.0;
+  if (tid == 0 && info3) info3[0] = theta, info3[1] = resid, info3[2] = (double)restarts;
+  *steps_out = steps;
+}
+
+__global__ __launch_bounds__(LP_NT) void lanczos_plain_kernel(
+    const double *__restrict__ G, const long *__restrict__ g_off, const long *__restrict__ ld_,
+    const long *__restrict__ n_, double *__restrict__ Q, const long *__restrict__ q_off,
+    double *__restrict__ vout, const long *__restrict__ v_off, int max_restart, double tol,
+    double *__restrict__ info, double *__restrict__ dbg) {
+  extern __shared__ __align__(16) double lz_dyn[];  // SmallWork, the squaring buffers, or PlainLds
+  const int k = blockIdx.x;
+  const int n = (int)n_[k], ld = (int)ld_[k];
+  if (n < 1) return;
+  const unsigned long long t_dbg = dbg ? wall_clock64() : 0ull;
+  const double *Gk = G + g_off[k];
+  double *v = vout + v_off[k];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int steps = 0;
+  if (n <= LANCZOS_M) {
+    SmallWork &sw = *reinterpret_cast<SmallWork *>(lz_dyn);
+    double *z8 = reinterpret_cast<double *>(&sw);
+    for (int i = tid; i < (int)(sizeof(SmallWork) / sizeof(double)); i += LP_NT) z8[i] = 0.0;
+    __syncthreads();
+    for (int c = wave; c < n; c += LP_NW)
+      if (lane < n) sw.G[c][lane] = Gk[(long)c * ld + lane];
+    __syncthreads();
+    eig_small_power<LP_NW>(n, ld, sw, v, info ? info + 3 * k : nullptr);
+    steps = -1;
+  } else if (n <= PW_N) {
+    eig_mid_power<LP_NW>(Gk, n, ld, lz_dyn, v, info ? info + 3 * k : nullptr);
+    steps = -2;
+  } else {
+    PlainLds &L = *reinterpret_cast<PlainLds *>(lz_dyn);
+    double *Vk = Q + q_off[k];
+    double *tph = dbg ? dbg + 2 * (long)gridDim.x + 8 * (long)k : nullptr;
+    if (tph && tid == 0)
+      for (int e = 0; e < 8; ++e) tph[e] = 0.0;
+    if (n <= 256)
+      lanczos_plain<1>(Gk, n, ld, Vk, v, L, max_restart, tol, info ? info + 3 * k : nullptr, &steps,
+                       tph);
+    else
+      lanczos_plain<2>(Gk, n, ld, Vk, v, L, max_restart, tol, info ? info + 3 * k : nullptr, &steps,
+                       tph);
+  }
+  if (dbg && tid == 0)
+    dbg[2 * k] = (double)steps, dbg[2 * k + 1] = (double)(wall_clock64() - t_dbg) * 0.01;
 }
 
 // ------------------------------------------------------------------------------------
@@ -1899,6 +2626,23 @@ int eig_launch(origin_ctx *ctx, int nmat, long ldmax, const double *d_G, const l
                                    hipFuncAttributeMaxDynamicSharedMemorySize, dyn_max));
     attr_done = true;
   }
+  // Above PW_N columns: plain Lanczos with the matrix resident on the CU (lanczos_plain_kernel;
+  // ORIGIN_PCA_EIG=cgs2 keeps the round-2 kernel for A/B runs).  A launch whose largest matrix
+  // exceeds LP_NMAX columns goes to the round-2 kernel as a whole.
+  static const bool cgs2 = getenv("ORIGIN_PCA_EIG") && !strcmp(getenv("ORIGIN_PCA_EIG"), "cgs2");
+  if (!d_slab && ldmax > PW_N && ldmax <= LP_NMAX && !cgs2) {
+    static bool attr_plain = false;
+    const size_t lds = std::max(std::max(PW_BYTES, sizeof(SmallWork)), LP_BYTES);
+    if (!attr_plain) {
+      ORIGIN_HIP(hipFuncSetAttribute((const void *)lanczos_plain_kernel,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_plain = true;
+    }
+    hipLaunchKernelGGL(lanczos_plain_kernel, dim3(nmat), dim3(LP_NT), lds, ctx->stream, d_G, d_g_off,
+                       d_ld, d_n, d_q, d_q_off, d_v, d_v_off, 8, 1e-14, d_info, d_dbg);
+    ORIGIN_LAUNCH_CHECK();
+    return ORIGIN_OK;
+  }
   // matrices of up to PW_N columns are solved by repeated squaring in LDS (PW_BYTES of it)
   const bool mid = ldmax > LANCZOS_M;
   const bool qlds = ldmax <= LANCZOS_QLDS_LD;
@@ -1986,7 +2730,7 @@ int origin_pca_eig(origin_ctx *ctx, const double *d_G, const long *d_g_off, cons
                     d_info);
 }
 
-int origin_pca_eig_qrows(void) { return LANCZOS_M + 2; }
+int origin_pca_eig_qrows(void) { return EIG_QROWS; }
 
 // The whole greedy PCA of `na` areas, in place on d_F.
 int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S, int na,
@@ -2284,7 +3028,7 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
       xp += (long)Nz * ld;
       c += ld;
       g += (long)ld * ld;
-      q += (long)(LANCZOS_M + 2) * ld;
+      q += (long)EIG_QROWS * ld;
       cb += ns;
       ldmax = std::max(ldmax, ld);
       nsmax = std::max(nsmax, ns);
@@ -2388,7 +3132,7 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
       scr = b_part.p;
       double *d_info = nullptr;
       if (debug) {
-        if ((rc = b_info.reserve(ctx, (size_t)5 * nw * sizeof(double)))) return rc;
+        if ((rc = b_info.reserve(ctx, (size_t)13 * nw * sizeof(double)))) return rc;
         d_info = (double *)b_info.p;
       }
       {
@@ -2399,7 +3143,7 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
           return rc;
       }
       if (debug) {
-        std::vector<double> info((size_t)5 * nw);
+        std::vector<double> info((size_t)13 * nw, 0.0);
         ORIGIN_HIP(hipMemcpyAsync(info.data(), d_info, info.size() * sizeof(double),
                                   hipMemcpyDeviceToHost, st));
         ORIGIN_HIP(hipStreamSynchronize(st));
@@ -2409,6 +3153,18 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
             fprintf(stderr, " %d:%.0f:%.0f:%.0f", (int)D[(size_t)DF_N * nw + w], info[3 * nw + 2 * w],
                     info[3 * w + 2], info[3 * nw + 2 * w + 1]);
           fprintf(stderr, "\n");
+          // phases (us) of the slowest plain-Lanczos block: setup, mat-vec, vector part, checks, final
+          int ws_ = -1;
+          for (int w = 0; w < nw; ++w)
+            if (info[3 * nw + 2 * w] > 0 && (ws_ < 0 || info[3 * nw + 2 * w + 1] > info[3 * nw + 2 * ws_ + 1]))
+              ws_ = w;
+          if (ws_ >= 0) {
+            const double *t = &info[5 * (size_t)nw + 8 * (size_t)ws_];
+            fprintf(stderr, "[pca-eig]   slowest n %d steps %.0f: setup %.1f matvec %.1f vector %.1f checks %.1f "
+                    "(prep %.1f rounds %.1f vector %.1f) final %.1f us\n",
+                    (int)D[(size_t)DF_N * nw + ws_], info[3 * nw + 2 * ws_], t[0] * 0.01, t[1] * 0.01,
+                    t[2] * 0.01, t[3] * 0.01, t[5] * 0.01, t[6] * 0.01, t[7] * 0.01, t[4] * 0.01);
+          }
         }
         double rmax = 0, rsum = 0, resmax = 0;
         int nmax = 0;

@@ -140,3 +140,41 @@ def test_config3_headline_600_bench_check():
     assert chk["level"] == "full" and len(chk["glr"]) == 3 and len(chk["pca"]) == 2
     assert chk["ok"], chk
     assert line["config"]["workload"].startswith("synthetic 3681x600x600")
+
+
+def test_config5_900_bf16_bench_check():
+    """BASELINE config 5's workload on one GPU (the largest single-GPU configuration): synthetic
+    3681 x 900 x 900, fp32 PCA + bf16 GLR, `bench.py --check full` at the bf16 tolerances of
+    SURVEY 8c (|dT| <= 5e-2, rms <= 5e-3, arg-max mismatch <= 2 %); the PCA / DCT checks keep the
+    fp32 tolerances."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--size", "900", "--glr-precision",
+           "bf16", "--steps", "1", "--warmup", "1", "--check", "full", "--no-cpu-baseline",
+           "--e2e-size", "0"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500,
+                       cwd=ROOT)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    chk = line["check"]
+    assert line["dtype"] == "f32+bf16" and line["config"]["glr_spectral_arithmetic"] == "bf16"
+    assert line["config"]["workload"].startswith("synthetic 3681x900x900")
+    assert chk["level"] == "full" and len(chk["glr"]) == 3 and len(chk["pca"]) == 2
+    assert "bf16" in chk["tolerances"]
+    print(json.dumps(chk, indent=1))   # (shown in full when the test fails)
+    assert chk["ok"]
+    assert all(p_["mapO2_mismatch"] == 0 for p_ in chk["pca"])
+
+
+def test_config5_900_f16x2_glr_windows_only():
+    """The same field with the fp32-class GLR (two-term f16 split): only the GLR windows are
+    checked again (|dT| <= 1e-4) -- DCT and PCA do not depend on the GLR's arithmetic and were
+    checked by the bf16 twin above."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--size", "900", "--steps", "1",
+           "--warmup", "1", "--check", "glr", "--no-cpu-baseline", "--e2e-size", "0"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500,
+                       cwd=ROOT)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    chk = line["check"]
+    assert line["dtype"] == "f32+f16x2" and len(chk["glr"]) == 3 and not chk["pca"]
+    print(json.dumps(chk, indent=1))
+    assert chk["ok"]

@@ -184,10 +184,15 @@ def test_gram_mfma_matches_numpy(ctx):
 @pytest.mark.parametrize("n,spectrum", [(1, "flat"), (2, "gap"), (20, "flat"), (37, "gap"),
                                         (48, "close"), (49, "gap"), (64, "close"), (90, "flat"),
                                         (96, "gap"), (97, "close"), (130, "close"),
-                                        (300, "flat"), (700, "close")])
+                                        (150, "gap"), (200, "close"), (208, "flat"),
+                                        (209, "close"), (256, "flat"), (257, "gap"),
+                                        (300, "flat"), (400, "close"), (512, "flat"),
+                                        (513, "gap"), (700, "close")])
 def test_lanczos_leading_eigenvector(ctx, n, spectrum):
     """Device eigen-solvers vs LAPACK on PSD matrices with wide, close and flat spectra:
-    repeated squaring on the f64 matrix cores for n <= 48 and n <= 96, Lanczos above."""
+    repeated squaring on the f64 matrix cores for n <= 48 and n <= 96; above, plain Lanczos
+    with the matrix resident on the CU (all of it up to 208 columns, the rest streamed; four
+    rows per lane up to 256 columns, eight up to 512), and the round-2 kernel beyond 512."""
     from origin_amd import _capi
     rng = np.random.default_rng(100 + n)
     Qm, _ = np.linalg.qr(rng.standard_normal((n, n)))
