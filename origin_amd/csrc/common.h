@@ -72,6 +72,11 @@ struct origin_ctx {
   bool aux_pending;
   void *aux_scratch;
   size_t aux_scratch_bytes;
+  // pinned staging of origin_d2h_f32_as_f64 / origin_h2d_f64_as_f32: two 64 MiB buffers and two
+  // events, made by the first conversion call on this context (all or nothing) and freed with it
+  float *cvt_stage[2];
+  hipEvent_t cvt_ev[2];
+  bool cvt_ready;
 };
 
 // aux stream plumbing (ctx.hip)

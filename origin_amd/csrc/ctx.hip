@@ -4,6 +4,7 @@
 
 #include <functional>
 
+#include <cstring>
 #include "common.h"
 
 void origin_host_pool_run(int n, const std::function<void(int)> &task);  // thresh.hip (C++ linkage)
@@ -219,9 +220,21 @@ int origin_ctx_create(int device, origin_ctx **out) {
   ctx->aux_pending = false;
   ctx->aux_scratch = nullptr;
   ctx->aux_scratch_bytes = 0;
+  ctx->cvt_stage[0] = ctx->cvt_stage[1] = nullptr;
+  ctx->cvt_ready = false;
   memset(ctx->prof_ms, 0, sizeof(ctx->prof_ms));
   memset(ctx->prof_n, 0, sizeof(ctx->prof_n));
-  hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  // ORIGIN_CTX_PRIORITY=high|low: queue priority of this context's main stream (measurements of
+  // concurrent contexts: a latency-bound chain beside a chip-filling pass, tools/pca_glr_overlap.py)
+  hipError_t e;
+  const char *prio = getenv("ORIGIN_CTX_PRIORITY");
+  if (prio && (!strcmp(prio, "high") || !strcmp(prio, "low"))) {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = least urgent, hi = most urgent
+    e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio[0] == 'h' ? hi : lo);
+  } else {
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  }
   if (e != hipSuccess) {
     delete ctx;
     origin_set_error("hipStreamCreate: %s", hipGetErrorString(e));
@@ -248,6 +261,12 @@ int origin_ctx_destroy(origin_ctx *ctx) {
     hipStreamDestroy(ctx->aux_stream);
     hipEventDestroy(ctx->aux_fork);
     hipEventDestroy(ctx->aux_join);
+  }
+  if (ctx->cvt_ready) {
+    for (int b = 0; b < 2; ++b) {
+      hipHostFree(ctx->cvt_stage[b]);
+      hipEventDestroy(ctx->cvt_ev[b]);
+    }
   }
   if (ctx->aux_scratch) hipFree(ctx->aux_scratch);
   if (ctx->scratch) hipFree(ctx->scratch);
@@ -335,11 +354,51 @@ int origin_h2d(origin_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
   return ORIGIN_OK;
 }
 
+// Reads of device arrays by the host wait for pending work of the auxiliary stream too (cont_dct /
+// ima_dct of origin_dct_cont_std_async): a caller that forgot origin_aux_join would otherwise get
+// a half-written array without any error.
+static int aux_before_read(origin_ctx *ctx) {
+  if (ctx->aux_stream && ctx->aux_pending) {
+    ORIGIN_HIP(hipStreamWaitEvent(ctx->stream, ctx->aux_join, 0));
+    ctx->aux_pending = false;
+  }
+  return ORIGIN_OK;
+}
+
 int origin_d2h(origin_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
   ORIGIN_USE(ctx);
   if (bytes == 0) return ORIGIN_OK;
+  { int rca = aux_before_read(ctx); if (rca) return rca; }
   ORIGIN_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   ORIGIN_HIP(hipStreamSynchronize(ctx->stream));
+  return ORIGIN_OK;
+}
+
+// Staging of the two conversions below: owned by the context (its device, its stream), marked
+// ready only when both buffers and both events exist; a partial failure is rolled back.
+constexpr size_t CVT_CH = (size_t)16 << 20;  // elements per chunk: 64 MiB of float32
+static int cvt_staging(origin_ctx *ctx) {
+  if (ctx->cvt_ready) return ORIGIN_OK;
+  float *st[2] = {nullptr, nullptr};
+  hipEvent_t ev[2];
+  int nev = 0;
+  hipError_t e = hipSuccess;
+  for (int b = 0; b < 2 && e == hipSuccess; ++b)
+    e = hipHostMalloc((void **)&st[b], CVT_CH * sizeof(float), hipHostMallocDefault);
+  for (int b = 0; b < 2 && e == hipSuccess; ++b) {
+    e = hipEventCreateWithFlags(&ev[b], hipEventDisableTiming);
+    if (e == hipSuccess) ++nev;
+  }
+  for (int b = 0; b < 2 && e == hipSuccess; ++b) e = hipEventRecord(ev[b], ctx->stream);
+  if (e != hipSuccess) {
+    for (int b = 0; b < nev; ++b) (void)hipEventDestroy(ev[b]);
+    for (int b = 0; b < 2; ++b)
+      if (st[b]) (void)hipHostFree(st[b]);
+    origin_set_error("conversion staging: %s", hipGetErrorString(e));
+    return e == hipErrorOutOfMemory ? ORIGIN_E_NOMEM : ORIGIN_E_HIP;
+  }
+  for (int b = 0; b < 2; ++b) ctx->cvt_stage[b] = st[b], ctx->cvt_ev[b] = ev[b];
+  ctx->cvt_ready = true;
   return ORIGIN_OK;
 }
 
@@ -351,15 +410,15 @@ int origin_d2h_f32_as_f64(origin_ctx *ctx, double *h_dst, const float *d_src, si
   ORIGIN_USE(ctx);
   if (n == 0) return ORIGIN_OK;
   ORIGIN_CHECK_ARG(h_dst && d_src, "null pointer");
-  constexpr size_t CH = (size_t)16 << 20;  // elements per chunk: 64 MiB of float32
-  static thread_local float *stage[2] = {nullptr, nullptr};
-  static thread_local hipEvent_t ev[2];
-  if (!stage[0]) {
-    for (int b = 0; b < 2; ++b) {
-      ORIGIN_HIP(hipHostMalloc((void **)&stage[b], CH * sizeof(float), hipHostMallocDefault));
-      ORIGIN_HIP(hipEventCreateWithFlags(&ev[b], hipEventDisableTiming));
-    }
-  }
+  constexpr size_t CH = CVT_CH;
+  int rcs = cvt_staging(ctx);
+  if (rcs) return rcs;
+  if ((rcs = aux_before_read(ctx))) return rcs;
+  float *const *stage = ctx->cvt_stage;
+  hipEvent_t *ev = ctx->cvt_ev;
+  // (a narrowing upload may still be reading the buffers)
+  ORIGIN_HIP(hipEventSynchronize(ev[0]));
+  ORIGIN_HIP(hipEventSynchronize(ev[1]));
   const size_t nch = (n + CH - 1) / CH;
   auto issue = [&](size_t c) -> int {
     const size_t o = c * CH, m = std::min(CH, n - o);
@@ -392,16 +451,11 @@ int origin_h2d_f64_as_f32(origin_ctx *ctx, float *d_dst, const double *h_src, si
   ORIGIN_USE(ctx);
   if (n == 0) return ORIGIN_OK;
   ORIGIN_CHECK_ARG(d_dst && h_src, "null pointer");
-  constexpr size_t CH = (size_t)16 << 20;  // elements per chunk
-  static thread_local float *stage[2] = {nullptr, nullptr};
-  static thread_local hipEvent_t ev[2];
-  if (!stage[0]) {
-    for (int b = 0; b < 2; ++b) {
-      ORIGIN_HIP(hipHostMalloc((void **)&stage[b], CH * sizeof(float), hipHostMallocDefault));
-      ORIGIN_HIP(hipEventCreateWithFlags(&ev[b], hipEventDisableTiming));
-      ORIGIN_HIP(hipEventRecord(ev[b], ctx->stream));
-    }
-  }
+  constexpr size_t CH = CVT_CH;
+  int rcs = cvt_staging(ctx);
+  if (rcs) return rcs;
+  float *const *stage = ctx->cvt_stage;
+  hipEvent_t *ev = ctx->cvt_ev;
   const size_t nch = (n + CH - 1) / CH;
   for (size_t c = 0; c < nch; ++c) {
     const size_t o = c * CH, m = std::min(CH, n - o);
@@ -440,6 +494,10 @@ int origin_copy_box(origin_ctx *ctx, int kind, void *dst, long dst_pitch_y, long
                        src_pitch_z >= src_pitch_y * (long)(ny > 0 ? 1 : 0),
                    "plane pitch smaller than a row");
   if (nz == 0 || ny == 0 || nx == 0) return ORIGIN_OK;
+  if (kind == 1) {
+    int rca = aux_before_read(ctx);
+    if (rca) return rca;
+  }
   hipMemcpyKind k = kind == 0   ? hipMemcpyHostToDevice
                     : kind == 1 ? hipMemcpyDeviceToHost
                                 : hipMemcpyDeviceToDevice;

@@ -47,6 +47,8 @@ int make_ctab(origin_ctx *ctx, int Nz, int order, double **d_tab) {
     for (int k = 0; k < NK; ++k) h[(size_t)z * NK + k] = std::cos((z + 0.5) * (M_PI / Nz) * k);
   if (ctx->ctab) {
     ORIGIN_HIP(hipStreamSynchronize(ctx->stream));
+    // (a continuum pass on the auxiliary stream may still be reading the table)
+    if (ctx->aux_stream && ctx->aux_pending) ORIGIN_HIP(hipStreamSynchronize(ctx->aux_stream));
     ORIGIN_HIP(hipFree(ctx->ctab));
     ctx->ctab = nullptr;
   }

@@ -173,8 +173,11 @@ int origin_where_above(origin_ctx *ctx, const float *d_cube, const uint8_t *d_au
                        uint8_t *d_auxout, long *h_count) {
   ORIGIN_USE(ctx);
   ORIGIN_CHECK_ARG(d_cube && h_count && Nz > 0 && Ny > 0 && Nx > 0, "bad arguments");
-  ORIGIN_CHECK_ARG(thr == thr, "NaN threshold");
   ORIGIN_CHECK_ARG(cap >= 0 && (cap == 0 || (d_z && d_y && d_x)), "cap > 0 needs d_z, d_y, d_x");
+  if (thr != thr) {  // np.where(cube > nan) is empty (step 6 without a purity crossing hands a NaN
+    *h_count = 0;    // threshold to step 7, reference steps.py:935-939, and the step carries on)
+    return ORIGIN_OK;
+  }
   ORIGIN_CHECK_ARG(!d_auxout || d_aux, "d_auxout without d_aux");
   ORIGIN_CHECK_ARG(((uintptr_t)d_cube & 15) == 0, "d_cube must be 16-byte aligned");
   const long S = (long)Ny * Nx, n = (long)Nz * S;

@@ -232,6 +232,10 @@ def init_comm(rank, world, local_rank, backend=None, group=None):
     return TileComm(rank, world, local_rank, backend, group)
 
 
+# names of rounds 1-2, kept as aliases (deprecated: use TileComm / Tiling)
+TorchComm = TileComm
+
+
 # ------------------------------------------------------------------------------- halo
 def _copy_box(ctx, dst, dst_shape, dst_off, src, src_shape, src_off, box):
     """device->device copy of an (nz, ny, nx) box between float32 cubes of the given shapes."""
@@ -364,6 +368,9 @@ class TiledGLR:
         self._strips = {}
 
     def run(self, cube_faint, mask, correl, profile, correl_min):
+        """Returns the caller's correl / profile / correl_min and the tile's maxmap / minmap.  The
+        two maps are DeviceArrays OWNED BY THIS OBJECT and rewritten by the next call: copy them
+        (``.to_host()`` / ``.copy()``) to keep them across steps."""
         ctx = self.ctx
         top, bot, left, right = self.halos
         Nz, ny, nx = self.shape

@@ -712,6 +712,9 @@ def test_where_above_is_numpy_where(ctx, shape):
             assert np.array_equal(got["aux"], aux[z, y, x])
     only = kernels.where_above(ctx, d_cube, 1.5)              # without the gathered cube
     assert "aux" not in only and np.array_equal(only["z"], np.where(cube > 1.5)[0])
+    # a NaN threshold (step 6 found no purity crossing): np.where(cube > nan) is empty
+    none = kernels.where_above(ctx, d_cube, float("nan"), aux=d_aux)
+    assert none["z"].size == 0 and none["value"].size == 0 and none["aux"].size == 0
 
 
 def test_where_above_large_cube_properties(ctx):

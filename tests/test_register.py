@@ -113,3 +113,23 @@ def test_registered_chain_equals_standalone_chain(ref):
     np.testing.assert_array_equal(a.thresO2, b.thresO2)
     assert a.param['threshold'] == b.param['threshold']
     assert a.param['compute_TGLR']['params'] == dict(size=3, ncpu=1, pcut=1e-8, pmeansub=True)
+
+
+def test_register_against_the_real_reference_module():
+    """oracle/check_register.py: register() on the reference's REAL muse_origin/steps.py
+    (metaclass, Step.__call__, STEPS, the way ORIGIN.__init__ instantiates the steps) -- build
+    container only: needs /root/reference and the conda interpreter that has astropy; the
+    reference never travels to the GPU box, where this test skips itself."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    py = "/opt/conda/bin/python3.9"
+    if not (os.path.exists("/root/reference/muse_origin/steps.py") and os.path.exists(py)):
+        pytest.skip("the reference / its interpreter are not on this machine")
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    r = subprocess.run([py, os.path.join(root, "oracle", "check_register.py")], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out[-3000:]
+    assert out.strip().endswith("OK")
+    assert "reference module: /root/reference/muse_origin/steps.py" in out

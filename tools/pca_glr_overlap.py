@@ -15,7 +15,15 @@ from origin_amd.device import Context, DeviceArray
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 delay_ms = float(sys.argv[2]) if len(sys.argv) > 2 else 17.0
 Nz = 3681
-a, b = Context(0), Context(0)
+# ORIGIN_OVERLAP_PRIO=1: the PCA's context on a high-priority queue, the GLR's on a low-priority one
+if os.environ.get("ORIGIN_OVERLAP_PRIO") == "1":
+    os.environ["ORIGIN_CTX_PRIORITY"] = "high"
+    a = Context(0)
+    os.environ["ORIGIN_CTX_PRIORITY"] = "low"
+    b = Context(0)
+    del os.environ["ORIGIN_CTX_PRIORITY"]
+else:
+    a, b = Context(0), Context(0)
 f = synth.SyntheticField(Nz, N, N)
 raw, var, mask = f.arrays()
 d_raw, d_var, d_mask = a.to_device(raw), a.to_device(var), a.to_device(mask.astype(np.uint8))
