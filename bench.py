@@ -38,7 +38,7 @@ PROFILE_KERNELS = {"glr_spectral": ["spectral_mfma2_kernel", "spectral3_kernel"]
                    "dct_fit": ["dct_moments_kernel"], "dct_plane_sums": ["dct_part_reduce_kernel"],
                    "dct_standardize": ["dct_standardize_kernel"],
                    "pca_deflate_dot": ["deflate_dot_rows_kernel", "deflate_dot_kernel"],
-                   "pca_flush": ["flush_kernel"], "local_max": ["local_max3_kernel"]}
+                   "pca_flush": ["flush_kernel"], "local_max": ["local_max3v_kernel", "local_max3_kernel"]}
 
 
 def executed_tflops(mfma_instructions, avg_launch_s):
@@ -155,7 +155,10 @@ def main():
                     help="side of the sub-field for the PCIe-inclusive pass (host arrays in, host "
                          "arrays out through the Step seam); 0 = skip")
     ap.add_argument("--glr-precision", choices=("f16x2", "f32", "bf16"), default="f16x2")
-    ap.add_argument("--local-max", action="store_true", help="also time compute_local_max")
+    ap.add_argument("--no-local-max", dest="local_max", action="store_false",
+                    help="leave compute_local_max (the last dense pass of ComputeTGLR.run, reference "
+                         "steps.py:796) out of the step")
+    ap.set_defaults(local_max=True)
     ap.add_argument("--area-size", type=int, default=100,
                     help="side of the square PCA areas (development: 128 makes area rows "
                          "cache-line aligned)")
@@ -203,8 +206,9 @@ def main():
     field = synth.SyntheticField(*field_args)
 
     if world > 1:
+        # halo: the PSF's half width, plus one spaxel for the 3x3x3 local maxima of the tile
         tiling = multigpu.Tiling(field.Ny, field.Nx, world, area_size=args.area_size,
-                                 halo=field.PSF.shape[-1] // 2)
+                                 halo=field.PSF.shape[-1] // 2 + (1 if args.local_max else 0))
         tile = tiling.tile(rank)
         y0, y1, x0, x1 = tile.y0, tile.y1, tile.x0, tile.x1
     else:
@@ -250,7 +254,7 @@ def main():
 
     cube_std = ctx.empty((Nz, ny, nx), np.float32)
     cont_dct = ctx.empty((Nz, ny, nx), np.float32)
-    cube_faint = ctx.empty((Nz, ny, nx), np.float32)
+    cube_faint = ctx.empty((Nz, ny, nx), np.float32) if world == 1 else None  # (tiled: in glr.ext)
     correl = ctx.empty((Nz, ny, nx), np.float32)
     correl_min = ctx.empty((Nz, ny, nx), np.float32)
     profile = ctx.empty((Nz, ny, nx), np.uint8)
@@ -272,6 +276,8 @@ def main():
     # the kernel)
     lmax_buf = ctx.empty(correl.shape, np.float32) if args.local_max else None
     lmin_buf = ctx.empty(correl.shape, np.float32) if args.local_max else None
+
+    glr_key = "glr_and_local_max" if args.local_max else "glr"
 
     def one_step():
         t0 = time.perf_counter()
@@ -299,22 +305,28 @@ def main():
         t1 = time.perf_counter()
         thr = pipeline.pca_threshold(o2, local_map, nb_local, 0.01, spx=spx)
         t2 = time.perf_counter()
+        # tiled: cube_faint is written straight into the interior of the GLR's halo-extended tile
+        # (origin_pca_run_into) -- the tile lives there, no copy before the halo exchange
         F, mapO2, nstop, drv = pipeline.greedy_pca(ctx, cube_std, local_map, nb_local,
                                                    thr["thresO2"], thr["testO2"], 50, 100,
                                                    spx=spx, inplace=False, driver=pca_driver,
-                                                   o2_dev=pre["o2"], out=cube_faint)
+                                                   o2_dev=pre["o2"],
+                                                   out=cube_faint if world == 1 else None,
+                                                   into=glr.faint_target() if world > 1 else None)
         t3 = time.perf_counter()
         if world > 1:
-            out = glr.run(cube_faint, mask, correl, profile, correl_min)
+            out = glr.run(None, mask, correl, profile, correl_min,
+                          local_max=(lmax_buf, lmin_buf) if args.local_max else None)
         else:
             out = plan.run(cube_faint, mask=mask, correl=correl, profile=profile,
                            correl_min=correl_min, want_maps=True)
-        if args.local_max:
-            kernels.local_max(ctx, correl, correl_min, mask, 3, out_max=lmax_buf, out_min=lmin_buf)
+            if args.local_max:   # cube_local_max / cube_local_min (steps.py:796)
+                kernels.local_max(ctx, correl, correl_min, mask, 3, out_max=lmax_buf,
+                                  out_min=lmin_buf)
         ctx.sync()
         t4 = time.perf_counter()
         for k, v in (("dct_std", t1 - t0), ("threshold_fit_host", t2 - t1),
-                     ("greedy_pca", t3 - t2), ("glr", t4 - t3)):
+                     ("greedy_pca", t3 - t2), (glr_key, t4 - t3)):
             phase[k] = phase.get(k, 0.0) + v
         info["pca_iters"] = drv.iterations
         info["n_nuis_first"] = drv.trace[0][1] if drv.trace else 0
@@ -375,6 +387,7 @@ def main():
         "dct_standardize": ("hbm", 17.0 * local_vox),   # + cube_std 4 + cont_dct 4
         "pca_deflate_dot": ("hbm", 4.0),                # per voxel of the launch's areas
         "pca_flush": ("hbm", 8.0 * local_vox),
+        "local_max": ("hbm", 17.0 * local_vox),        # correl 4 + correl_min 4 + mask 1 in, 2 x 4 out
         # flops per launch for the compute-bound GLR stages (fp32 FMA = 2 flop)
         "glr_spatial": ("mfma", 2.0 * 25 * 25 * local_vox),
         "glr_spectral": ("mfma", 2.0 * ntaps * local_vox),
@@ -467,7 +480,7 @@ def main():
         tot = comm.allreduce_sum(np.array([(it_mean or 0.0) * len(spx), float(len(spx))]))
         it_mean = float(tot[0] / max(tot[1], 1.0))
     if rank == 0 and it_mean is not None:
-        bpv = 17.0 + 14.0 + 4.0 * (it_mean + 2.0)
+        bpv = 17.0 + 14.0 + 4.0 * (it_mean + 2.0) + (17.0 if args.local_max else 0.0)
         gbs = bpv * Nz * N * N / (ms_per_step * 1e-3) / 1e9
         path_hbm = dict(bytes_per_voxel=round(bpv, 2), achieved=round(gbs, 1),
                         peak=HBM_PEAK_GBS * world, unit="GB/s",
@@ -475,8 +488,10 @@ def main():
                         # SURVEY 8(d) asks for both peaks: the 8 TB/s of the data sheet and the
                         # 6.29 TB/s a float4 copy reaches (MI355X_MICROARCH.md)
                         frac_of_measured_copy=round(gbs / (6290.0 * world), 4),
-                        note="algorithmic bytes of DCT+standardise, greedy PCA and GLR over the "
-                             "step time; the GLR stages are MFMA-bound (see roofline)")
+                        note="algorithmic bytes of DCT+standardise (17 B/voxel), greedy PCA "
+                             "(4 (n_iter + 2)), GLR (14)" + (" and the 3x3x3 local maxima (17)"
+                                                            if args.local_max else "") +
+                             " over the step time; the GLR stages are MFMA-bound (see roofline)")
 
     # ---- CPU baseline: the oracle on a centred crop, all host cores, rank 0, N == 1 ----
     cpu_baseline = None
@@ -520,6 +535,8 @@ def main():
         else:
             gtol = dict(tol=1e-4, tol_argmax=1e-4)
             gtxt = "GLR |dT|<=1e-4, argmax mismatch<=1e-4"
+        if args.local_max:   # bit-exact check of the local maxima on the same windows
+            out = dict(out, local_max=lmax_buf, local_min=lmin_buf)
         glr_res = [wc.check_glr_window(cube_faint, out, mask, psf64, field.profiles, w,
                                        nthreads=ncpu, **gtol) for w in wins]
         # PCA: the area that iterated longest and (full) the one with the median count
@@ -541,8 +558,9 @@ def main():
             dct_res.append(r_)
         check = dict(level=args.check, glr=glr_res, pca=pca_res, dct=dct_res,
                      ok=bool(all(r_["ok"] for r_ in glr_res + pca_res + dct_res)),
-                     tolerances=gtxt + "; PCA rel-Frobenius<=2e-6, "
-                                "max-abs<=1e-4, mapO2 identical; DCT 1e-5*max(1,|x|)",
+                     tolerances=gtxt + "; local maxima bit exact on the device's correl; PCA "
+                                "rel-Frobenius<=2e-6, max-abs<=1e-4, mapO2 identical; DCT "
+                                "1e-5*max(1,|x|)",
                      oracle="oracle.cpu_ref (float64) on haloed windows / whole areas of the "
                             "device arrays of the last step",
                      seconds=round(time.perf_counter() - t, 1))
@@ -578,13 +596,20 @@ def main():
     # ---- per-rank phase times and PCA imbalance (each rank fills its row of one all-reduce) ----
     per_rank = None
     if comm is not None:
-        keys = ("dct_std", "threshold_fit_host", "greedy_pca", "glr")
+        keys = ("dct_std", "threshold_fit_host", "greedy_pca", glr_key)
         row = np.zeros((world, len(keys) + 3))
         row[rank, :len(keys)] = [1e3 * phase.get(k_, 0.0) / max(1, args.steps) for k_ in keys]
         row[rank, len(keys):] = [info.get("pca_iters", 0), len(spx), float(ny * nx)]
         allrows = comm.allreduce_sum(row.reshape(-1)).reshape(world, -1)
+        def mx_mean(v):
+            v = np.asarray(v, dtype=float)
+            return round(float(v.max() / max(v.mean(), 1e-300)), 3)
         per_rank = dict(phases_ms={k_: [round(v, 2) for v in allrows[:, i]]
                                    for i, k_ in enumerate(keys)},
+                        imbalance=dict(note="max / mean over the ranks (1 = even)",
+                                       tiling=tiling.balance(),
+                                       pca_iterations=mx_mean(allrows[:, len(keys)]),
+                                       **{k_: mx_mean(allrows[:, i]) for i, k_ in enumerate(keys)}),
                         pca_iterations=[int(v) for v in allrows[:, len(keys)]],
                         areas=[int(v) for v in allrows[:, len(keys) + 1]],
                         spaxels=[int(v) for v in allrows[:, len(keys) + 2]],
@@ -595,6 +620,9 @@ def main():
     if rank == 0:
         line = {
             "metric": "voxels/s through DCT+PCA+GLR (ORIGIN hot path)",
+            "step": "Preprocessing (DCT, standardise) -> PCA thresholds -> greedy PCA -> TGLR "
+                    "(correl, correl_min, profile, maxmap, minmap" +
+                    (", cube_local_max, cube_local_min)" if args.local_max else ")"),
             "value": round(value, 1),
             "unit": "voxels/s",
             "n_gpus": 1 if share_gpu else world,

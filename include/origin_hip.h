@@ -226,12 +226,24 @@ int origin_o2(origin_ctx *ctx, const float *d_cube, int Nz, long S, double *d_ou
  * filtered-index quirk of :908-917), b = mean background (:917), Xp = X - b(b^T X)
  * (:920-923; the division by sum(b^2) at :924 only rescales Xp), G = Xp^T Xp with
  * v_mfma_f64_16x16x4_f64 and its leading eigenvector (repeated squaring on the f64 matrix
- * cores up to 96 columns, restarted Lanczos above) in place of svds(k=1) (:940), u = Xp v/|Xp v|, F -= u u^T F and the new O2 test (:943-946). */
+ * cores up to 96 columns; above, Lanczos with the matrix resident in the registers and LDS of
+ * one CU, converged to a Ritz residual of 1e-14 and verified against G) in place of svds(k=1)
+ * (:940), u = Xp v/|Xp v|, F -= u u^T F and the new O2 test (:943-946). */
 int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S, int na,
                    const int *d_spx,
                    const long *h_spx_off, const double *d_test0, const double *h_thr,
                    double noise_pop, int itermax, int *d_mapO2, int *h_nstop, int *h_iters,
                    long *h_trace, int trace_cap);
+/* The same with cube_faint written into a box of a larger cube: d_F is the box's first element,
+ * spaxel y * out_nx + x of the (Nz, S) input goes to d_F[z * out_pz + y * out_py + x].  The tiled
+ * path (origin_amd/multigpu.py) points it at the interior of the halo-extended tile the GLR
+ * reads, so that no copy stands between the greedy PCA and the halo exchange.  d_X must be a
+ * separate contiguous cube.  out_nx == 0: identical to origin_pca_run. */
+int origin_pca_run_into(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S, int na,
+                        const int *d_spx, const long *h_spx_off, const double *d_test0,
+                        const double *h_thr, double noise_pop, int itermax, int *d_mapO2,
+                        int *h_nstop, int *h_iters, long *h_trace, int trace_cap, int out_nx,
+                        long out_py, long out_pz);
 
 /* Pieces of the above exposed for unit tests.  gram: G_a = X_a^T X_a for `nmat` float64
  * matrices X_a ([Nz][ld_a] at d_Xp + xp_off[a], ld_a a multiple of 16); the caller lists the

@@ -96,6 +96,24 @@ def check_glr_window(faint, dev_out, mask, psf, profiles, window, pcut=1e-8, pme
             dm = d.to_host()[y0 + a0:y0 + a1, x0 + b0:x0 + b1]
             res[key] = float(np.max(np.abs(dm - ref_map)))
             ok = ok and bool(np.all(np.abs(dm - ref_map) <= bound(ref_map)))
+    # compute_local_max (lib_origin.py:1220-1256) of the DEVICE's correl / correl_min on this window
+    # against the device's local maxima: index work on identical float32 inputs, bit exact.  A
+    # 3x3x3 window needs its neighbours: one more spaxel is dropped at the window's cut edges.
+    if dev_out.get("local_max") is not None and dev_out.get("local_min") is not None:
+        dc = dev_out["correl"].window(y0, y1, x0, x1).astype(np.float64)
+        dm = dev_out["correl_min"].window(y0, y1, x0, x1).astype(np.float64)
+        mk = mask.window(y0, y1, x0, x1).astype(bool) if mask is not None else \
+            np.zeros(dc.shape, bool)
+        rmax, rmin = cpu_ref.compute_local_max(dc, dm, mk, 3)
+        i0, i1 = (1 if y0 > 0 else 0), dc.shape[1] - (1 if y1 < Ny else 0)
+        j0, j1 = (1 if x0 > 0 else 0), dc.shape[2] - (1 if x1 < Nx else 0)
+        inner = (slice(None), slice(i0, i1), slice(j0, j1))
+        gmax = dev_out["local_max"].window(y0, y1, x0, x1)[inner]
+        gmin = dev_out["local_min"].window(y0, y1, x0, x1)[inner]
+        res["local_max_mismatch"] = int(np.count_nonzero(gmax != rmax[inner]) +
+                                        np.count_nonzero(gmin != rmin[inner]))
+        res["local_maxima"] = int(np.count_nonzero(gmax))
+        ok = ok and res["local_max_mismatch"] == 0 and res["local_maxima"] > 0
     res["ok"] = bool(ok)
     return res
 

@@ -67,6 +67,8 @@ SIGNATURES = {
     "origin_o2": [vp, vp, i32, i64, vp],
     "origin_pca_run": [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, C.c_double, i32, vp, PP(i32),
                        PP(i32), vp, i32],
+    "origin_pca_run_into": [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, C.c_double, i32, vp,
+                            PP(i32), PP(i32), vp, i32, i32, i64, i64],
     "origin_pca_gram": [vp, vp, vp, vp, i32, i32, vp, vp, vp, i64, vp, vp],
     "origin_pca_eig": [vp, vp, vp, vp, vp, i32, i64, vp, vp, vp, vp],
     "origin_pca_eig_qrows": [],

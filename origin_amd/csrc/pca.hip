@@ -2496,7 +2496,10 @@ __global__ __launch_bounds__(256, 4) void flush_kernel(const float *X, float *F,
                                                     const long *__restrict__ FD, int nf,
                                                     const double *__restrict__ U,
                                                     const double *__restrict__ C, long ntot,
-                                                    int nxb, int nzb) {
+                                                    int nxb, int nzb, int out_nx, long out_py,
+                                                    long out_pz) {
+  // out_nx > 0: F is a box inside a larger cube (the halo-extended tile of the tiled path):
+  // spaxel col = y * out_nx + x of the (Nz, S) input goes to F[z * out_pz + y * out_py + x]
   // FD: [4][nf] = area, list0, ns, T
   __shared__ double Us[FLUSH_ZB][PCA_CAP];  // this block's rows of U (zero beyond T / Nz)
   // 1-D grid decoded so that the blocks of neighbouring areas for the same rows and channels
@@ -2517,6 +2520,8 @@ __global__ __launch_bounds__(256, 4) void flush_kernel(const float *X, float *F,
   const bool live = li < ns;
   const long pos = FD[(long)1 * nf + k] + (live ? li : ns - 1);
   const long col = spx[pos];
+  const long fcol = out_nx > 0 ? (col / out_nx) * out_py + (col % out_nx) : col;
+  const long fS = out_nx > 0 ? out_pz : S;
   const double *Ua = U + FD[k] * (long)Nz * PCA_CAP;
   const int z0 = by * FLUSH_ZB;
   for (int i = threadIdx.x; i < FLUSH_ZB * PCA_CAP; i += 256) {
@@ -2552,7 +2557,7 @@ __global__ __launch_bounds__(256, 4) void flush_kernel(const float *X, float *F,
 #pragma unroll
     for (int r = 0; r < FLUSH_ZB; ++r) {
       const int z = z0 + r;
-      if (z < Nz) F[(long)z * S + col] = (float)((double)xv[r] - acc[r]);
+      if (z < Nz) F[(long)z * fS + fcol] = (float)((double)xv[r] - acc[r]);
     }
   }
 }
@@ -2607,7 +2612,7 @@ struct HostBuf {
 };
 
 struct PcaWorkspace {
-  DevBuf b[20];
+  DevBuf b[21];
   HostBuf h_nnb, h_stage;
 };
 
@@ -2732,13 +2737,20 @@ int origin_pca_eig(origin_ctx *ctx, const double *d_G, const long *d_g_off, cons
 
 int origin_pca_eig_qrows(void) { return EIG_QROWS; }
 
-// The whole greedy PCA of `na` areas, in place on d_F.
-int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S, int na,
-                   const int *d_spx,
-                   const long *h_spx_off, const double *d_test0, const double *h_thr,
-                   double noise_pop, int itermax, int *d_mapO2, int *h_nstop, int *h_iters,
-                   long *h_trace, int trace_cap) {
+// The whole greedy PCA of `na` areas; d_F receives cube_faint.  out_nx > 0: d_F is the first
+// element of an (Nz, S / out_nx, out_nx) box inside a larger cube with row pitch out_py and plane
+// pitch out_pz (elements) -- the interior of a halo-extended tile, so that the tiled path needs no
+// copy between the PCA and the halo exchange; d_X must then be a different, contiguous cube.
+int origin_pca_run_into(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S, int na,
+                        const int *d_spx, const long *h_spx_off, const double *d_test0,
+                        const double *h_thr, double noise_pop, int itermax, int *d_mapO2,
+                        int *h_nstop, int *h_iters, long *h_trace, int trace_cap, int out_nx,
+                        long out_py, long out_pz) {
   ORIGIN_USE(ctx);
+  const bool strided = out_nx > 0;
+  ORIGIN_CHECK_ARG(!strided || (d_X && d_X != d_F && S % out_nx == 0 && out_py >= out_nx &&
+                                out_pz >= (S / out_nx) * out_py),
+                   "strided output needs a separate contiguous input and consistent pitches");
   ORIGIN_CHECK_ARG(d_F && d_spx && h_spx_off && d_test0 && h_thr && d_mapO2 && h_nstop &&
                        Nz > 0 && S > 0 && na > 0,
                    "bad arguments");
@@ -2752,8 +2764,15 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
   if (h_iters) *h_iters = 0;
   *h_nstop = 0;
   ORIGIN_HIP(hipMemsetAsync(d_mapO2, 0, (size_t)S * sizeof(int), st));
-  if (src != d_F && ntot < S)  // spaxels outside every area are simply copied
-    ORIGIN_HIP(hipMemcpyAsync(d_F, d_X, (size_t)Nz * S * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (src != d_F && ntot < S) {  // spaxels outside every area are simply copied
+    if (strided) {
+      int rcb = origin_copy_box(ctx, 2, d_F, out_py, out_pz, d_X, out_nx, S, Nz, (int)(S / out_nx),
+                                out_nx, (int)sizeof(float));
+      if (rcb) return rcb;
+    } else {
+      ORIGIN_HIP(hipMemcpyAsync(d_F, d_X, (size_t)Nz * S * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+  }
   if (ntot == 0) return ORIGIN_OK;
 
   // ---- persistent state on the device
@@ -2859,8 +2878,22 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
   // (Flushing the areas that have finished at once, on a second low-priority or CU-masked stream
   // in the shadow of the iterations that go on, was built and measured: no gain -- 25.4-25.5 ms
   // against 25.0-25.1; the one-block kernels of the chain slow down by what the flush overlaps.)
-  auto flush = [&]() -> int {
-    const bool all = src != d_F;
+  // (strided output: a flush in the middle of the run -- an area used up its PCA_CAP slots -- goes
+  // to a contiguous work cube the later passes read; only the final one writes d_F)
+  float *d_work = nullptr;
+  auto flush = [&](bool final) -> int {
+    float *dst = d_F;
+    if (strided && !final) {
+      int rw = W.b[20].reserve(ctx, (size_t)Nz * S * sizeof(float));
+      if (rw) return rw;
+      if (!d_work && ntot < S)
+        ORIGIN_HIP(hipMemcpyAsync(W.b[20].p, d_X, (size_t)Nz * S * sizeof(float),
+                                  hipMemcpyDeviceToDevice, st));
+      d_work = (float *)W.b[20].p;
+      dst = d_work;
+    }
+    const bool to_strided = strided && final;
+    const bool all = src != dst;
     std::vector<long> fd;
     int nf = 0, nsmax = 0;
     auto wanted = [&](int a) { return (all || T[a] > 0) && h_spx_off[a + 1] > h_spx_off[a]; };
@@ -2886,14 +2919,15 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
       ProfScope ps(ctx, K_PCA_FLUSH, 2);
       const int nxb = cdiv(nsmax, 256), nzb = cdiv(Nz, FLUSH_ZB);
       const long ngroups = ((long)nxb * nzb + 7) / 8;  // groups of 8 (spaxel chunk, channel block)
-      hipLaunchKernelGGL(flush_kernel, dim3((unsigned)(ngroups * nf * 8)), dim3(256), 0, st, src, d_F,
-                         Nz, S, d_spx, (const long *)b_fd.p, nf, d_U, d_C, ntot, nxb, nzb);
+      hipLaunchKernelGGL(flush_kernel, dim3((unsigned)(ngroups * nf * 8)), dim3(256), 0, st, src, dst,
+                         Nz, S, d_spx, (const long *)b_fd.p, nf, d_U, d_C, ntot, nxb, nzb,
+                         to_strided ? out_nx : 0, out_py, out_pz);
       ORIGIN_LAUNCH_CHECK();
     }
     for (int a = 0; a < na; ++a) T[a] = 0;
     std::fill(fb_off.begin(), fb_off.end(), -1L);  // (blocks refer to columns of U)
     std::fill(s_valid.begin(), s_valid.end(), (char)0);  // (sums refer to the cube read so far)
-    src = d_F;
+    src = dst;
     return ORIGIN_OK;
   };
   // LDS cache of the select kernel: the largest area, if it fits in 120 KiB
@@ -2995,7 +3029,7 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
         full = full || T[a] >= PCA_CAP;
       }
     if (nw == 0) break;
-    if (full && (rc = flush())) return rc;  // an area used up its PCA_CAP slots
+    if (full && (rc = flush(false))) return rc;  // an area used up its PCA_CAP slots
     D.assign((size_t)DF_COUNT * nw, 0);
     long xp = 0, c = 0, g = 0, q = 0, cb = 0;
     int ldmax = 0, nsmax = 0, k = 0;
@@ -3235,12 +3269,20 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
   if (getenv("ORIGIN_PCA_TIMING"))
     fprintf(stderr, "[pca] host loop: %d iterations, build %.2f ms, enqueue %.2f ms, wait %.2f ms\n",
             iters, 1e3 * t_build, 1e3 * t_enq, 1e3 * t_wait);
-  if ((rc = flush())) return rc;
+  if ((rc = flush(true))) return rc;
   ORIGIN_HIP(hipMemcpyAsync(h_nnb, d_nstop, sizeof(int), hipMemcpyDeviceToHost, st));
   ORIGIN_HIP(hipStreamSynchronize(st));
   *h_nstop = h_nnb[0];
   if (h_iters) *h_iters = iters;
   return ORIGIN_OK;
+}
+
+int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S, int na,
+                   const int *d_spx, const long *h_spx_off, const double *d_test0,
+                   const double *h_thr, double noise_pop, int itermax, int *d_mapO2, int *h_nstop,
+                   int *h_iters, long *h_trace, int trace_cap) {
+  return origin_pca_run_into(ctx, d_X, d_F, Nz, S, na, d_spx, h_spx_off, d_test0, h_thr, noise_pop,
+                             itermax, d_mapO2, h_nstop, h_iters, h_trace, trace_cap, 0, 0, 0);
 }
 
 }  // extern "C"

@@ -1,15 +1,17 @@
 """Spatial tiling of the hot path over the GPUs of one node.
 
-One process per GPU.  The field is cut into a gy x gx grid of tiles whose boundaries follow
-the PCA area grid, so every area lives on exactly one GPU and the greedy PCA needs no
-communication.  Two exchanges remain:
+One process per GPU.  The field is cut into one rectangle per GPU along the PCA area grid (row
+bands with their own column cuts, so that the fullest tile holds as few areas as possible), so
+every area lives on exactly one GPU and the greedy PCA needs no communication.  Two exchanges
+remain:
 
 * one all-reduce of 2*Nz float64 (per-channel sum and count of the DCT residual) for the
   ``nanmean`` over the *whole* field in the standardisation (reference steps.py:442);
-* one halo exchange of ``cube_faint`` before the GLR: strips of P//2 spaxels from the (up to)
-  8 neighbours, done in two phases (x, then y including the fresh x halos, which delivers
-  the corners without diagonal messages).  Outside the true field nothing is exchanged:
-  the kernels zero-pad there exactly as the reference's ``fftconvolve(..., 'same')`` does.
+* one halo exchange of ``cube_faint`` before the GLR, in ONE phase: every rank sends each
+  other rank the part of its tile that lies inside that rank's halo-extended box (edge strips
+  and corner blocks; P//2 spaxels wide, + 1 when the local maxima are computed on the tiles).
+  Outside the true field nothing is exchanged: the kernels zero-pad there exactly as the
+  reference's ``fftconvolve(..., 'same')`` does.
 
 The GLR then runs on the halo-extended tile as if it were a field of its own: spatial sums
 of kept spaxels only touch data inside the extension, and their border class is the class
@@ -27,7 +29,7 @@ import numpy as np
 
 from . import _capi, kernels
 
-Tile = namedtuple("Tile", "rank ty tx y0 y1 x0 x1")
+Tile = namedtuple("Tile", "rank ty tx y0 y1 x0 x1")   # ty: row band, tx: position in the band
 
 
 def _split(n_units, parts):
@@ -38,50 +40,126 @@ def _split(n_units, parts):
     return edges
 
 
-def grid_shape(world):
-    """gy x gx with gy*gx == world, as square as possible, gx >= gy."""
-    gy = int(np.floor(np.sqrt(world)))
-    while world % gy:
-        gy -= 1
-    return gy, world // gy
+def _compositions(total, parts, lo=1):
+    """All ways to write `total` as an ordered sum of `parts` integers >= lo."""
+    if parts == 1:
+        if total >= lo:
+            yield (total,)
+        return
+    for first in range(lo, total - lo * (parts - 1) + 1):
+        for rest in _compositions(total - first, parts - 1, lo):
+            yield (first,) + rest
+
+
+def grid_shape(world, nay=None, nax=None):
+    """gy x gx with gy*gx == world.  Without an area grid: as square as possible, gx >= gy.
+    With one (nay x nax areas): the factorisation whose fullest tile holds the fewest areas,
+    then the squarest, then gx >= gy."""
+    if nay is None or nax is None:
+        gy = int(np.floor(np.sqrt(world)))
+        while world % gy:
+            gy -= 1
+        return gy, world // gy
+    best = None
+    for gy in range(1, world + 1):
+        if world % gy:
+            continue
+        gx = world // gy
+        if gy > nay or gx > nax:
+            continue
+        worst = int(np.ceil(nay / gy)) * int(np.ceil(nax / gx))
+        key = (worst, abs(gy - gx), gy > gx)
+        if best is None or key < best[0]:
+            best = (key, (gy, gx))
+    if best is None:
+        raise ValueError(f"{world} tiles do not fit a {nay}x{nax} area grid")
+    return best[1]
+
+
+def band_layout(world, nay, nax):
+    """Row bands, each cut into its own number of columns: (rows per band, ranks per band) with
+    the smallest number of areas in the fullest tile -- the greedy PCA of a rank costs at least its
+    share of the areas, and DCT / GLR go with the spaxels.  A regular gy x gx grid is the special
+    case of equal bands; when world does not divide the area grid evenly the bands win: 9 x 9
+    areas on 8 ranks are 15 areas at most as a 2 x 4 grid, 12 as bands of 4 / 3 / 2 rows with
+    3 / 3 / 2 ranks (the bound is ceil(81 / 8) = 11).  Ties: fewer bands, then the most even
+    rows."""
+    best = None
+    for nb in range(1, min(world, nay) + 1):
+        for ranks in _compositions(world, nb):
+            if max(ranks) > nax:
+                continue
+            for rows in _compositions(nay, nb):
+                worst = max(h * int(np.ceil(nax / r)) for h, r in zip(rows, ranks))
+                key = (worst, nb, max(rows) - min(rows), max(ranks) - min(ranks), rows, ranks)
+                if best is None or key < best[0]:
+                    best = (key, (rows, ranks))
+    if best is None:
+        raise ValueError(f"{world} tiles do not fit a {nay}x{nax} area grid")
+    return best[1]
 
 
 class Tiling:
-    """Tile grid aligned to the area grid (areas are area_size x area_size squares, the last
-    one absorbs the remainder, as synth.grid_areamap builds them)."""
+    """Partition of the field into one rectangle per rank, cut along the area grid (areas are
+    area_size x area_size squares, the last one of a row / column absorbs the remainder, as
+    synth.grid_areamap builds them), so that every PCA area lives on exactly one GPU.
 
-    def __init__(self, Ny, Nx, world, area_size=100, halo=12):
+    layout="bands" (default): row bands with their own column cuts (band_layout);
+    layout="grid": a regular gy x gx grid (grid_shape) -- what rounds 1-2 used."""
+
+    def __init__(self, Ny, Nx, world, area_size=100, halo=12, layout="bands"):
         self.Ny, self.Nx, self.world, self.halo = Ny, Nx, world, halo
-        self.gy, self.gx = grid_shape(world)
         nay, nax = max(1, Ny // area_size), max(1, Nx // area_size)
-        if self.gy > nay or self.gx > nax:
-            raise ValueError(f"{world} tiles do not fit a {nay}x{nax} area grid")
-        ey = _split(nay, self.gy) * area_size
-        ex = _split(nax, self.gx) * area_size
-        ey[-1], ex[-1] = Ny, Nx
-        self.ey, self.ex = ey, ex
+        self.nay, self.nax, self.area_size = nay, nax, area_size
+        if layout == "grid":
+            gy, gx = grid_shape(world, nay, nax)
+            rows = tuple(int(v) for v in np.diff(_split(nay, gy)))
+            ranks = (gx,) * gy
+        elif layout == "bands":
+            rows, ranks = band_layout(world, nay, nax)
+        else:
+            raise ValueError("layout must be 'bands' or 'grid'")
+        self.rows, self.ranks = rows, ranks
+        self.tiles, self._areas = [], []
+        ay0 = 0
+        for ty, (h, nr) in enumerate(zip(rows, ranks)):
+            y0 = ay0 * area_size
+            y1 = Ny if ay0 + h == nay else (ay0 + h) * area_size
+            ex = _split(nax, nr)
+            for tx in range(nr):
+                x0 = int(ex[tx]) * area_size
+                x1 = Nx if ex[tx + 1] == nax else int(ex[tx + 1]) * area_size
+                self.tiles.append(Tile(len(self.tiles), ty, tx, y0, y1, x0, x1))
+                self._areas.append(h * int(ex[tx + 1] - ex[tx]))
+            ay0 += h
+        # a regular grid is described by (gy, gx); other band layouts have no single gx
+        self.gy = len(rows)
+        self.gx = ranks[0] if len(set(ranks)) == 1 else None
 
     def tile(self, rank):
-        ty, tx = divmod(rank, self.gx)
-        return Tile(rank, ty, tx, int(self.ey[ty]), int(self.ey[ty + 1]), int(self.ex[tx]),
-                    int(self.ex[tx + 1]))
+        return self.tiles[rank]
 
-    def neighbour(self, rank, dy, dx):
-        ty, tx = divmod(rank, self.gx)
-        ny_, nx_ = ty + dy, tx + dx
-        if 0 <= ny_ < self.gy and 0 <= nx_ < self.gx:
-            return ny_ * self.gx + nx_
-        return None
+    def balance(self):
+        """max / mean over the ranks of the tile's spaxels (DCT, GLR work) and of its areas (the
+        PCA's work, to first order): what the tiling costs against an even split."""
+        spx = [float((t.y1 - t.y0) * (t.x1 - t.x0)) for t in self.tiles]
+        ar = [float(a) for a in self._areas]
+        return dict(spaxels=float(max(spx) / np.mean(spx)), areas=float(max(ar) / np.mean(ar)),
+                    rows_per_band=[int(v) for v in self.rows],
+                    ranks_per_band=[int(v) for v in self.ranks])
 
     def extended(self, rank):
         """Extent of the tile plus its halo, clipped to the field: (y0, y1, x0, x1) and the
         halo widths (top, bottom, left, right) actually present."""
-        t, h = self.tile(rank), self.halo
-        top = h if t.ty > 0 else 0
-        bot = h if t.ty < self.gy - 1 else 0
-        left = h if t.tx > 0 else 0
-        right = h if t.tx < self.gx - 1 else 0
+        t, h = self.tiles[rank], self.halo
+        top = min(h, t.y0)
+        bot = min(h, self.Ny - t.y1)
+        left = min(h, t.x0)
+        right = min(h, self.Nx - t.x1)
         return (t.y0 - top, t.y1 + bot, t.x0 - left, t.x1 + right), (top, bot, left, right)
+
+    def min_tile_side(self):
+        return min(min(t.y1 - t.y0, t.x1 - t.x0) for t in self.tiles)
 
 
 # ------------------------------------------------------------------------------- comm
@@ -249,58 +327,69 @@ def _copy_box(ctx, dst, dst_shape, dst_off, src, src_shape, src_off, box):
                src_shape[1] * src_shape[2], nz, ny, nx, es)
 
 
-def halo_plan(tiling, rank, ny, nx):
-    """The two exchange phases of one rank as plain index boxes (no data):
-    [(phase, peer, send_src, recv_dst, (by, bx)), ...] where phase 0 strips are cut from the
-    bare tile (y, x offsets in tile coordinates) and phase 1 strips from the extended tile
-    (offsets in extended coordinates); recv_dst is always in extended coordinates."""
-    (_, _, _, _), (top, bot, left, right) = tiling.extended(rank)
-    h = tiling.halo
-    nx_e = nx + left + right
-    plan = []
-    for dx, src_x, dst_x in ((-1, 0, 0), (1, nx - h, left + nx)):
-        peer = tiling.neighbour(rank, 0, dx)
-        if peer is not None:
-            plan.append((0, peer, (0, src_x), (top, dst_x), (ny, h)))
-    for dy, src_y, dst_y in ((-1, top, 0), (1, top + ny - h, top + ny)):
-        peer = tiling.neighbour(rank, dy, 0)
-        if peer is not None:
-            plan.append((1, peer, (src_y, 0), (dst_y, 0), (h, nx_e)))
-    return plan
+def halo_plan(tiling, rank):
+    """The halo exchange of one rank as plain index boxes (no data), ONE phase for any partition
+    into rectangles: rank r sends to every other rank t the part of its own tile that lies inside
+    t's halo-extended box, and receives from every u the part of u's tile inside its own extended
+    box (edge strips and corner blocks alike; a tile of another band can cover part of an edge).
+    Returns (sends, recvs): lists of (peer, (y, x) offset, (by, bx) size), offsets in this
+    rank's TILE coordinates for sends and in its EXTENDED coordinates for receives, both ordered by
+    peer -- what rank r sends to t is, box for box, what t receives from r."""
+    me = tiling.tile(rank)
+    (ey0, ey1, ex0, ex1), _ = tiling.extended(rank)
+    sends, recvs = [], []
+    for other in range(tiling.world):
+        if other == rank:
+            continue
+        o = tiling.tile(other)
+        (oy0, oy1, ox0, ox1), _ = tiling.extended(other)
+        # my interior inside the other's extended box
+        y0, y1 = max(me.y0, oy0), min(me.y1, oy1)
+        x0, x1 = max(me.x0, ox0), min(me.x1, ox1)
+        if y1 > y0 and x1 > x0:
+            sends.append((other, (y0 - me.y0, x0 - me.x0), (y1 - y0, x1 - x0)))
+        # the other's interior inside my extended box
+        y0, y1 = max(o.y0, ey0), min(o.y1, ey1)
+        x0, x1 = max(o.x0, ex0), min(o.x1, ex1)
+        if y1 > y0 and x1 > x0:
+            recvs.append((other, (y0 - ey0, x0 - ex0), (y1 - y0, x1 - x0)))
+    return sends, recvs
 
 
 def exchange_halo(ctx, comm, tiling, rank, cube, ext=None, bufs=None):
-    """Build the halo-extended copy of this rank's (Nz, ny, nx) device tile.  Returns the
-    extended DeviceArray (Nz, ny + top + bot, nx + left + right).  ``bufs``: a dict the
-    caller keeps between calls so that the strip buffers are allocated once."""
-    Nz, ny, nx = cube.shape
+    """Fill the halo of this rank's extended device tile (Nz, ny + top + bot, nx + left + right).
+    ``cube``: the bare (Nz, ny, nx) tile, copied into the interior first -- or None when the
+    interior of ``ext`` already holds it (the greedy PCA can write there directly).  ``bufs``: a
+    dict the caller keeps between calls so that the strip buffers are allocated once."""
+    t = tiling.tile(rank)
+    ny, nx = t.y1 - t.y0, t.x1 - t.x0
     (_, _, _, _), (top, bot, left, right) = tiling.extended(rank)
+    Nz = (cube if cube is not None else ext).shape[0]
     eshape = (Nz, ny + top + bot, nx + left + right)
     if ext is None:
         ext = ctx.empty(eshape, np.float32)
-    _copy_box(ctx, ext, eshape, (0, top, left), cube, cube.shape, (0, 0, 0), (Nz, ny, nx))
-    plan = halo_plan(tiling, rank, ny, nx)
-    for phase in (0, 1):
-        src, sshape = (cube, cube.shape) if phase == 0 else (ext, eshape)
-        sends, recvs, unpack = [], [], []
-        for ph, peer, (sy, sx), (dy, dx), (by, bx) in plan:
-            if ph != phase:
-                continue
-            key = (phase, peer, Nz, by, bx)
-            if bufs is not None and key in bufs:
-                sbuf, rbuf = bufs[key]
-            else:
-                sbuf = ctx.empty((Nz, by, bx), np.float32)
-                rbuf = ctx.empty((Nz, by, bx), np.float32)
+    if cube is not None:
+        _copy_box(ctx, ext, eshape, (0, top, left), cube, cube.shape, (0, 0, 0), (Nz, ny, nx))
+    plan_s, plan_r = halo_plan(tiling, rank)
+    sends, recvs, unpack = [], [], []
+    for kind, items in (("s", plan_s), ("r", plan_r)):
+        for peer, (oy, ox), (by, bx) in items:
+            key = (kind, peer, Nz, by, bx)
+            buf = bufs.get(key) if bufs is not None else None
+            if buf is None:
+                buf = ctx.empty((Nz, by, bx), np.float32)
                 if bufs is not None:
-                    bufs[key] = (sbuf, rbuf)
-            _copy_box(ctx, sbuf, sbuf.shape, (0, 0, 0), src, sshape, (0, sy, sx), (Nz, by, bx))
-            sends.append((peer, sbuf))
-            recvs.append((peer, rbuf))
-            unpack.append((rbuf, (0, dy, dx), (Nz, by, bx)))
-        comm.exchange(ctx, sends, recvs)
-        for rbuf, off, box in unpack:
-            _copy_box(ctx, ext, eshape, off, rbuf, rbuf.shape, (0, 0, 0), box)
+                    bufs[key] = buf
+            if kind == "s":   # cut from the interior of ext (tile coordinates + halo offset)
+                _copy_box(ctx, buf, buf.shape, (0, 0, 0), ext, eshape, (0, top + oy, left + ox),
+                          (Nz, by, bx))
+                sends.append((peer, buf))
+            else:
+                recvs.append((peer, buf))
+                unpack.append((buf, (0, oy, ox), (Nz, by, bx)))
+    comm.exchange(ctx, sends, recvs)
+    for rbuf, off, box in unpack:
+        _copy_box(ctx, ext, eshape, off, rbuf, rbuf.shape, (0, 0, 0), box)
     return ext
 
 
@@ -311,21 +400,14 @@ def exchange_halo_host(comm, tiling, rank, tile):
     (_, _, _, _), (top, bot, left, right) = tiling.extended(rank)
     ext = np.zeros((Nz, ny + top + bot, nx + left + right), dtype=tile.dtype)
     ext[:, top: top + ny, left: left + nx] = tile
-    plan = halo_plan(tiling, rank, ny, nx)
-    for phase in (0, 1):
-        src = tile if phase == 0 else ext
-        sends, recvs, pending = [], [], []
-        for ph, peer, (sy, sx), (dy, dx), (by, bx) in plan:
-            if ph != phase:
-                continue
-            sends.append((peer, np.ascontiguousarray(src[:, sy: sy + by, sx: sx + bx])))
-            rbuf = np.empty((Nz, by, bx), dtype=tile.dtype)
-            recvs.append((peer, rbuf))
-            pending.append((rbuf, dy, dx, by, bx))
-        if sends:
-            comm.group.exchange(sends, recvs)
-        for rbuf, dy, dx, by, bx in pending:
-            ext[:, dy: dy + by, dx: dx + bx] = rbuf
+    plan_s, plan_r = halo_plan(tiling, rank)
+    sends = [(peer, np.ascontiguousarray(tile[:, oy: oy + by, ox: ox + bx]))
+             for peer, (oy, ox), (by, bx) in plan_s]
+    recvs = [(peer, np.empty((Nz, by, bx), dtype=tile.dtype)) for peer, _, (by, bx) in plan_r]
+    if sends or recvs:
+        comm.group.exchange(sends, recvs)
+    for (peer, (oy, ox), (by, bx)), (_, rbuf) in zip(plan_r, recvs):
+        ext[:, oy: oy + by, ox: ox + bx] = rbuf
     return ext
 
 
@@ -343,11 +425,9 @@ class TiledGLR:
         need = int(np.asarray(psf0).shape[-1]) // 2
         if tiling.halo < need:
             raise ValueError(f"tiling halo {tiling.halo} is smaller than the PSF half width {need}")
-        for r in range(tiling.world):
-            t_ = tiling.tile(r)
-            if min(t_.y1 - t_.y0, t_.x1 - t_.x0) < tiling.halo:
-                raise ValueError(f"tile {r} ({t_.y1 - t_.y0}x{t_.x1 - t_.x0}) is narrower than "
-                                 f"the halo {tiling.halo}")
+        if tiling.min_tile_side() < tiling.halo:
+            raise ValueError(f"a tile is narrower than the halo {tiling.halo}: a halo must come "
+                             "from the tiles next to this one, not from beyond them")
         (y0, y1, x0, x1), self.halos = tiling.extended(rank)
         self.eshape = (Nz, y1 - y0, x1 - x0)
         wext = None
@@ -366,14 +446,27 @@ class TiledGLR:
                          minmap=ctx.empty(self.shape[1:], np.float32))
         self._mask_set = False
         self._strips = {}
+        self._lm = None   # extended local-maxima cubes, allocated by the first run that wants them
 
-    def run(self, cube_faint, mask, correl, profile, correl_min):
+    def faint_target(self):
+        """``into`` argument of pipeline.greedy_pca: the interior of the extended tile.  A PCA run
+        that writes there is followed by ``run(None, ...)`` -- no copy of the tile in between."""
+        top, _, left, _ = self.halos
+        return (self.ext, top, left)
+
+    def run(self, cube_faint, mask, correl, profile, correl_min, local_max=None, size=3):
         """Returns the caller's correl / profile / correl_min and the tile's maxmap / minmap.  The
         two maps are DeviceArrays OWNED BY THIS OBJECT and rewritten by the next call: copy them
-        (``.to_host()`` / ``.copy()``) to keep them across steps."""
+        (``.to_host()`` / ``.copy()``) to keep them across steps.
+
+        ``local_max``: None, or a pair of tile-shaped DeviceArrays that receive
+        ``compute_local_max(correl, correl_min, mask, size)`` (reference steps.py:796).  The
+        maximum filter looks size // 2 spaxels beyond the tile, so the tiling's halo must be at
+        least P // 2 + size // 2: those neighbours are then exact values of the extended GLR."""
         ctx = self.ctx
         top, bot, left, right = self.halos
         Nz, ny, nx = self.shape
+        # cube_faint None: the greedy PCA wrote this step's tile straight into self.ext's interior
         exchange_halo(ctx, self.comm, self.tiling, self.rank, cube_faint, self.ext, self._strips)
         if mask is not None and not self._mask_set:  # halo spaxels are discarded: mask 0 there
             _copy_box(ctx, self.emask, self.eshape, (0, top, left), mask, mask.shape, (0, 0, 0),
@@ -390,5 +483,20 @@ class TiledGLR:
         for name in ("maxmap", "minmap"):
             _copy_box(ctx, self.maps[name], (1, ny, nx), (0, 0, 0), o[name], (1, e_ny, e_nx),
                       (0, top, left), (1, ny, nx))
-        return dict(correl=correl, profile=profile, correl_min=correl_min,
-                    maxmap=self.maps["maxmap"], minmap=self.maps["minmap"])
+        res = dict(correl=correl, profile=profile, correl_min=correl_min,
+                   maxmap=self.maps["maxmap"], minmap=self.maps["minmap"])
+        if local_max is not None:
+            need = self.plan.P // 2 + int(size) // 2
+            if self.tiling.halo < need:
+                raise ValueError(f"local maxima of size {size} on tiles need a halo of {need} "
+                                 f"spaxels, the tiling has {self.tiling.halo}")
+            if self._lm is None:
+                self._lm = (ctx.empty(self.eshape, np.float32), ctx.empty(self.eshape, np.float32))
+            kernels.local_max(ctx, o["correl"], o["correl_min"],
+                              self.emask if mask is not None else None, size,
+                              out_max=self._lm[0], out_min=self._lm[1])
+            for src, dst in zip(self._lm, local_max):
+                _copy_box(ctx, dst, dst.shape, (0, 0, 0), src, self.eshape, (0, top, left),
+                          (Nz, ny, nx))
+            res["local_max"], res["local_min"] = local_max
+        return res

@@ -37,9 +37,13 @@ class GreedyPCA:
         return self
 
     def run(self, F, area_spx, tests, thresholds, Noise_population=50, itermax=100,
-            test_map=None, want_map=True, src=None):
+            test_map=None, want_map=True, src=None, into=None):
         """F: DeviceArray (Nz, Ny, Nx) float32 receiving cube_faint; ``src`` (cube_std) is
         read instead of F when given (out of place), else F is updated in place.
+        ``into``: None, or ``(ext, top, left)`` -- cube_faint goes into the box of the larger
+        DeviceArray ``ext`` (Nz, Ny_e, Nx_e) that starts at row ``top``, column ``left``
+        (origin_pca_run_into; the tiled path's halo-extended tile); F is then None and ``src``
+        the (Nz, Ny, Nx) input.
         area_spx: per area, int32 flat spaxel indices in C order (``areamap == i``).
         tests: per area float64 O2 values in the same order (``testO2``); alternatively
         ``test_map``: a float64 DeviceArray [Ny*Nx] holding the O2 test of every spaxel (what
@@ -47,8 +51,9 @@ class GreedyPCA:
         Returns (mapO2 per area as float64 arrays, nstop); ``want_map="full"``: the int32 map
         over all S spaxels instead of the per-area arrays."""
         ctx = self.ctx
-        Nz = F.shape[0]
-        S = F.size // Nz
+        ref = src if into is not None else F
+        Nz = ref.shape[0]
+        S = ref.size // Nz
         na = len(area_spx)
         if na == 0:
             return [], 0
@@ -70,11 +75,24 @@ class GreedyPCA:
         nstop, iters = C.c_int(0), C.c_int(0)
         cap = int(itermax) + 2
         trace = np.zeros(2 * cap, dtype=np.int64)
-        _capi.call("origin_pca_run", ctx.handle, (src.p if src is not None else F.p), F.p, Nz, S,
-                   na, d_spx.p,
-                   off.ctypes.data_as(C.c_void_p), d_test.p, thr.ctypes.data_as(C.c_void_p),
-                   float(Noise_population), int(itermax), d_map.p, C.byref(nstop),
-                   C.byref(iters), trace.ctypes.data_as(C.c_void_p), cap)
+        if into is not None:
+            ext, top, left = into
+            _, ny_e, nx_e = ext.shape
+            nx = ref.shape[2]
+            if src is None or ext.shape[0] != Nz or top + ref.shape[1] > ny_e or left + nx > nx_e:
+                raise ValueError("`into` needs a separate source cube and a box inside `ext`")
+            first = C.c_void_p(ext.ptr + (top * nx_e + left) * 4)
+            _capi.call("origin_pca_run_into", ctx.handle, src.p, first, Nz, S, na, d_spx.p,
+                       off.ctypes.data_as(C.c_void_p), d_test.p, thr.ctypes.data_as(C.c_void_p),
+                       float(Noise_population), int(itermax), d_map.p, C.byref(nstop),
+                       C.byref(iters), trace.ctypes.data_as(C.c_void_p), cap, nx, nx_e,
+                       ny_e * nx_e)
+        else:
+            _capi.call("origin_pca_run", ctx.handle, (src.p if src is not None else F.p), F.p, Nz,
+                       S, na, d_spx.p,
+                       off.ctypes.data_as(C.c_void_p), d_test.p, thr.ctypes.data_as(C.c_void_p),
+                       float(Noise_population), int(itermax), d_map.p, C.byref(nstop),
+                       C.byref(iters), trace.ctypes.data_as(C.c_void_p), cap)
         self.iterations = iters.value
         self.trace = [(int(trace[2 * i]), int(trace[2 * i + 1]))
                       for i in range(min(iters.value, cap))]

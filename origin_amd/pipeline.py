@@ -77,13 +77,22 @@ def pca_threshold(o2_map, areamap, nbAreas, pfa_test=0.01, spx=None):
 
 
 def greedy_pca(ctx, cube_std, areamap, nbAreas, thresholds, testO2, Noise_population=50,
-               itermax=100, spx=None, inplace=False, driver=None, o2_dev=None, out=None):
+               itermax=100, spx=None, inplace=False, driver=None, o2_dev=None, out=None,
+               into=None):
     """``Compute_GreedyPCA_area`` (lib_origin.py:769-821) on a device cube.  Returns
     (cube_faint DeviceArray, mapO2 (Ny,Nx) float64, nstop, driver).  ``o2_dev``: the O2 map of
     cube_std still on the device (float64 [Ny,Nx]) -- used instead of ``testO2`` when given;
-    ``driver``: a GreedyPCA to reuse (keeps the area lists on the device between calls)."""
+    ``driver``: a GreedyPCA to reuse (keeps the area lists on the device between calls);
+    ``into = (ext, top, left)``: cube_faint is written into that box of the larger cube ``ext``
+    (the halo-extended tile of multigpu.TiledGLR) and the first return value is None."""
     Nz, Ny, Nx = cube_std.shape
     spx = area_lists(areamap, nbAreas) if spx is None else spx
+    if into is not None:
+        drv = driver or GreedyPCA(ctx)
+        hmap, nstop = drv.run(None, spx, testO2, [float(t) for t in thresholds],
+                              Noise_population, itermax, test_map=o2_dev, src=cube_std,
+                              want_map="full", into=into)
+        return None, hmap.astype(np.float64).reshape(Ny, Nx), nstop, drv
     # cube_faint = cube_std.copy() (:799): the copy is folded into the final F = X - U C pass
     F = cube_std if inplace else (out if out is not None else ctx.empty(cube_std.shape,
                                                                         np.float32))

@@ -55,7 +55,8 @@ def main():
                               backend="rccl" if mode == "rccl" else "host", group=group)
     f, raw, var, mask = field()
     Nz, Ny, Nx = raw.shape
-    tiling = multigpu.Tiling(Ny, Nx, world, area_size=20, halo=f.PSF.shape[1] // 2)
+    # (+1: the 3x3x3 local maxima of the tile look one spaxel beyond it)
+    tiling = multigpu.Tiling(Ny, Nx, world, area_size=20, halo=f.PSF.shape[1] // 2 + 1)
     t = tiling.tile(rank)
     sl = (slice(None), slice(t.y0, t.y1), slice(t.x0, t.x1))
     traw, tvar, tmask = raw[sl], var[sl], mask[sl]
@@ -88,9 +89,11 @@ def main():
             wts_ = [w_[ey0:ey1, ex0:ex1] for w_ in wfull]
         g = cpu_ref.compute_TGLR(ext, psf_, wts_, f.profiles, emask, pcut=1e-8)
         crop = (slice(None), slice(top, top + tmask.shape[1]), slice(left, left + tmask.shape[2]))
+        lmax, lmin = cpu_ref.compute_local_max(g["cube_correl"], g["cube_correl_min"], emask, 3)
         res = dict(cube_std=data, cube_faint=faint, correl=g["cube_correl"][crop],
                    correl_min=g["cube_correl_min"][crop], mapO2=mapO2,
-                   maxmap=g["maxmap"][crop[1:]], thr=np.array(thr[3]))
+                   maxmap=g["maxmap"][crop[1:]], thr=np.array(thr[3]),
+                   local_max=lmax[crop], local_min=lmin[crop])
     else:
         from origin_amd import kernels, pipeline
         from origin_amd.device import Context
@@ -107,21 +110,32 @@ def main():
                                       allreduce=comm.allreduce_sum)
         spx = pipeline.area_lists(lmap, len(labels))
         thr = pipeline.pca_threshold(pre["o2"].to_host(), lmap, len(labels), 0.01, spx=spx)
-        faint, mapO2, nstop, _ = pipeline.greedy_pca(ctx, pre["cube_std"], lmap, len(labels),
-                                                     thr["thresO2"], thr["testO2"], spx=spx)
         psf_, wts_ = (f.PSF.astype(float), None)
         if weighted:
             psf_, wts_ = mosaic(f)
         glr = multigpu.TiledGLR(ctx, comm, tiling, rank, Nz, psf_, f.profiles, pcut=1e-8,
                                 weights=wts_)
         shape = d_raw.shape
+        # TILED_INTO=1: the PCA writes cube_faint straight into the interior of the GLR's
+        # halo-extended tile (origin_pca_run_into), no copy in between -- what bench.py does
+        into = os.environ.get("TILED_INTO", "1") == "1"
+        faint, mapO2, nstop, _ = pipeline.greedy_pca(ctx, pre["cube_std"], lmap, len(labels),
+                                                     thr["thresO2"], thr["testO2"], spx=spx,
+                                                     into=glr.faint_target() if into else None)
         correl = ctx.empty(shape, np.float32)
         cmin = ctx.empty(shape, np.float32)
         prof = ctx.empty(shape, np.uint8)
-        o = glr.run(faint, d_mask, correl, prof, cmin)
-        res = dict(cube_std=pre["cube_std"].to_host(), cube_faint=faint.to_host(),
+        lm = (ctx.empty(shape, np.float32), ctx.empty(shape, np.float32))
+        o = glr.run(faint, d_mask, correl, prof, cmin, local_max=lm)
+        if into:   # the tile lives inside the extended buffer
+            top, _, left, _ = glr.halos
+            faint_host = glr.ext.window(top, top + shape[1], left, left + shape[2])
+        else:
+            faint_host = faint.to_host()
+        res = dict(cube_std=pre["cube_std"].to_host(), cube_faint=faint_host,
                    correl=correl.to_host(), correl_min=cmin.to_host(), mapO2=mapO2,
-                   maxmap=o["maxmap"].to_host(), thr=np.array(thr["thresO2"]))
+                   maxmap=o["maxmap"].to_host(), thr=np.array(thr["thresO2"]),
+                   local_max=lm[0].to_host(), local_min=lm[1].to_host())
     np.savez(f"{out}.rank{rank}.npz", y0=t.y0, y1=t.y1, x0=t.x0, x1=t.x1, **res)
     comm.barrier()
     comm.close()

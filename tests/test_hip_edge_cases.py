@@ -180,11 +180,16 @@ def test_bad_arguments_raise(ctx, hip):
                                    [np.zeros(3)])  # testO2 length != area size
 
 
-@pytest.mark.parametrize("shape", [(1, 1, 1), (2, 3, 5), (7, 1, 70), (5, 17, 1), (40, 19, 130)])
+@pytest.mark.parametrize("shape", [(1, 1, 1), (2, 3, 5), (7, 1, 70), (5, 17, 1), (40, 19, 130),
+                                   (3, 1, 4), (9, 5, 8), (33, 7, 260), (70, 9, 600), (12, 66, 132),
+                                   (6, 3, 1028)])
 @pytest.mark.parametrize("size", [3, 5])
 def test_local_max_small_and_ragged_shapes(hip, shape, size):
-    """3x3x3 z-marching kernel (size 3) and the generic kernel on shapes smaller than a tile,
-    single planes / rows / columns; plateaus (equal neighbours) and masked voxels included."""
+    """3x3x3 z-marching kernels (size 3: the four-samples-per-lane form when Nx % 4 == 0 -- rows
+    that end inside a wave, waves that end inside a row, rows shorter than a wave, a row count
+    that is not a multiple of the lane's row group, more than one z chunk --, the one-sample form
+    otherwise) and the generic kernel on shapes smaller than a tile, single planes / rows /
+    columns; plateaus (equal neighbours) and masked voxels included."""
     rng = np.random.default_rng(sum(shape) + size)
     correl = np.round(rng.standard_normal(shape) * 2).astype(np.float32).astype(float)  # ties
     cmin = -np.abs(np.round(rng.standard_normal(shape) * 2)).astype(np.float32).astype(float)

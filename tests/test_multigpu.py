@@ -58,20 +58,55 @@ def stitch(tiles, key, shape):
 
 def test_tiling_follows_area_grid():
     from origin_amd.multigpu import Tiling
-    for world, (gy, gx) in {1: (1, 1), 2: (1, 2), 4: (2, 2), 8: (2, 4)}.items():
-        tl = Tiling(600, 600, world, area_size=100, halo=12)
-        assert (tl.gy, tl.gx) == (gy, gx)
-        cover = np.zeros((600, 600), int)
-        for r in range(world):
-            t = tl.tile(r)
-            assert t.y0 % 100 == 0 and t.x0 % 100 == 0      # PCA areas never straddle tiles
-            cover[t.y0:t.y1, t.x0:t.x1] += 1
-            (ey0, ey1, ex0, ex1), (top, bot, left, right) = tl.extended(r)
-            assert ey0 >= 0 and ex0 >= 0 and ey1 <= 600 and ex1 <= 600
-            assert top == (12 if t.ty > 0 else 0) and right == (12 if t.tx < gx - 1 else 0)
-        assert np.all(cover == 1)
+    for (N, world), worst_areas in {(600, 1): 36, (600, 2): 18, (600, 4): 9, (600, 8): 5,
+                                    (900, 4): 21, (900, 8): 12, (900, 6): 15, (600, 5): 8}.items():
+        for layout in ("bands", "grid"):
+            if layout == "grid" and world == 5:
+                continue
+            tl = Tiling(N, N, world, area_size=100, halo=12, layout=layout)
+            cover = np.zeros((N, N), int)
+            for r in range(world):
+                t = tl.tile(r)
+                assert t.y0 % 100 == 0 and t.x0 % 100 == 0      # PCA areas never straddle tiles
+                cover[t.y0:t.y1, t.x0:t.x1] += 1
+                (ey0, ey1, ex0, ex1), (top, bot, left, right) = tl.extended(r)
+                assert ey0 >= 0 and ex0 >= 0 and ey1 <= N and ex1 <= N
+                assert top == (12 if t.y0 > 0 else 0) and right == (12 if t.x1 < N else 0)
+            assert np.all(cover == 1)
+            areas = [((t.y1 - t.y0) // 100) * ((t.x1 - t.x0) // 100) for t in tl.tiles]
+            if layout == "bands":   # the fullest tile: what band_layout minimises
+                assert max(areas) == worst_areas, (N, world, areas)
+                assert abs(tl.balance()["areas"] - max(areas) / np.mean(areas)) < 1e-12
+    # bands never do worse than the regular grid (900 x 900 on 8 ranks: 12 areas against 15)
+    assert max(Tiling(900, 900, 8, 100, 12, "grid")._areas) == 15
     with pytest.raises(ValueError):
         Tiling(100, 100, 4, area_size=100)
+
+
+@pytest.mark.parametrize("N,world,layout", [(600, 4, "grid"), (600, 8, "bands"), (900, 8, "bands"),
+                                            (600, 5, "bands"), (300, 3, "bands")])
+def test_one_phase_halo_plan_rebuilds_every_extended_tile(N, world, layout):
+    """halo_plan on plain arrays, all ranks in one process: what rank r sends to t is box for box
+    what t receives from r, and interior + received boxes rebuild exactly the window of the
+    field a rank's extended tile covers (edges, corners, neighbours of another band)."""
+    from origin_amd.multigpu import Tiling, halo_plan
+    tl = Tiling(N, N, world, area_size=100, halo=13, layout=layout)
+    field = np.arange(N * N, dtype=np.float64).reshape(N, N)
+    plans = [halo_plan(tl, r) for r in range(world)]
+    for r in range(world):
+        t = tl.tile(r)
+        (ey0, ey1, ex0, ex1), (top, bot, left, right) = tl.extended(r)
+        ext = np.full((ey1 - ey0, ex1 - ex0), -1.0)
+        ext[top:top + t.y1 - t.y0, left:left + t.x1 - t.x0] = field[t.y0:t.y1, t.x0:t.x1]
+        for peer, (oy, ox), (by, bx) in plans[r][1]:
+            # the matching send of the peer: same size, cut from the peer's tile
+            match = [s_ for s_ in plans[peer][0] if s_[0] == r]
+            assert len(match) == 1 and match[0][2] == (by, bx)
+            p = tl.tile(peer)
+            (sy, sx) = match[0][1]
+            ext[oy:oy + by, ox:ox + bx] = field[p.y0 + sy:p.y0 + sy + by, p.x0 + sx:p.x0 + sx + bx]
+        assert np.array_equal(ext, field[ey0:ey1, ex0:ex1])
+        assert all(peer != r for peer, _, _ in plans[r][0] + plans[r][1])
 
 
 @pytest.mark.parametrize("world,group", [(2, "rdv"), (4, "rdv"), (2, "gloo"), (4, "gloo")])
@@ -89,6 +124,14 @@ def test_tiled_oracle_equals_untiled_oracle(tmp_path, world, group):
         assert np.max(np.abs(got - ref[rk])) <= 1e-9 * max(1.0, np.max(np.abs(ref[rk]))), key
     assert np.array_equal(stitch(tiles, "mapO2", shape[1:]), ref["mapO2"])
     assert np.max(np.abs(stitch(tiles, "maxmap", shape[1:]) - ref["maxmap"])) <= 1e-9
+    # local maxima of the tiles (halo P//2 + 1): the same voxels are local maxima, same values
+    # (the stitched correl differs from the untiled one by rounding only: compare the support and
+    # the values to that rounding)
+    lmax, lmin = cpu_ref.compute_local_max(ref["cube_correl"], ref["cube_correl_min"], mask, 3)
+    for key, want in (("local_max", lmax), ("local_min", lmin)):
+        got = stitch(tiles, key, shape)
+        assert np.mean((got != 0) != (want != 0)) <= 1e-5, key
+        assert np.max(np.abs(got - want)[(got != 0) & (want != 0)]) <= 1e-9, key
 
 
 def test_tiled_weighted_mosaic_oracle_equals_untiled_oracle(tmp_path):
@@ -141,6 +184,9 @@ def test_tiled_hip_equals_single_hip(tmp_path, world):
         got, one = stitch(tiles, key, shape), stitch(single, key, shape)
         assert np.max(np.abs(got - one)) <= tol, key
     assert np.array_equal(stitch(tiles, "mapO2", shape[1:]), stitch(single, "mapO2", shape[1:]))
+    for key in ("local_max", "local_min"):   # (support can differ only where fp32 rounding ties)
+        got, one = stitch(tiles, key, shape), stitch(single, key, shape)
+        assert np.mean((got != 0) != (one != 0)) <= 1e-4, key
     # and against the oracle
     ref = cpu_ref.run_chain(raw.astype(float), var.astype(float), mask, f.PSF.astype(float), None,
                             f.profiles, f.areamap, f.nbAreas)
