@@ -279,7 +279,8 @@ def main():
 
     glr_key = "glr_and_local_max" if args.local_max else "glr"
 
-    def one_step():
+    def one_step(with_local_max=None):
+        do_lm = args.local_max if with_local_max is None else with_local_max
         t0 = time.perf_counter()
         ctx.aux_join()  # (coef_buf / cont_dct of the previous step: idle after its closing sync)
         coef, zsum, zcnt = kernels.dct_fit_sums(ctx, raw, var, mask, 10, False, coef=coef_buf,
@@ -316,11 +317,11 @@ def main():
         t3 = time.perf_counter()
         if world > 1:
             out = glr.run(None, mask, correl, profile, correl_min,
-                          local_max=(lmax_buf, lmin_buf) if args.local_max else None)
+                          local_max=(lmax_buf, lmin_buf) if do_lm else None)
         else:
             out = plan.run(cube_faint, mask=mask, correl=correl, profile=profile,
                            correl_min=correl_min, want_maps=True)
-            if args.local_max:   # cube_local_max / cube_local_min (steps.py:796)
+            if do_lm:   # cube_local_max / cube_local_min (steps.py:796)
                 kernels.local_max(ctx, correl, correl_min, mask, 3, out_max=lmax_buf,
                                   out_min=lmin_buf)
         ctx.sync()
@@ -358,9 +359,29 @@ def main():
     if comm is not None:
         elapsed = comm.max_float(elapsed)
     prof = ctx.prof_report()
+    # the same number of steps WITHOUT the local maxima -- the scope of the rounds-1/2 bench line
+    # (DCT + thresholds + PCA + GLR), timed the same way, so that lines of different rounds compare
+    saved_phase = dict(phase)
+    scope_r02 = None
+    if args.local_max:
+        barrier()
+        ctx.sync()
+        tq = time.perf_counter()
+        for _ in range(args.steps):
+            one_step(with_local_max=False)
+        ctx.sync()
+        barrier()
+        el2 = time.perf_counter() - tq
+        if comm is not None:
+            el2 = comm.max_float(el2)
+        scope_r02 = dict(step="the same steps without cube_local_max / cube_local_min (what "
+                              "rounds 1-2 timed)",
+                         ms_per_step=round(1e3 * el2 / max(1, args.steps), 3),
+                         value=round(float(Nz) * N * N * args.steps / el2, 1))
+        phase.clear()
+        phase.update(saved_phase)
     # per-kernel detail of the greedy PCA: one extra step OUTSIDE the timed region (an event
     # pair per PCA kernel costs ~10 us of stream time, ~5 ms per step)
-    saved_phase = dict(phase)
     ctx.prof_reset()
     ctx.prof_enable(2)
     one_step()
@@ -645,6 +666,7 @@ def main():
                        "glr_spectral_arithmetic": glr_precision, "tiles": world, "comm": (comm.backend + (" " + comm.note if comm.note else ""))
                        if comm is not None else None, "pca": info,
                        "gen_seconds": round(t_gen, 1)},
+            "without_local_max": scope_r02,
             "roofline": roofline,
             "path_hbm": path_hbm,
             "cpu_baseline": cpu_baseline,

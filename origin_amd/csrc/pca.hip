@@ -1991,7 +1991,11 @@ __device__ void lanczos_plain(const double *__restrict__ Gk, int n, int ld, doub
       tq = t;
     }
   };
-  constexpr int NRC = LP_NREG / RS, NLC = LP_NLDS / RS;  // column slots in registers / in LDS
+  // column slots in registers / in LDS.  (Eight rows per lane, n > 256, stream most of the matrix
+  // from L2 every step: ~70 GB/s per CU, 13 us per step at n = 315.  Trading register slots for
+  // 32 instead of 16 loads in flight was measured and is slower -- 1255 against 1134 us for that
+  // matrix's 86 steps: the CU's L2 bandwidth bounds it, not the latency.)
+  constexpr int NRC = LP_NREG / RS, NLC = LP_NLDS / RS;
   const int tid = threadIdx.x, lane = tid & 63;
   const int g = __builtin_amdgcn_readfirstlane(tid >> 6);  // column group = wave (uniform)
   const int ncol8 = (n + 7) >> 3;
@@ -2917,6 +2921,9 @@ int origin_pca_run_into(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, l
                                 st));
       ORIGIN_HIP(hipStreamSynchronize(st));
       ProfScope ps(ctx, K_PCA_FLUSH, 2);
+      // (Round 3 measured two more forms of this pass at 3681 x 600 x 600 and dropped them: the
+      // cube's memory order with one pass per area present in a wave, 3.39 ms; two / four spaxels
+      // per lane so that one LDS read of U serves several products, 3.0 / 3.8 ms; this form 2.83.)
       const int nxb = cdiv(nsmax, 256), nzb = cdiv(Nz, FLUSH_ZB);
       const long ngroups = ((long)nxb * nzb + 7) / 8;  // groups of 8 (spaxel chunk, channel block)
       hipLaunchKernelGGL(flush_kernel, dim3((unsigned)(ngroups * nf * 8)), dim3(256), 0, st, src, dst,
