@@ -1037,6 +1037,27 @@ int origin_glr_plan_create(origin_ctx *ctx, int Nz, int Ny, int Nx, int nfields,
   TRY(upload(ctx, taps2, &pl->d_taps2, &pl->bytes));
   TRY(upload(ctx, off, &pl->d_tap_off, &pl->bytes));
 
+  if (pl->mode == 1) {
+    // the norm cube of a weighted plan (padded like cube_fsf: MF_PAD_FRONT zero channels in front,
+    // MF_PAD_BACK behind) is a constant of the plan: allocated HERE, where the callers' memory
+    // checks run and plan->bytes is read, and filled by the first run
+    const size_t padded = ((size_t)Nz + MF_PAD_FRONT + MF_PAD_BACK) * (size_t)Ny * Nx;
+    hipError_t e = hipMalloc((void **)&pl->d_normc, padded * sizeof(float));
+    if (e != hipSuccess) {
+      origin_set_error("norm cube of the weighted plan (%zu bytes): %s", padded * sizeof(float),
+                       hipGetErrorString(e));
+      origin_glr_plan_destroy(pl);
+      return e == hipErrorOutOfMemory ? ORIGIN_E_NOMEM : ORIGIN_E_HIP;
+    }
+    e = hipMemsetAsync(pl->d_normc, 0, padded * sizeof(float), ctx->stream);
+    if (e != hipSuccess) {
+      origin_set_error("norm cube memset: %s", hipGetErrorString(e));
+      origin_glr_plan_destroy(pl);
+      return ORIGIN_E_HIP;
+    }
+    pl->bytes += padded * sizeof(float);
+    pl->normc_ready = 0;
+  }
   if (pl->mode == 0) {
     std::vector<int> border;
     const int c = P / 2;

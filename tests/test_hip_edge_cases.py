@@ -258,3 +258,45 @@ def test_pca_area_larger_than_the_register_resident_selection(hip):
     assert ref[1].max() >= 5
     assert got[2] == ref[2] and np.array_equal(got[1], ref[1])
     assert np.max(np.abs(got[0] - ref[0])) <= 1e-4
+
+
+@pytest.mark.parametrize("deep", [False, True])
+def test_pca_into_a_box_of_a_larger_cube(ctx, deep):
+    """origin_pca_run_into (the tiled path: cube_faint goes straight into the interior of the
+    halo-extended tile): bit for bit what the contiguous run writes, the rest of the larger cube
+    untouched -- with spaxels outside every area (copied through), and (deep) with an area that
+    needs more iterations than the 64 vector slots, whose flush in the middle of the run goes to a
+    contiguous work cube while only the final pass writes the strided box."""
+    from origin_amd import pipeline
+    rng = np.random.default_rng(77 + deep)
+    Nz, Ny, Nx = (240, 20, 25) if deep else (96, 12, 16)
+    cube = rng.standard_normal((Nz, Ny, Nx)).astype(np.float32)
+    flat = cube.reshape(Nz, -1)
+    n_src = 80 if deep else 9
+    for j in range(n_src):
+        flat[:, (5 if deep else 11) * j + 3] += (6.0 + 0.05 * j) * rng.standard_normal(Nz).astype(np.float32)
+    areamap = np.ones((Ny, Nx), int)
+    areamap[0, :] = 0                      # a row outside every area
+    if not deep:
+        areamap[:, Nx // 2:] = 2           # two areas
+        areamap[0, :] = 0
+    nb = int(areamap.max())
+    X = cube.astype(float)
+    tests = [cpu_ref.O2test(X[:, areamap == a + 1]) for a in range(nb)]
+    thr = [float(np.percentile(t, 83.5 if deep else 90.0)) for t in tests]
+    d = ctx.to_device(cube)
+    F, map_a, nstop_a, _ = pipeline.greedy_pca(ctx, d, areamap, nb, thr, tests, 50, 300)
+    want = F.to_host()
+    if deep:
+        assert map_a.max() > 64            # the run does flush in the middle
+    top, left = 3, 5
+    ext_h = np.full((Nz, Ny + 7, Nx + 9), -7.0, np.float32)
+    ext = ctx.to_device(ext_h)
+    none, map_b, nstop_b, _ = pipeline.greedy_pca(ctx, d, areamap, nb, thr, tests, 50, 300,
+                                                  into=(ext, top, left))
+    got = ext.to_host()
+    assert none is None and nstop_a == nstop_b and np.array_equal(map_a, map_b)
+    assert np.array_equal(got[:, top:top + Ny, left:left + Nx], want)
+    assert np.array_equal(want[:, 0, :], cube[:, 0, :])       # outside every area: copied
+    got[:, top:top + Ny, left:left + Nx] = -7.0
+    assert np.all(got == -7.0)                                 # nothing else was written
