@@ -187,7 +187,8 @@ def test_gram_mfma_matches_numpy(ctx):
                                         (150, "gap"), (200, "close"), (208, "flat"),
                                         (209, "close"), (256, "flat"), (257, "gap"),
                                         (300, "flat"), (400, "close"), (512, "flat"),
-                                        (513, "gap"), (700, "close")])
+                                        (513, "gap"), (700, "close"), (120, "lowrank"),
+                                        (230, "lowrank"), (300, "lowrank")])
 def test_lanczos_leading_eigenvector(ctx, n, spectrum):
     """Device eigen-solvers vs LAPACK on PSD matrices with wide, close and flat spectra:
     repeated squaring on the f64 matrix cores for n <= 48 and n <= 96; above, plain Lanczos
@@ -200,6 +201,8 @@ def test_lanczos_leading_eigenvector(ctx, n, spectrum):
         lam = np.concatenate([[1000.0], rng.uniform(0.1, 10, n - 1)])
     elif spectrum == "close":
         lam = np.concatenate([[1.0, 0.999], rng.uniform(0.0, 0.9, n - 2)])
+    elif spectrum == "lowrank":   # rank 2: the Krylov space is exhausted after two steps
+        lam = np.concatenate([[1000.0, 3.0], np.zeros(n - 2)])
     else:
         lam = 1.0 + 0.05 * rng.random(n)
     lam = np.sort(lam)[::-1]
