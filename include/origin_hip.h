@@ -331,6 +331,15 @@ int origin_glr_plan_bytes(origin_glr_plan *plan, size_t *bytes);
  * (partial edge tiles included); 0 for a stage that runs the fp32 kernels or the weighted forms.
  * bench.py prices `roofline.executed` with it (measurement). */
 int origin_glr_plan_mfma_count(origin_glr_plan *plan, long *spatial, long *spectral);
+/* FOLD of the matrix-core spectral stage (plans without weight maps): away from the cube's first
+ * and last 32 channels 1/sqrt(den_k[z]) = a_k s(z) (1 + e_k(z)) with a_k = 1/sqrt(sum p_k^2) and s
+ * a factor of the spaxel's border class alone; *eps = the plan's max |e| (measured on its own
+ * tables at creation; +inf for plans the stage does not serve).  Where eps <= 2e-6 (and K <= 24)
+ * the stage compares the profiles through accumulators that carry a_k and applies s(z) to the
+ * maximum and the minimum (*active = 1): correl and correl_min carry a relative error <= eps, the
+ * profile index is that of a maximum up to the same eps.
+ * ORIGIN_GLR_NO_FOLD=1 in the environment runs the exact form everywhere. */
+int origin_glr_plan_fold_eps(origin_glr_plan *plan, float *eps, int *active);
 /* The same arithmetic without a plan or a device (host only: num_cu compute units, `terms` = 3
  * for the f16 split, 1 for bf16; n_narrow = profiles of half width <= 16): lets the CPU tests
  * check bench.py's `executed` against the counter passes committed under profiles/. */

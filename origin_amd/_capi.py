@@ -83,6 +83,7 @@ SIGNATURES = {
     "origin_glr_plan_get_precision": [vp, PP(i32)],
     "origin_glr_plan_bytes": [vp, PP(sz)],
     "origin_glr_plan_mfma_count": [vp, PP(i64), PP(i64)],
+    "origin_glr_plan_fold_eps": [vp, PP(C.c_float), PP(i32)],
     "origin_glr_mfma_count_model": [i32, i32, i32, i32, i32, i32, i32, i32, PP(i64), PP(i64)],
     "origin_glr_work_elems": [vp, PP(sz)],
     "origin_glr_run": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],

@@ -56,7 +56,14 @@ struct origin_glr_plan {
   uint4 *d_atab2;      // the squared taps in the same layout (plans with an explicit norm cube)
   int *d_pwide;    // [K] processing order, narrow first: original index | (half width > 16) << 8
   int n_narrow;    // number of narrow profiles (the first n_narrow slots)
+  int order_ident; // the processing order is the caller's order (slot = index)
   float *d_rdi_s;  // interior-class 1/sqrt(den) in processing order [slot][NzP]
+  // FOLD (glr_spectral_mfma.hip): taps times a_k = 1/sqrt(sum p_k^2), the table 1/(a_k sqrt(den))
+  // [P*P][K][NzP], the class factors s [P*P][NzP]; fold_eps = max |1/(a_k sqrt(den)) / s - 1| over
+  // the FOLD channels (the tables are dropped when it exceeds MF_FOLD_EPS)
+  uint4 *d_atab_fold, *d_atab_bf16_fold;
+  float *d_rden_fold, *d_sden;
+  float fold_eps;
   std::vector<int> *h_order;  // processing order on the host (plan creation only)
   int precision;   // 0 = fp32 FMA kernels, 1 = split-f16 MFMA stages, 2 = bf16 MFMA stages
   float *d_normc;  // mode 1: norm_fsf [Nz][Ny][Nx], a constant of the plan (PSFs and weight maps
@@ -320,6 +327,32 @@ __global__ __launch_bounds__(256) void norm_classes_kernel(const float *__restri
   for (int dy = dy0; dy <= dy1; ++dy)
     for (int dx = dx0; dx <= dx1; ++dx) acc += (double)kz[dy * P + dx];
   ncls[i] = acc;
+}
+
+// FOLD tables of the matrix-core spectral stage (glr_spectral_mfma.hip): rden_fold = rden / a_k,
+// s[cls][z] = the middle of its range over k, eps = the largest half width of that range relative
+// to s over the FOLD channels [zf0, zf1) (float bits, atomicMax: every value is >= 0)
+__global__ __launch_bounds__(256) void fold_tables_kernel(const float *__restrict__ rden,
+                                                          const float *__restrict__ ainv, int K,
+                                                          int PP, int NzP, int zf0, int zf1,
+                                                          float *__restrict__ rden_fold,
+                                                          float *__restrict__ sden,
+                                                          unsigned *__restrict__ eps_bits) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)PP * NzP) return;
+  const int cls = (int)(i / NzP), z = (int)(i % NzP);
+  float lo = INFINITY, hi = 0.0f;
+  for (int k = 0; k < K; ++k) {
+    const long j = ((long)cls * K + k) * NzP + z;
+    const float v = rden[j] * ainv[k];
+    rden_fold[j] = v;
+    lo = fminf(lo, v), hi = fmaxf(hi, v);
+  }
+  sden[i] = 0.5f * (lo + hi);
+  if (z >= zf0 && z < zf1) {
+    const float eps = lo > 0.0f ? (hi - lo) / (hi + lo) : INFINITY;
+    atomicMax(eps_bits, __float_as_uint(eps));
+  }
 }
 
 // rden[cls][k][z] = 1/sqrt(sum_j p_k[j]^2 normcls[z + lw - j][cls])   (0 if den <= 0 or z >= Nz)
@@ -856,7 +889,8 @@ int origin_glr_plan_destroy(origin_glr_plan *plan) {
                   (void *)plan->d_htaps, (void *)plan->d_htap_off, (void *)plan->d_rows,
                   (void *)plan->d_border, (void *)plan->d_atab, (void *)plan->d_atab_bf16,
                   (void *)plan->d_pwide, (void *)plan->d_rdi_s, (void *)plan->d_normc,
-                  (void *)plan->d_atab2})
+                  (void *)plan->d_atab2, (void *)plan->d_atab_fold, (void *)plan->d_atab_bf16_fold,
+                  (void *)plan->d_rden_fold, (void *)plan->d_sden})
     if (p) (void)hipFree(p);
   delete plan->h_order;
   delete plan;
@@ -880,6 +914,7 @@ int origin_glr_plan_create(origin_ctx *ctx, int Nz, int Ny, int Nx, int nfields,
     ORIGIN_CHECK_ARG(h_tap_off[k + 1] > h_tap_off[k], "profile %d is empty", k);
 
   origin_glr_plan *pl = new origin_glr_plan();
+  pl->fold_eps = INFINITY;
   memset(pl, 0, sizeof(*pl));
   pl->ctx = ctx;
   pl->Nz = Nz, pl->Ny = Ny, pl->Nx = Nx, pl->nfields = nfields, pl->P = P, pl->K = K;
@@ -969,6 +1004,7 @@ int origin_glr_plan_create(origin_ctx *ctx, int Nz, int Ny, int Nx, int nfields,
     TRY(upload(ctx, rows, &pl->d_rows, &pl->bytes));
     pl->lwt = lwt;
   }
+  std::vector<double> fold_a;  // a_k (filled with the tap tables below)
   // matrix-core spectral stage: padded tap arrays G_k[e] = p_k[lw_k + 63 - e], 8 copies shifted
   // by 0..7 elements (glr_tables.h), profiles in processing order (narrow ones -- half width
   // <= 16: window blocks 1..4 -- first, so that the kernel's profile pairs are narrow/narrow,
@@ -982,6 +1018,15 @@ int origin_glr_plan_create(origin_ctx *ctx, int Nz, int Ny, int Nx, int nfields,
     std::vector<_Float16> at((size_t)K * MF_PROF_BYTES / 2, (_Float16)0.0f);
     std::vector<_Float16> at2(pl->mode == 1 ? at.size() : 0, (_Float16)0.0f);
     std::vector<unsigned short> ab((size_t)K * MF_PROF_BYTES / 2, 0);
+    // FOLD: the same tables with the taps times a_k = 1/sqrt(sum p_k^2) (mode 0 only)
+    std::vector<_Float16> atf(pl->mode == 0 ? at.size() : 0, (_Float16)0.0f);
+    std::vector<unsigned short> abf(pl->mode == 0 ? ab.size() : 0, 0);
+    fold_a.assign(K, 1.0);
+    for (int kk = 0; kk < K; ++kk) {
+      double s2 = 0.0;
+      for (int j = off[kk]; j < off[kk + 1]; ++j) s2 += (double)taps[j] * taps[j];
+      if (s2 > 0.0) fold_a[kk] = 1.0 / std::sqrt(s2);
+    }
     const float tscale = (float)(1 << MF_TAP_SCALE_LOG2);
     auto to_bf16 = [](float v) -> unsigned short {  // round to nearest even
       unsigned u;
@@ -1006,6 +1051,13 @@ int origin_glr_plan_create(origin_ctx *ctx, int Nz, int Ny, int Nx, int nfields,
             at[base] = gh;
             at[base + 8 * (MF_COPY_BYTES / 2)] = gl;
             ab[base] = to_bf16(t);
+            if (!atf.empty()) {
+              const float tf = (float)((double)t * fold_a[kk]), gf = tf * tscale;
+              const _Float16 gfh = (_Float16)gf;
+              atf[base] = gfh;
+              atf[base + 8 * (MF_COPY_BYTES / 2)] = (_Float16)(gf - (float)gfh);
+              abf[base] = to_bf16(tf);
+            }
             if (!at2.empty()) {  // squared taps (float32 squares, as d_taps2) for the denominator
               const float g2 = (t * t) * tscale;
               const _Float16 g2h = (_Float16)g2;
@@ -1017,10 +1069,16 @@ int origin_glr_plan_create(origin_ctx *ctx, int Nz, int Ny, int Nx, int nfields,
     TRY(upload(ctx, at, (_Float16 **)&pl->d_atab, &pl->bytes));
     TRY(upload(ctx, ab, (unsigned short **)&pl->d_atab_bf16, &pl->bytes));
     if (!at2.empty()) TRY(upload(ctx, at2, (_Float16 **)&pl->d_atab2, &pl->bytes));
+    if (!atf.empty()) {
+      TRY(upload(ctx, atf, (_Float16 **)&pl->d_atab_fold, &pl->bytes));
+      TRY(upload(ctx, abf, (unsigned short **)&pl->d_atab_bf16_fold, &pl->bytes));
+    }
     TRY(upload(ctx, pinfo, &pl->d_pwide, &pl->bytes));
     pl->n_narrow = 0;
     for (int slot = 0; slot < K; ++slot) pl->n_narrow += (pinfo[slot] >> 8) == 0;
     pl->h_order = new std::vector<int>(order);
+    pl->order_ident = 1;
+    for (int slot = 0; slot < K; ++slot) pl->order_ident &= order[slot] == slot;
     pl->precision = getenv("ORIGIN_GLR_FP32") ? 0 : 1;
   }
   // a mosaic of weighted fields: its spatial stage runs on the matrix cores too (per-field
@@ -1099,12 +1157,50 @@ int origin_glr_plan_create(origin_ctx *ctx, int Nz, int Ny, int Nx, int nfields,
                            pl->d_rdi + (size_t)(*pl->h_order)[slot] * pl->NzP,
                            pl->NzP * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream);
     }
+    // FOLD tables and their eps test
+    int zf0, zf1;
+    mf_fold_range(Nz, &zf0, &zf1);
+    float *d_ainv = nullptr;
+    unsigned *d_eps = nullptr;
+    unsigned eps_bits = 0x7f800000u;
+    if (e == hipSuccess && pl->d_atab_fold && zf1 > zf0 && mf_fold_fits(K)) {
+      std::vector<float> ainv(K);
+      for (int kk = 0; kk < K; ++kk) ainv[kk] = (float)(1.0 / fold_a[kk]);
+      e = hipMalloc((void **)&d_ainv, K * sizeof(float) + sizeof(unsigned));
+      if (e == hipSuccess) {
+        d_eps = (unsigned *)(d_ainv + K);
+        e = hipMemcpyAsync(d_ainv, ainv.data(), K * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+      }
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // (ainv is a local)
+      if (e == hipSuccess) e = hipMemsetAsync(d_eps, 0, sizeof(unsigned), ctx->stream);
+      if (e == hipSuccess) e = hipMalloc((void **)&pl->d_rden_fold, rn * sizeof(float));
+      if (e == hipSuccess) e = hipMalloc((void **)&pl->d_sden, PP * (size_t)pl->NzP * sizeof(float));
+      if (e == hipSuccess) {
+        hipLaunchKernelGGL(fold_tables_kernel, dim3(cdiv((long)(PP * pl->NzP), 256)), dim3(256), 0,
+                           ctx->stream, pl->d_rden, d_ainv, K, (int)PP, pl->NzP, zf0, zf1,
+                           pl->d_rden_fold, pl->d_sden, d_eps);
+        e = hipGetLastError();
+      }
+      if (e == hipSuccess)
+        e = hipMemcpyAsync(&eps_bits, d_eps, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(ncls);
+    if (d_ainv) (void)hipFree(d_ainv);
     if (e != hipSuccess) {
       origin_set_error("rden kernels: %s", hipGetErrorString(e));
       origin_glr_plan_destroy(pl);
       return ORIGIN_E_HIP;
+    }
+    memcpy(&pl->fold_eps, &eps_bits, sizeof(float));
+    if (pl->d_rden_fold && pl->fold_eps <= MF_FOLD_EPS) {
+      pl->bytes += (rn + PP * (size_t)pl->NzP) * sizeof(float);
+    } else {  // no FOLD for this plan: drop its tables
+      for (void **q : {(void **)&pl->d_atab_fold, (void **)&pl->d_atab_bf16_fold,
+                       (void **)&pl->d_rden_fold, (void **)&pl->d_sden}) {
+        if (*q) (void)hipFree(*q);
+        *q = nullptr;
+      }
     }
   }
 #undef TRY
@@ -1126,6 +1222,13 @@ int origin_glr_plan_set_precision(origin_glr_plan *plan, int precision) {
 int origin_glr_plan_get_precision(origin_glr_plan *plan, int *precision) {
   ORIGIN_CHECK_ARG(plan && precision, "null argument");
   *precision = plan->precision;
+  return ORIGIN_OK;
+}
+
+int origin_glr_plan_fold_eps(origin_glr_plan *plan, float *eps, int *active) {
+  ORIGIN_CHECK_ARG(plan && eps && active, "null argument");
+  *eps = plan->fold_eps;
+  *active = plan->d_rden_fold != nullptr && !getenv("ORIGIN_GLR_NO_FOLD");
   return ORIGIN_OK;
 }
 
@@ -1290,7 +1393,9 @@ int origin_glr_run(origin_ctx *ctx, origin_glr_plan *pl, const float *d_cube,
         ctx, pl->precision == 2 ? 1 : 3, fsf, pl->d_rden, pl->d_rdi_s, pl->NzP,
         pl->precision == 2 ? pl->d_atab_bf16 : pl->d_atab, pl->d_pwide, K, pl->n_narrow, Nz, Ny, Nx,
         P, d_mask,
-        d_correl, d_profile, d_correl_min, part, want_maps, &nzc, &pmax, &pmin);
+        d_correl, d_profile, d_correl_min, part, want_maps, &nzc, &pmax, &pmin,
+        pl->precision == 2 ? pl->d_atab_bf16_fold : pl->d_atab_fold, pl->d_rden_fold, pl->d_sden,
+        pl->order_ident);
     if (rc) return rc;
   } else if (packed) {
     // packed path: one lane = two adjacent spaxels, SPEC_ZC channels per step

@@ -38,6 +38,26 @@
 //    counted in the arg-max mismatch rate the tests bound, <= 1e-4); correl / correl_min are
 //    exact maxima / minima (v_max3 / v_min3 on the unmodified T);
 //  * the power-of-two unscaling is applied to the final max / min, not to every 1/sqrt(den);
+//  * FOLD (round 3): 1/sqrt(den_k[z]) = a_k s(z) (1 + eps_k(z)) with a_k = 1/sqrt(sum_j p_k[j]^2),
+//    s a factor of the lane's border class alone and |eps| a few 1e-7 wherever the PSF varies
+//    smoothly with the channel and the profile's support lies inside the cube (den_k is norm_fsf
+//    smoothed by p_k^2: what depends on k is the curvature of norm_fsf times the profile's
+//    variance).  The plan measures eps on its own tables (fold_tables_kernel, glr.hip: s = the
+//    middle of the range over k, eps = half its relative width; 5.4e-7 for the benchmark's Moffat
+//    PSF and dictionary); where it is <= MF_FOLD_EPS = 2e-6 the taps carry a_k and the pair loop
+//    compares the bare accumulators -- 5 instead of 7 VALU instructions per output and pair, no
+//    table of 1/sqrt(den) in LDS, no values of it in registers -- and max and min take s(z) once,
+//    behind the loop: T carries a relative error <= eps (the f16 split's own is ~3e-7 of the
+//    window's largest product; making the maximum exact with its profile's own 1/sqrt(den) was
+//    measured: a gather of eight values per half tile from global memory or from a per-tile LDS
+//    table costs 1.8 - 2.3 ms, more than the two multiplies had).  The 32 channels at each end of
+//    the cube (profile support cut: eps ~ 0.2) run the exact pair loop on the same folded taps
+//    with the table 1/(a_k sqrt(den)); plans that fail the test, or ORIGIN_GLR_NO_FOLD=1, run the
+//    exact form everywhere.  What the freed registers buy: the next tile's two new window blocks
+//    are requested a tile ahead through LDS (global_load_lds_dword: sixteen staging rows per wave
+//    where the 1/sqrt(den) tables were) and a stage's first A fragments by the stage before.
+//    11.2 -> 9.5 ms at 3681 x 600 x 600 (the exact form itself 11.2 -> 10.9 with the pointer
+//    stepping that came along).
 //  * everything lives in VGPRs: hipcc splits the register file 128 / 128 as soon as an "a"
 //    operand appears in inline asm;
 //  * the window's f16 fragments are carried from tile to tile: consecutive 32-channel tiles share
@@ -97,12 +117,23 @@ struct SmState {
 
 // Epilogue item o of a profile pair: output o of the lane is accumulator register o (profile a)
 // and o + 8 (profile b).
-template <int O>
+template <int O, bool FOLD>
 __device__ __forceinline__ void sm_epi_item(const f32x16 &acc, const f32x4v (&fa)[2],
                                             const f32x4v (&fb)[2], SmState &st, unsigned maskv,
                                             int ca, int cb) {
   constexpr int g = O >> 2, q = O & 3;
   float T0, T1, K0, K1;
+  if constexpr (FOLD) {  // the taps carry a_k: the accumulators are compared as they are
+    asm volatile(
+        "v_and_or_b32 %0, %5, %7, %8\n\t"
+        "v_and_or_b32 %1, %6, %7, %9\n\t"
+        "v_max3_f32 %2, %2, %0, %1\n\t"
+        "v_max3_f32 %3, %3, %5, %6\n\t"
+        "v_min3_f32 %4, %4, %5, %6"
+        : "=&v"(K0), "=&v"(K1), "+v"(st.key[O]), "+v"(st.best[O]), "+v"(st.worst[O])
+        : "v"(acc[O]), "v"(acc[O + 8]), "v"(maskv), "s"(ca), "s"(cb));
+    return;
+  }
   asm volatile(
       "v_mul_f32 %0, %7, %8\n\t"
       "v_mul_f32 %1, %9, %10\n\t"
@@ -131,27 +162,39 @@ constexpr int sm_epi_start(int j, int NM) {
 // branch around six bare MFMAs: one stage body for every pair, so the pair loop is ONE loop and
 // the state registers never move; the epilogue sits in the gaps of the nine mandatory MFMAs).
 // OFF: 0 for the first 16 channels of a 32-channel tile, 1 for the second (window one block on).
-template <int TERMS, int OFF>
-__device__ __forceinline__ void sm_stage(const char *ak, bool wide, const u32x4v (&bh)[6],
+// FOLD (the registers of the 1/sqrt(den) values are free): the fragments of block 1 arrive in
+// fh / fl -- requested by the stage before, behind its own last request -- and leave as the next
+// stage's (ak_next), so that no stage opens with a wait for LDS.
+template <int TERMS, int OFF, bool FOLD>
+__device__ __forceinline__ void sm_stage(const char *ak, const char *ak_next, u32x4v &fh,
+                                         u32x4v &fl, bool wide, const u32x4v (&bh)[6],
                                          const u32x4v (&bl)[6], f32x16 &acc, const f32x16 &pacc,
                                          const f32x4v (&pfa)[2], const f32x4v (&pfb)[2],
                                          SmState &st, unsigned maskv, int pca, int pcb) {
   constexpr int LO = 8 * MF_COPY_BYTES;
   constexpr int NM = TERMS * 3;
   // A fragments of window blocks 1, 2, 3 (mandatory), requested one block ahead
-  u32x4v ah = *reinterpret_cast<const u32x4v *>(ak + 32), al = ah;
-  if constexpr (TERMS == 3) al = *reinterpret_cast<const u32x4v *>(ak + 32 + LO);
+  u32x4v ah, al;
+  if constexpr (FOLD) {
+    ah = fh, al = fl;
+  } else {
+    ah = *reinterpret_cast<const u32x4v *>(ak + 32), al = ah;
+    if constexpr (TERMS == 3) al = *reinterpret_cast<const u32x4v *>(ak + 32 + LO);
+  }
   sm_for<0, 3>([&](auto ic) {
     constexpr int g = decltype(ic)::value, ks = 1 + g;
     u32x4v nh = ah, nl = al;
     if constexpr (g + 1 < 3) {
       nh = *reinterpret_cast<const u32x4v *>(ak + (ks + 1) * 32);
       if constexpr (TERMS == 3) nl = *reinterpret_cast<const u32x4v *>(ak + (ks + 1) * 32 + LO);
+    } else if constexpr (FOLD) {
+      nh = *reinterpret_cast<const u32x4v *>(ak_next + 32), nl = nh;
+      if constexpr (TERMS == 3) nl = *reinterpret_cast<const u32x4v *>(ak_next + 32 + LO);
     }
     auto gap = [&](auto jc) {
       constexpr int j = decltype(jc)::value;
       sm_for<sm_epi_start(j, NM), sm_epi_start(j + 1, NM)>([&](auto kc) {
-        sm_epi_item<decltype(kc)::value>(pacc, pfa, pfb, st, maskv, pca, pcb);
+        sm_epi_item<decltype(kc)::value, FOLD>(pacc, pfa, pfb, st, maskv, pca, pcb);
       });
     };
     sm_mma<TERMS, g == 0>(acc, ah, bh[OFF + ks]);
@@ -164,6 +207,7 @@ __device__ __forceinline__ void sm_stage(const char *ak, bool wide, const u32x4v
     }
     ah = nh, al = nl;
   });
+  if constexpr (FOLD) fh = ah, fl = al;
   if (wide) {  // window blocks 0 and 4
     const u32x4v a0h = *reinterpret_cast<const u32x4v *>(ak);
     const u32x4v a4h = *reinterpret_cast<const u32x4v *>(ak + 4 * 32);
@@ -184,13 +228,14 @@ __device__ __forceinline__ void sm_stage(const char *ak, bool wide, const u32x4v
 }
 
 // the epilogue of the last pair, nothing to overlap it with
+template <bool FOLD>
 __device__ __forceinline__ void sm_drain(const f32x16 &pacc, const f32x4v (&pfa)[2],
                                          const f32x4v (&pfb)[2], SmState &st, unsigned maskv,
                                          int pca, int pcb) {
   unsigned mv = maskv;
   asm volatile("s_nop 15\n\ts_nop 3" : "+v"(mv));  // the last MFMA's result -> VALU readers
   sm_for<0, SM_EPI_ITEMS>([&](auto kc) {
-    sm_epi_item<decltype(kc)::value>(pacc, pfa, pfb, st, mv, pca, pcb);
+    sm_epi_item<decltype(kc)::value, FOLD>(pacc, pfa, pfb, st, mv, pca, pcb);
   });
 }
 
@@ -202,13 +247,16 @@ __device__ __forceinline__ void sm_drain(const f32x16 &pacc, const f32x4v (&pfa)
 // run-time test inside the loop: with a test the two kinds of pointer merge into flat loads.
 // PODD: the number of profile pairs is odd (the two accumulators alternate per pair; the pair
 // loop is unrolled by two, and an odd count leaves one stage behind it).
-template <int TERMS, bool BW, bool PODD>
+template <int TERMS, bool BW, bool PODD, bool FOLD, bool IDENT = false>
 __device__ __forceinline__ void sm_tiles(
-    const float *__restrict__ fsf, const float *__restrict__ rdb, const float *__restrict__ rdi_s,
+    const float *__restrict__ sdl, const float *__restrict__ fsf, const float *__restrict__ rdb, const float *__restrict__ rdi_s,
     int NzP, const int *__restrict__ pinfo, int K, int NP, int Nz, long S, long s_base, int rr,
     bool sv, bool all_valid, int h, int lane, const char *a_lane, char *rd_wave, int zc0, int zc1,
     const uint8_t *__restrict__ mask, float *__restrict__ correl, uint8_t *__restrict__ profile,
-    float *__restrict__ correl_min, float &vmax, float &vmin) {
+    float *__restrict__ correl_min, float &vmax, float &vmin, int nN, char *stage = nullptr) {
+  // (IDENT: the processing order is the caller's order -- slot = index, wide from slot nN on: no
+  // look-up per pair, and with no scalar load outstanding the waits for LDS are counted ones)
+  // (stage: FOLD, the wave's 16 staging rows of 256 bytes in LDS)
   const char *rd_lane = rd_wave + 16 * h;  // channels 4h..4h+3 of each group of 8
   const bool second = (lane & 16) != 0;    // this lane's A rows belong to the pair's profile b
   // Addresses are a wave-uniform base (SGPR pair) plus ONE 32-bit lane offset: the window rows,
@@ -263,13 +311,56 @@ __device__ __forceinline__ void sm_tiles(
       ub += 8 * S;
     }
   };
+  // FOLD: the next tile's two new blocks.  A tile's global loads are awaited right where they
+  // are issued -- the pair loop leaves no registers to keep sixteen values in flight (three waves
+  // per SIMD: 168 VGPRs) -- so they go through LDS instead: global_load_lds_dword writes lane l's
+  // dword to M0 + 4 l without touching a VGPR.  Sixteen of them (one 256-byte staging row each, in
+  // the space the exact form's 1/sqrt(den) tables take) are issued when a tile starts and read
+  // when the next one does.  By then they have landed: the second half's stores waited for its
+  // s(z) loads, which were issued after the sixteen, and loads complete in order; the s_waitcnt
+  // in front of the reads says the same in the counter's terms (a half that stores without tests
+  // issues exactly 24 stores behind those loads).
+  const unsigned stage_lds = (unsigned)(uintptr_t)stage;  // LDS byte address (uniform)
+  auto stage_new_blocks = [&](int z0n) {  // channels z0n+32 .. z0n+63
+    const float *ub = fsf + (long)(z0n + 32) * S + s_base;
+    unsigned m = __builtin_amdgcn_readfirstlane(stage_lds);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        unsigned keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %1\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dword %2, %3\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "s"(m), "v"(off_in), "s"(ub)
+            : "memory");
+        ub += S;
+        m += 256;
+      }
+      ub += 8 * S;
+    }
+  };
+  auto take_staged_blocks = [&](float (&xb)[2][8]) {
+    if (all_valid) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const float *sp = reinterpret_cast<const float *>(stage) + lane;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xb[ks][j] = sp[64 * (8 * ks + j)];
+    asm volatile("" ::: "memory");
+  };
   int bmx[6] = {0, 0, 0, 0, 0, 0};  // max |x| of each window block (float bits, wave-uniform)
   int se_cur = 127;                 // exponent field of the scale the fragments are stored under
   for (int z0 = zc0; z0 < zc1; z0 += 32) {
     // ---- 1/sqrt(den)[slot][z0 .. z0+31] of the interior class -> this wave's LDS table (raw:
     // the power-of-two unscaling is applied to the final max / min).  rdi_s is in processing
     // order [slot][NzP]: element i = lane + 64 q is slot (lane>>5) + 2q, channel lane & 31
-    if constexpr (!BW) {
+    if constexpr (!BW && !FOLD) {
       float rv[MF_MAX_K / 2];
       const float *ub = rdi_s + z0;
       unsigned ord = off_rd;
@@ -337,7 +428,8 @@ __device__ __forceinline__ void sm_tiles(
       // one tile ahead, in front of the previous tile's stores, was measured: 13.9 ms against
       // 11.4 -- sixteen registers carried around the tile loop cost more than the wait.)
       float xb[2][8];
-      load_new_blocks(z0, xb);
+      if constexpr (FOLD) take_staged_blocks(xb);
+      else load_new_blocks(z0, xb);
       int se = 127;
       if constexpr (TERMS == 3) {
         float m4 = 0.0f, m5 = 0.0f;
@@ -400,6 +492,11 @@ __device__ __forceinline__ void sm_tiles(
       inv = __uint_as_float((unsigned)(254 - se_cur - MF_TAP_SCALE_LOG2) << 23);
     }
 
+    // FOLD: request the next tile's two new blocks now; they land in the wave's staging rows
+    // while this tile's pairs run and are picked up behind the second half's pairs
+    if constexpr (FOLD) {
+      if (z0 + 32 < zc1) stage_new_blocks(z0 + 32);  // (uniform)
+    }
     // ---- the two 16-channel halves
     sm_for<0, 2>([&](auto hc) {
       constexpr int HALF = decltype(hc)::value;
@@ -431,6 +528,13 @@ __device__ __forceinline__ void sm_tiles(
           }
         }
       }
+      // FOLD: s(z) of the lane's border class for its eight channels (two 16-byte loads, requested
+      // in front of the pairs like the mask bytes; zero beyond Nz like the 1/sqrt(den) table)
+      f32x4v sg[2] = {(f32x4v){0.f, 0.f, 0.f, 0.f}, (f32x4v){0.f, 0.f, 0.f, 0.f}};
+      if constexpr (FOLD) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) sg[g] = *reinterpret_cast<const f32x4v *>(sdl + zh + 8 * g);
+      }
       SmState st;
 #pragma unroll
       for (int i = 0; i < 8; ++i)
@@ -445,18 +549,43 @@ __device__ __forceinline__ void sm_tiles(
       int ca = 0, cb = 0;
 #pragma unroll
       for (int g = 0; g < 2; ++g) fa[g] = fb[g] = (f32x4v){NAN, NAN, NAN, NAN};
-      asm volatile("s_nop 1" : "=v"(accY));  // (accY: any bits; B fragment writes -> first MFMA)
+      if constexpr (FOLD) {  // the neutral "previous pair": NaN accumulators (ignored by max3 / min3)
+        // (the NaN comes out of an asm statement: as a constant the sixteen copies are hoisted out
+        // of the tile loop and spilled)
+        float nanv;
+        asm volatile("v_mov_b32 %0, 0x7fc00000" : "=v"(nanv));
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accY[i] = nanv;
+        asm volatile("s_nop 1" : "+v"(accY));
+      } else {
+        asm volatile("s_nop 1" : "=v"(accY));  // (accY: any bits; B fragment writes -> first MFMA)
+      }
+      // the lane's own profile of the pair: slot 2p (rows 0-15) or 2p+1 (rows 16-31; an odd K's
+      // last profile sits in LDS twice): one pointer, a constant step per pair
+      const char *akp = a_lane + (second ? MF_PROF_BYTES : 0);
+      u32x4v fh, fl;
+      if constexpr (FOLD) {
+        fh = *reinterpret_cast<const u32x4v *>(akp + 32), fl = fh;
+        if constexpr (TERMS == 3) fl = *reinterpret_cast<const u32x4v *>(akp + 32 + 8 * MF_COPY_BYTES);
+      }
       auto run = [&](int p, f32x16 &wacc, const f32x16 &racc) {
         const int sa = 2 * p, sb = min(2 * p + 1, K - 1);  // (odd K: the last profile twice)
-        const int ia = pinfo[sa], ib = pinfo[sb];
-        // the lane's own profile of the pair: slot sa (rows 0-15) or sb (rows 16-31)
-        const char *ak = a_lane + (second ? sb : sa) * MF_PROF_BYTES;
-        sm_stage<TERMS, HALF>(ak, ((ia | ib) >> 8) != 0, bh, bl, wacc, racc, fa, fb, st, maskv,
-                              ca, cb);
+        int ia, ib;
+        if constexpr (IDENT) {
+          ia = sa, ib = sb | (sb >= nN ? 0x100 : 0);
+        } else {
+          ia = pinfo[sa], ib = pinfo[sb];
+        }
+        const char *ak = akp;
+        akp += 2 * MF_PROF_BYTES;
+        sm_stage<TERMS, HALF, FOLD>(ak, akp, fh, fl, ((ia | ib) >> 8) != 0, bh, bl, wacc, racc, fa,
+                                    fb, st, maskv, ca, cb);
         // 1/sqrt(den) of this pair for the lane's 8 channels: requested now (the epilogue that
         // read the previous values is done), used from the third MFMA gap of the next stage
         const int ka = ia & 0xff, kb = ib & 0xff;
-        if constexpr (BW) {
+        if constexpr (FOLD) {
+          // (no per-pair normalisation)
+        } else if constexpr (BW) {
 #pragma unroll
           for (int g = 0; g < 2; ++g) {
             fa[g] = *reinterpret_cast<const f32x4v *>(rdb + (long)ka * NzP + zh + 8 * g);
@@ -478,9 +607,9 @@ __device__ __forceinline__ void sm_tiles(
       }
       if constexpr (PODD) {
         run(p, accX, accY);
-        sm_drain(accX, fa, fb, st, maskv, ca, cb);
+        sm_drain<FOLD>(accX, fa, fb, st, maskv, ca, cb);
       } else {
-        sm_drain(accY, fa, fb, st, maskv, ca, cb);
+        sm_drain<FOLD>(accY, fa, fb, st, maskv, ca, cb);
       }
 
       // store (mask glue: steps.py:781,788)
@@ -498,8 +627,13 @@ __device__ __forceinline__ void sm_tiles(
           const int zu = zh + (i & 3) + 8 * (i >> 2);  // uniform part of the channel
           if (STRAIGHT || zu + 4 * h < zc1) {
             float b = st.best[i] * inv;
-            const float w = st.worst[i] * inv;
+            float w = st.worst[i] * inv;
             int kk = 31 - (int)(__float_as_uint(st.key[i]) & 31u);
+            if constexpr (FOLD) {
+              // the class factor s(z) of the lane's channel
+              b *= sg[i >> 2][i & 3];
+              w *= sg[i >> 2][i & 3];
+            }
             // profiles run narrow-first, not in index order: when every T is the same number (a
             // spaxel of zeros) the first maximum is index 0 (np.argmax semantics, lib :1210)
             if (st.best[i] == st.worst[i]) kk = 0;
@@ -522,18 +656,24 @@ __device__ __forceinline__ void sm_tiles(
   }
 }
 
+// VARIANT bit 0: odd number of profile pairs; bit 2 (with FOLD): IDENT; bit 1: FOLD -- atab holds the taps times a_k, rden
+// the table 1/(a_k sqrt(den)), sden the class factors s; tiles in [zf0, zf1) (multiples of 32)
+// run the FOLD pair loop, the tiles at the cube's ends the exact one (with each lane reading its
+// own class from global memory, interior or not: the block's LDS holds no 1/sqrt(den) table).
 template <int TERMS, int VARIANT>
 __global__ __launch_bounds__(64 * MF_WAVES, 1) void spectral_mfma2_kernel(
     const float *__restrict__ fsf, const float *__restrict__ rden,
     const float *__restrict__ rdi_s, int NzP, const uint4 *__restrict__ atab,
     const int *__restrict__ pinfo, int K, int NP, int Nz, int Ny, int Nx, int P, int zchunk, const uint8_t *__restrict__ mask, float *__restrict__ correl,
     uint8_t *__restrict__ profile, float *__restrict__ correl_min, float *__restrict__ part_max,
-    float *__restrict__ part_min) {
+    float *__restrict__ part_min, const float *__restrict__ sden, int zf0, int zf1, int nN) {
   extern __shared__ __align__(16) char sm_lds[];
+  const int Kp = K + (K & 1);  // slots in LDS: an odd K's last profile twice (its pair partner)
   {
-    const int nvec = K * (MF_PROF_BYTES / 16);
+    constexpr int PV = MF_PROF_BYTES / 16;
+    const int nvec = Kp * PV;
     for (int i = threadIdx.x; i < nvec; i += 64 * MF_WAVES)
-      reinterpret_cast<uint4 *>(sm_lds)[i] = atab[i];
+      reinterpret_cast<uint4 *>(sm_lds)[i] = atab[i < K * PV ? i : i - PV];
   }
   __syncthreads();
   const long S = (long)Ny * Nx;
@@ -549,7 +689,7 @@ __global__ __launch_bounds__(64 * MF_WAVES, 1) void spectral_mfma2_kernel(
   const char *a_lane = sm_lds + (E0 & 7) * MF_COPY_BYTES + (E0 >> 3) * 16;
   // this wave's [K][32] table of 1/sqrt(den) for the current tile (behind the tap copies), in
   // the order the profiles are processed
-  char *rd_wave = sm_lds + K * MF_PROF_BYTES + wv * K * MF_RD_BYTES;
+  char *rd_wave = sm_lds + Kp * MF_PROF_BYTES + wv * K * MF_RD_BYTES;
   const bool sv = s_base + r < S;
   const bool all_valid = s_base + 32 <= S;
   const long sc = sv ? s_base + r : S - 1;
@@ -564,14 +704,33 @@ __global__ __launch_bounds__(64 * MF_WAVES, 1) void spectral_mfma2_kernel(
   }
   const float *rdb = rden + (long)cls * K * NzP + 4 * h;
   constexpr bool PODD = (VARIANT & 1) != 0;  // odd number of profile pairs
-  if (__any(cls != ccls))
-    sm_tiles<TERMS, true, PODD>(fsf, rdb, rdi_s, NzP, pinfo, K, NP, Nz, S, s_base, rr, sv,
-                                all_valid, h, lane, a_lane, rd_wave, zc0, zc1, mask, correl,
-                                profile, correl_min, vmax, vmin);
-  else
-    sm_tiles<TERMS, false, PODD>(fsf, rdb, rdi_s, NzP, pinfo, K, NP, Nz, S, s_base, rr, sv,
-                                 all_valid, h, lane, a_lane, rd_wave, zc0, zc1, mask, correl,
-                                 profile, correl_min, vmax, vmin);
+  constexpr bool FOLD = (VARIANT & 2) != 0;
+  constexpr bool IDENT = (VARIANT & 4) != 0;
+  if constexpr (FOLD) {
+    const float *sdl = sden + (long)cls * NzP + 4 * h;
+    const int f0 = max(zc0, zf0), f1 = min(zc1, zf1);
+    if (f0 < f1)
+      sm_tiles<TERMS, false, PODD, true, IDENT>(sdl, fsf, rdb, rden + (long)ccls * K * NzP, NzP, pinfo, K,
+                                         NP, Nz, S, s_base, rr, sv, all_valid, h, lane, a_lane,
+                                         rd_wave, f0, f1, mask, correl, profile, correl_min, vmax,
+                                         vmin, nN,
+                                         sm_lds + Kp * MF_PROF_BYTES + wv * MF_STAGE_BYTES);
+    for (int e = 0; e < 2; ++e) {  // the chunk's tiles in front of / behind the FOLD range
+      const int a = e ? max(zc0, zf1) : zc0, b = e ? zc1 : min(zc1, zf0);
+      if (a < b)
+        sm_tiles<TERMS, true, PODD, false>(nullptr, fsf, rdb, rdi_s, NzP, pinfo, K, NP, Nz, S,
+                                           s_base, rr, sv, all_valid, h, lane, a_lane, rd_wave, a, b,
+                                           mask, correl, profile, correl_min, vmax, vmin, nN);
+    }
+  } else if (__any(cls != ccls)) {
+    sm_tiles<TERMS, true, PODD, false>(nullptr, fsf, rdb, rdi_s, NzP, pinfo, K, NP, Nz, S, s_base,
+                                       rr, sv, all_valid, h, lane, a_lane, rd_wave, zc0, zc1, mask,
+                                       correl, profile, correl_min, vmax, vmin, nN);
+  } else {
+    sm_tiles<TERMS, false, PODD, false>(nullptr, fsf, rdb, rdi_s, NzP, pinfo, K, NP, Nz, S, s_base,
+                                        rr, sv, all_valid, h, lane, a_lane, rd_wave, zc0, zc1, mask,
+                                        correl, profile, correl_min, vmax, vmin, nN);
+  }
   if (part_max) {
     const float a = fmaxf(vmax, __shfl_xor(vmax, 32));
     const float b = fminf(vmin, __shfl_xor(vmin, 32));
@@ -636,38 +795,54 @@ int origin_spectral_mfma_launch(origin_ctx *ctx, int terms, const float *fsf, co
                                 const float *rdi_s, int NzP, const uint4 *atab, const int *pinfo,
                                 int K, int nN, int Nz, int Ny, int Nx, int P, const uint8_t *mask,
                                 float *correl, uint8_t *profile, float *correl_min, float *part,
-                                bool want_maps, int *nzc_out, float **pmax_out, float **pmin_out) {
+                                bool want_maps, int *nzc_out, float **pmax_out, float **pmin_out,
+                                const uint4 *atab_fold, const float *rden_fold, const float *sden,
+                                int ident) {
   const long S = (long)Ny * Nx;
   long bx;
   int nzm, zcm;
   sm_geometry(ctx->num_cu, Nz, S, &bx, &nzm, &zcm);
   float *pmax = want_maps ? part : nullptr;
   float *pmin = want_maps ? part + (size_t)nzm * S : nullptr;
-  const size_t lds = (size_t)K * (MF_PROF_BYTES + MF_WAVES * MF_RD_BYTES);
+  const int Kp = K + (K & 1);
+  // (+ one profile of slack: the last stage requests the fragments of a pair that is not there)
+  const size_t lds = std::max((size_t)Kp * MF_PROF_BYTES + (size_t)K * MF_WAVES * MF_RD_BYTES,
+                              (size_t)(Kp + 1) * MF_PROF_BYTES);
   // pairs of slots (2p, 2p+1); an odd last profile pairs with itself
   const int NP = (K + 1) / 2;
-  const int variant = NP & 1;
-  (void)nN;
-  const void *fn = nullptr;
+  auto pick = [&](int fold) -> const void * {
+    const int variant = (NP & 1) | (fold << 1) | ((fold && ident) << 2);
 #define SM_PICK(T, V) \
-  if (terms == T && variant == V) fn = (const void *)spectral_mfma2_kernel<T, V>
-  SM_PICK(3, 0); SM_PICK(3, 1); SM_PICK(1, 0); SM_PICK(1, 1);
+  if (terms == T && variant == V) return (const void *)spectral_mfma2_kernel<T, V>
+    SM_PICK(3, 0); SM_PICK(3, 1); SM_PICK(3, 2); SM_PICK(3, 3); SM_PICK(3, 6); SM_PICK(3, 7);
+    SM_PICK(1, 0); SM_PICK(1, 1); SM_PICK(1, 2); SM_PICK(1, 3); SM_PICK(1, 6); SM_PICK(1, 7);
 #undef SM_PICK
+    return nullptr;
+  };
+  // FOLD for the tiles whose profile supports lie inside the cube (plans whose eps test passed
+  // bring the folded tables), the exact form for the tiles at the ends
+  int zf0 = 0, zf1 = 0;
+  if (atab_fold && rden_fold && sden && !getenv("ORIGIN_GLR_NO_FOLD")) {
+    mf_fold_range(Nz, &zf0, &zf1);
+  }
+  // (LDS: the tap copies and the staging rows -- K <= 24 with twelve waves)
+  const size_t lds_fold = (size_t)Kp * MF_PROF_BYTES + (size_t)MF_WAVES * MF_STAGE_BYTES;
+  if (!mf_fold_fits(K)) zf0 = zf1 = 0;
+  const int fold = zf1 > zf0;
+  const void *fn = pick(fold);
   if (!fn) {
-    origin_set_error("spectral MFMA kernel: no variant %d for %d terms", variant, terms);
+    origin_set_error("spectral MFMA kernel: no variant for %d terms", terms);
     return ORIGIN_E_STATE;
   }
   ORIGIN_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  MF_MAX_K * (MF_PROF_BYTES + MF_WAVES * MF_RD_BYTES)));
-  const float *a_fsf = fsf, *a_rden = rden, *a_rdi = rdi_s;
-  const uint4 *a_atab = atab;
-  const int *a_pinfo = pinfo;
-  const uint8_t *a_mask = mask;
-  int a_NzP = NzP, a_K = K, a_NP = NP, a_Nz = Nz, a_Ny = Ny, a_Nx = Nx, a_P = P, a_zcm = zcm;
-  void *args[] = {&a_fsf, &a_rden, &a_rdi, &a_NzP, &a_atab, &a_pinfo, &a_K, &a_NP, &a_Nz, &a_Ny,
-                  &a_Nx, &a_P, &a_zcm, &a_mask, &correl, &profile, &correl_min, &pmax, &pmin};
-  ORIGIN_HIP(hipLaunchKernel(fn, dim3((unsigned)bx, nzm), dim3(64 * MF_WAVES), args, lds,
-                             ctx->stream));
+  const uint4 *a_atab = fold ? atab_fold : atab;
+  const float *a_rden = fold ? rden_fold : rden;
+  int a_NP = NP, a_zcm = zcm;
+  void *args[] = {&fsf, &a_rden, &rdi_s, &NzP, &a_atab, &pinfo, &K, &a_NP, &Nz, &Ny, &Nx, &P, &a_zcm,
+                  &mask, &correl, &profile, &correl_min, &pmax, &pmin, &sden, &zf0, &zf1, &nN};
+  ORIGIN_HIP(hipLaunchKernel(fn, dim3((unsigned)bx, (unsigned)nzm), dim3(64 * MF_WAVES), args,
+                             fold ? std::max(lds, lds_fold) : lds, ctx->stream));
   ORIGIN_LAUNCH_CHECK();
   *nzc_out = nzm;
   *pmax_out = pmax;

@@ -21,11 +21,32 @@ constexpr int MF_MAX_K = 26;                          // 26 * (4608 + 12 * 128) 
 // its 96-channel windows [z0 - 32, z0 + 63] without bounds tests
 constexpr int MF_PAD_FRONT = 32, MF_PAD_BACK = 64;
 
+// FOLD (glr_spectral_mfma.hip): the channels [zf0, zf1) whose tiles compare bare accumulators --
+// every profile of the matrix-core path (half width <= 32) has its support inside the cube there
+constexpr int MF_FOLD_MARGIN = 32;
+inline void mf_fold_range(int Nz, int *zf0, int *zf1) {
+  *zf0 = MF_FOLD_MARGIN;
+  *zf1 = (Nz - MF_FOLD_MARGIN) / 32 * 32;
+  if (*zf1 <= *zf0) *zf0 = *zf1 = 0;
+}
+// a wave's staging rows for the next tile's new window blocks (16 rows x 64 lanes x 4 bytes), in
+// the LDS behind the tap copies (an odd K's last profile is held twice): K <= 24 with twelve waves
+constexpr int MF_STAGE_BYTES = 16 * 256;
+inline bool mf_fold_fits(int K) {
+  return (size_t)(K + (K & 1)) * MF_PROF_BYTES + (size_t)MF_WAVES * MF_STAGE_BYTES <=
+         (size_t)MF_MAX_K * (MF_PROF_BYTES + MF_WAVES * MF_RD_BYTES);
+}
+// largest |1/(a_k sqrt(den_k)) / s - 1| a plan may show over [zf0, zf1) and still run FOLD
+constexpr float MF_FOLD_EPS = 2e-6f;
+
+// atab_fold / rden_fold / sden: the folded tables (nullptr: the exact form everywhere)
 int origin_spectral_mfma_launch(origin_ctx *ctx, int terms, const float *fsf, const float *rden,
                                 const float *rdi_s, int NzP, const uint4 *atab, const int *pinfo, int K,
                                 int nN, int Nz, int Ny, int Nx, int P, const uint8_t *mask, float *correl,
                                 uint8_t *profile, float *correl_min, float *part, bool want_maps,
-                                int *nzc_out, float **pmax_out, float **pmin_out);
+                                int *nzc_out, float **pmax_out, float **pmin_out,
+                                const uint4 *atab_fold, const float *rden_fold, const float *sden,
+                                int ident);
 
 long origin_spectral_mfma_count(int num_cu, int terms, int K, int n_narrow, int Nz, int Ny,
                                 int Nx);

@@ -187,6 +187,14 @@ class GLRPlan:
         _capi.call("origin_glr_plan_mfma_count", self._h, C.byref(a), C.byref(b))
         return a.value, b.value
 
+    def fold_eps(self):
+        """(eps, active): FOLD of the matrix-core spectral stage -- the plan's measured
+        max |1/(a_k sqrt(den_k)) / s - 1| away from the cube's ends and whether the stage uses it
+        (eps <= 2e-6, include/origin_hip.h origin_glr_plan_fold_eps)."""
+        e, a = C.c_float(), C.c_int()
+        _capi.call("origin_glr_plan_fold_eps", self._h, C.byref(e), C.byref(a))
+        return e.value, bool(a.value)
+
     def close(self):
         if self._h is not None and self._h.value:
             _capi.load().origin_glr_plan_destroy(self._h)

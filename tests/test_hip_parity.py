@@ -481,6 +481,86 @@ def test_glr_matrix_core_profile_list_shapes(ctx, nprof, expect):
     plan.close()
 
 
+@pytest.mark.parametrize("case", ["dictionary", "odd count", "wide first", "bf16", "P25 borders"])
+def test_glr_fold_form_against_the_exact_form_and_the_oracle(ctx, case, monkeypatch):
+    """FOLD of the matrix-core spectral stage (glr_spectral_mfma.hip): away from the cube's first
+    and last 32 channels the pair loop compares accumulators that carry a_k = 1/sqrt(sum p_k^2)
+    and the class factor s(z) is applied once, behind the loop -- T carries a relative error
+    <= the plan's measured eps (<= 2e-6, here a few 1e-7).  The PSF is the first channels of the
+    benchmark's 3681-channel FWHM ramp (the smoothness the plan's eps test asks for).  Checked:
+    the plan reports FOLD active with eps under the limit; FOLD against the exact form of the
+    same plan (ORIGIN_GLR_NO_FOLD=1) within eps of the window's largest |T| (+ the f16 split's
+    rounding); both against the float64 oracle at the usual bounds; the arg-max rate.  Cases:
+    the 20-profile dictionary (identity processing order), an odd number of profiles (the last
+    one sits in LDS twice), wide profiles first (processing order != caller's order: look-up per
+    pair), the bf16 arithmetic, and a 25 x 25 PSF on a field where most spaxels are border
+    classes (each lane its own s)."""
+    from scipy.ndimage import maximum_filter1d
+    from origin_amd import kernels
+    rng = np.random.default_rng(31)
+    P = 25 if case == "P25 borders" else 9
+    Nz, Ny, Nx = (330, 30, 44) if P == 25 else (330, 40, 70)
+    cube = rng.standard_normal((Nz, Ny, Nx)).astype(np.float32)
+    cube[100:140] *= 37.0                    # a scale step inside the FOLD range
+    psf = synth.moffat_psf(3681, P)[:Nz].astype(np.float64)
+    prof = synth.dico_fwhm(20)
+    if case == "odd count":
+        prof = synth.dico_fwhm(7)
+    elif case == "wide first":
+        prof = list(prof[::-1])
+    precision = "bf16" if case == "bf16" else "f16x2"
+    ref = cpu_ref.Correlation_GLR_test(cube.astype(np.float64), psf, None, prof, nthreads=1,
+                                       pcut=1e-8, pmeansub=True)
+    plan = kernels.GLRPlan(ctx, cube.shape, psf, None, prof, 1e-8, True, precision=precision)
+    assert plan.precision == precision
+    monkeypatch.delenv("ORIGIN_GLR_NO_FOLD", raising=False)
+    eps, active = plan.fold_eps()
+    assert active and 0.0 < eps <= 2e-6
+    d_cube = ctx.to_device(cube)
+    out = plan.run(d_cube, mask=None, want_maps=True)
+    fold = {k: out[k].to_host() for k in ("correl", "correl_min", "profile", "maxmap")}
+    monkeypatch.setenv("ORIGIN_GLR_NO_FOLD", "1")
+    assert plan.fold_eps()[1] is False
+    out = plan.run(d_cube, mask=None, want_maps=True)
+    exact = {k: out[k].to_host() for k in ("correl", "correl_min", "profile", "maxmap")}
+    monkeypatch.delenv("ORIGIN_GLR_NO_FOLD")
+    plan.close()
+    # the ends of the cube run the exact pair loop in both forms (on folded / plain taps)
+    local = maximum_filter1d(np.abs(ref[0]).max(axis=(1, 2)), size=193, mode="nearest")
+    # the arithmetic's own bound per unit of the window's largest |T| (bf16: the 5e-2 of
+    # test_glr_bf16_precision_meets_the_bf16_tolerance at unit noise, where that maximum is ~4)
+    rnd = 1.2e-2 if precision == "bf16" else 3e-6
+    tol = ((eps + rnd) * local)[:, None, None]
+    for k, r in (("correl", ref[0]), ("correl_min", ref[2])):
+        assert np.all(np.abs(fold[k] - exact[k]) <= 2 * tol), k
+        assert np.all(np.abs(fold[k] - r) <= tol), k
+        assert np.all(np.abs(exact[k] - r) <= tol), k
+    assert np.max(np.abs(fold["maxmap"] - fold["correl"].max(axis=0))) == 0.0
+    if precision == "f16x2":
+        assert np.mean(fold["profile"] != ref[1]) <= 1e-4
+        assert np.mean(fold["profile"] != exact["profile"]) <= 1e-4
+
+
+def test_glr_fold_is_refused_for_a_steep_psf_ramp(ctx):
+    """A PSF whose width changes quickly with the channel fails the plan's eps test: the plan
+    reports FOLD inactive and the stage runs the exact form (same bounds as ever)."""
+    from origin_amd import kernels
+    rng = np.random.default_rng(32)
+    Nz, Ny, Nx = 200, 26, 36
+    cube = rng.standard_normal((Nz, Ny, Nx)).astype(np.float32)
+    psf = synth.moffat_psf(Nz, 9, fwhm0=6.0, fwhm1=2.0).astype(np.float64)
+    prof = synth.dico_fwhm(20)
+    plan = kernels.GLRPlan(ctx, cube.shape, psf, None, prof, 1e-8, True, precision="f16x2")
+    eps, active = plan.fold_eps()
+    assert eps > 2e-6 and not active
+    ref = cpu_ref.Correlation_GLR_test(cube.astype(np.float64), psf, None, prof, nthreads=1,
+                                       pcut=1e-8, pmeansub=True)
+    out = plan.run(ctx.to_device(cube), mask=None, want_maps=False)
+    assert np.max(np.abs(out["correl"].to_host() - ref[0])) <= 1e-4
+    assert np.max(np.abs(out["correl_min"].to_host() - ref[2])) <= 1e-4
+    plan.close()
+
+
 def test_glr_f16_split_survives_huge_dynamic_range(ctx):
     """Per-tile power-of-two scaling: slabs of channels at 1e-6, 1 and 1e+7 times unit noise must
     neither overflow the f16 halves nor lose the faint slabs.  Error bound relative to the

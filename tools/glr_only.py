@@ -39,6 +39,7 @@ def main():
     ctx.sync()
     dt = (time.perf_counter() - t) / reps
     ctx.prof_enable(False)
+    print("fold (eps, active):", plan.fold_eps())
     print(plan.precision, f"{1e3 * dt:.2f} ms per GLR",
           {k: round(v[0] / reps, 3) for k, v in ctx.prof_report().items()})
 
