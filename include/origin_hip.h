@@ -234,6 +234,15 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
                    const long *h_spx_off, const double *d_test0, const double *h_thr,
                    double noise_pop, int itermax, int *d_mapO2, int *h_nstop, int *h_iters,
                    long *h_trace, int trace_cap);
+/* Tail hook of the greedy PCA: `hook(user, n_active, areas)` is called ONCE per run, from inside
+ * origin_pca_run / origin_pca_run_into on the calling thread, at the first iteration (after the
+ * first) at which at most max_active areas still iterate.  Before the call the areas that have
+ * finished -- they never iterate again -- are written to d_F (the pass they would have had at the
+ * end, on the context's stream); `areas` lists the indices of those that go on.  The caller may
+ * enqueue the next stage for everything that does not depend on them (origin_glr_run_rows with
+ * ORIGIN_GLR_SIDE).  hook = NULL removes it.  Results of the PCA are unchanged. */
+int origin_pca_set_tail_hook(origin_ctx *ctx, void (*hook)(void *user, int n_active, const int *areas),
+                             void *user, int max_active);
 /* The same with cube_faint written into a box of a larger cube: d_F is the box's first element,
  * spaxel y * out_nx + x of the (Nz, S) input goes to d_F[z * out_pz + y * out_py + x].  The tiled
  * path (origin_amd/multigpu.py) points it at the interior of the halo-extended tile the GLR
@@ -345,6 +354,26 @@ int origin_glr_plan_fold_eps(origin_glr_plan *plan, float *eps, int *active);
  * check bench.py's `executed` against the counter passes committed under profiles/. */
 int origin_glr_mfma_count_model(int num_cu, int terms, int K, int n_narrow, int Nz, int Ny, int Nx,
                                 int P, long *spatial, long *spectral);
+
+/* A GLR run in ROW BANDS: the same results as origin_glr_run, written band by band -- so that the
+ * bands whose input is final can start while the greedy PCA still iterates over its last areas
+ * (origin_pca_set_tail_hook).  A band is the rows [y0, y1) of the field, y0 a multiple of 64, y1 a
+ * multiple of 64 or Ny; its spatial stage reads cube rows [y0 - P/2, y1 + P/2).  flags:
+ * ORIGIN_GLR_FIRST on the first band of a run (zeroes the pad channels of the work cube, on the main
+ * stream), ORIGIN_GLR_SIDE to enqueue the band on the context's side stream (all compute units but
+ * ORIGIN_GLR_SIDE_RESERVE, default an eighth of them; it starts behind everything the main stream was given before
+ * the call).  origin_glr_run_finish makes the main stream wait for the side bands and writes the
+ * maps (NULL: none).  Only plans whose two stages run the table kernels on the matrix cores
+ * (one field, no weight maps, precision 1 or 2, PSF 5..25, profile half widths <= 32, K <= 26):
+ * origin_glr_rows_supported; others return ORIGIN_E_STATE. */
+#define ORIGIN_GLR_FIRST 1
+#define ORIGIN_GLR_SIDE 2
+int origin_glr_rows_supported(origin_glr_plan *plan, int *ok);
+int origin_glr_run_rows(origin_ctx *ctx, origin_glr_plan *plan, const float *d_cube,
+                        const uint8_t *d_mask, float *d_work, float *d_correl, uint8_t *d_profile,
+                        float *d_correl_min, int y0, int y1, int flags);
+int origin_glr_run_finish(origin_ctx *ctx, origin_glr_plan *plan, float *d_work, float *d_maxmap,
+                          float *d_minmap);
 
 /* correl = max_k T_k, profile = first argmax_k, correl_min = min_k T_k (lib :1205-1212).
  * If d_mask != NULL the ComputeTGLR glue is fused: correl[mask] = 0, profile[mask] = 0

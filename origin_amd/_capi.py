@@ -87,6 +87,10 @@ SIGNATURES = {
     "origin_glr_mfma_count_model": [i32, i32, i32, i32, i32, i32, i32, i32, PP(i64), PP(i64)],
     "origin_glr_work_elems": [vp, PP(sz)],
     "origin_glr_run": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "origin_glr_rows_supported": [vp, PP(i32)],
+    "origin_glr_run_rows": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32],
+    "origin_glr_run_finish": [vp, vp, vp, vp, vp],
+    "origin_pca_set_tail_hook": [vp, vp, vp, i32],
     "origin_local_max": [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp],
 }
 _RESTYPE = {"origin_last_error": C.c_char_p}

@@ -77,7 +77,24 @@ struct origin_ctx {
   float *cvt_stage[2];
   hipEvent_t cvt_ev[2];
   bool cvt_ready;
+  // Side stream of the row-band GLR (origin_glr_run_rows with ORIGIN_GLR_SIDE): restricted to the
+  // first num_cu - reserve compute units, so that a band started while the greedy PCA still
+  // iterates over its last areas leaves CUs to the PCA's small kernels.  side_join is recorded
+  // behind the band; origin_glr_run_finish / origin_sync wait for it.
+  hipStream_t side_stream;
+  hipEvent_t side_fork, side_join;
+  bool side_pending;
+  // greedy PCA: called once, when at most pca_tail_max areas still iterate, after the areas that
+  // have finished were written to the output (origin_pca_set_tail_hook, pca.hip)
+  void (*pca_tail_hook)(void *user, int n_active, const int *areas);
+  void *pca_tail_user;
+  int pca_tail_max;
 };
+
+// side stream plumbing (ctx.hip)
+int origin_side_begin(origin_ctx *ctx);  // side waits for the main stream's work so far
+int origin_side_end(origin_ctx *ctx);    // marks the end of the side work enqueued
+int origin_side_join(origin_ctx *ctx);   // main waits for the side work
 
 // aux stream plumbing (ctx.hip)
 int origin_aux_begin(origin_ctx *ctx);                        // aux waits for the main stream's work so far
@@ -116,9 +133,10 @@ int origin_scratch(origin_ctx *ctx, size_t bytes, void **out);
 // glr_spatial_mfma.hip: matrix-core spatial GLR stage (one field, or one weighted field of a
 // mosaic: W its weight map, accf = add to what the fields before left in out)
 int origin_spatial_mfma_ok(int Ny, int Nx, int P);
+// (ry0, nry: rows of 64 x 64 regions to run, nry <= 0 = the whole field)
 int origin_spatial_mfma_launch(origin_ctx *ctx, int terms, const float *A, const float *W,
                                const float *taps, int Nz, int Ny, int Nx, int P, int accf,
-                               float *out);
+                               float *out, int ry0 = 0, int nry = 0);
 long origin_spatial_mfma_count(int terms, int Nz, int Ny, int Nx, int P);
 
 #define ORIGIN_CHECK_ARG(cond, ...)       \

@@ -53,6 +53,45 @@ int origin_scratch(origin_ctx *ctx, size_t bytes, void **out) {
   return ORIGIN_OK;
 }
 
+// The side stream, made on first use: every CU but the last `reserve` (ORIGIN_GLR_SIDE_RESERVE,
+// default an eighth of the chip: 32 of 256).  Measured at 3681 x 600 x 600 with the GLR's early
+// bands beside the greedy PCA's tail (tools/tail_overlap_tune.sh, profiles/r03_tail_overlap_tune.txt):
+// step 55.8 ms with no reserve (the PCA's small kernels wait for a GLR workgroup to leave a CU: no
+// better than running the two in sequence, 55.9), 53.8 / 53.3 / 53.1 with 8 / 16 / 24 CUs,
+// 51.9 with 32, 52.4 / 52.7 / 53.0 with 40 / 64 / 96.  Work enqueued on the stream afterwards starts
+// behind everything the main stream has been given so far.
+int origin_side_begin(origin_ctx *ctx) {
+  if (!ctx->side_stream) {
+    const char *e = getenv("ORIGIN_GLR_SIDE_RESERVE");
+    const int ncu = ctx->num_cu > 0 ? std::min(ctx->num_cu, 256) : 256;
+    int reserve = e ? atoi(e) : ncu / 8;
+    reserve = std::max(0, std::min(reserve, ncu - 8));
+    uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < ncu - reserve; ++i) mask[i >> 5] |= 1u << (i & 31);
+    ORIGIN_HIP(hipExtStreamCreateWithCUMask(&ctx->side_stream, 8, mask));
+    ORIGIN_HIP(hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
+    ORIGIN_HIP(hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming));
+  }
+  ORIGIN_HIP(hipEventRecord(ctx->side_fork, ctx->stream));
+  ORIGIN_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0));
+  return ORIGIN_OK;
+}
+
+int origin_side_end(origin_ctx *ctx) {
+  ORIGIN_HIP(hipEventRecord(ctx->side_join, ctx->side_stream));
+  ctx->side_pending = true;
+  return ORIGIN_OK;
+}
+
+// the main stream waits for what the side stream was given
+int origin_side_join(origin_ctx *ctx) {
+  if (ctx->side_stream && ctx->side_pending) {
+    ORIGIN_HIP(hipStreamWaitEvent(ctx->stream, ctx->side_join, 0));
+    ctx->side_pending = false;
+  }
+  return ORIGIN_OK;
+}
+
 // The aux stream is created on first use, with the lowest priority the device offers: its
 // thousands of HBM-bound workgroups must not sit in front of the one-block kernels of the PCA.
 int origin_aux_begin(origin_ctx *ctx) {
@@ -228,7 +267,16 @@ int origin_ctx_create(int device, origin_ctx **out) {
   // concurrent contexts: a latency-bound chain beside a chip-filling pass, tools/pca_glr_overlap.py)
   hipError_t e;
   const char *prio = getenv("ORIGIN_CTX_PRIORITY");
-  if (prio && (!strcmp(prio, "high") || !strcmp(prio, "low"))) {
+  // ORIGIN_CTX_CUS=n: this context's main stream may use the first n compute units only
+  // (hipExtStreamCreateWithCUMask) -- leaves the others to a concurrent context's small kernels
+  const char *cus = getenv("ORIGIN_CTX_CUS");
+  int masked_cus = 0;
+  if (cus && atoi(cus) > 0 && atoi(cus) < 256) {
+    masked_cus = atoi(cus);
+    uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < masked_cus; ++i) mask[i >> 5] |= 1u << (i & 31);
+    e = hipExtStreamCreateWithCUMask(&ctx->stream, 8, mask);
+  } else if (prio && (!strcmp(prio, "high") || !strcmp(prio, "low"))) {
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = least urgent, hi = most urgent
     e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio[0] == 'h' ? hi : lo);
@@ -243,6 +291,7 @@ int origin_ctx_create(int device, origin_ctx **out) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
   if (ctx->num_cu <= 0) ctx->num_cu = 256;
+  if (masked_cus > 0 && masked_cus < ctx->num_cu) ctx->num_cu = masked_cus;  // (grids are sized by it)
   *out = ctx;
   return ORIGIN_OK;
 }
@@ -261,6 +310,12 @@ int origin_ctx_destroy(origin_ctx *ctx) {
     hipStreamDestroy(ctx->aux_stream);
     hipEventDestroy(ctx->aux_fork);
     hipEventDestroy(ctx->aux_join);
+  }
+  if (ctx->side_stream) {
+    hipStreamSynchronize(ctx->side_stream);
+    hipStreamDestroy(ctx->side_stream);
+    hipEventDestroy(ctx->side_fork);
+    hipEventDestroy(ctx->side_join);
   }
   if (ctx->cvt_ready) {
     for (int b = 0; b < 2; ++b) {
@@ -281,6 +336,10 @@ int origin_ctx_destroy(origin_ctx *ctx) {
 
 int origin_sync(origin_ctx *ctx) {
   ORIGIN_USE(ctx);
+  if (ctx->side_stream && ctx->side_pending) {
+    ORIGIN_HIP(hipStreamSynchronize(ctx->side_stream));
+    ctx->side_pending = false;
+  }
   ORIGIN_HIP(hipStreamSynchronize(ctx->stream));
   if (ctx->aux_stream && ctx->aux_pending) {
     ORIGIN_HIP(hipStreamSynchronize(ctx->aux_stream));

@@ -1273,6 +1273,86 @@ int origin_glr_work_elems(origin_glr_plan *plan, size_t *elems) {
   return ORIGIN_OK;
 }
 
+// ---- a GLR run in row bands (plans whose two stages run the table kernels on the matrix cores)
+static bool glr_rows_ok(const origin_glr_plan *pl) {
+  return pl->mode == 0 && pl->nfields == 1 && !pl->d_w && pl->precision >= 1 && pl->d_atab &&
+         pl->d_rdi && origin_spatial_mfma_ok(pl->Ny, pl->Nx, pl->P);
+}
+
+int origin_glr_rows_supported(origin_glr_plan *plan, int *ok) {
+  ORIGIN_CHECK_ARG(plan && ok, "null argument");
+  *ok = glr_rows_ok(plan) ? 1 : 0;
+  return ORIGIN_OK;
+}
+
+int origin_glr_run_rows(origin_ctx *ctx, origin_glr_plan *pl, const float *d_cube,
+                        const uint8_t *d_mask, float *d_work, float *d_correl, uint8_t *d_profile,
+                        float *d_correl_min, int y0, int y1, int flags) {
+  ORIGIN_USE(ctx);
+  ORIGIN_CHECK_ARG(pl && pl->ctx == ctx, "plan does not belong to this context");
+  ORIGIN_CHECK_ARG(d_cube && d_work && d_correl && d_profile && d_correl_min, "null pointer");
+  const int Nz = pl->Nz, Ny = pl->Ny, Nx = pl->Nx, P = pl->P, K = pl->K;
+  ORIGIN_CHECK_ARG(y0 >= 0 && y0 < y1 && y1 <= Ny && y0 % 64 == 0 && (y1 % 64 == 0 || y1 == Ny),
+                   "row band must start at a multiple of 64 and end at one or at Ny");
+  if (!glr_rows_ok(pl)) {
+    origin_set_error("origin_glr_run_rows: the plan's stages do not run the matrix-core table kernels");
+    return ORIGIN_E_STATE;
+  }
+  const long S = (long)Ny * Nx;
+  const size_t cube = (size_t)Nz * S;
+  float *fsf = d_work + (size_t)MF_PAD_FRONT * S;
+  float *part = fsf + cube + (size_t)MF_PAD_BACK * S;
+  const bool side = (flags & ORIGIN_GLR_SIDE) != 0;
+  if (flags & ORIGIN_GLR_FIRST) {  // the zero channels around cube_fsf (main stream: before any band)
+    ORIGIN_HIP(hipMemsetAsync(d_work, 0, (size_t)MF_PAD_FRONT * S * sizeof(float), ctx->stream));
+    ORIGIN_HIP(hipMemsetAsync(fsf + cube, 0, (size_t)MF_PAD_BACK * S * sizeof(float), ctx->stream));
+  }
+  // the launch functions enqueue on ctx->stream: the side stream takes its place for this band
+  if (side) {
+    if (int rc = origin_side_begin(ctx)) return rc;
+    std::swap(ctx->stream, ctx->side_stream);
+  }
+  int rc = ORIGIN_OK;
+  {
+    ProfScope ps(ctx, K_GLR_SPATIAL);
+    rc = origin_spatial_mfma_launch(ctx, pl->precision == 2 ? 1 : 3, d_cube, nullptr, pl->d_k, Nz, Ny,
+                                    Nx, P, 0, fsf, y0 / 64, cdiv(y1 - y0, 64));
+  }
+  if (rc == ORIGIN_OK) {
+    ProfScope ps(ctx, K_GLR_SPECTRAL);
+    int nzc = 0;
+    float *pmax = nullptr, *pmin = nullptr;
+    rc = origin_spectral_mfma_launch(
+        ctx, pl->precision == 2 ? 1 : 3, fsf, pl->d_rden, pl->d_rdi_s, pl->NzP,
+        pl->precision == 2 ? pl->d_atab_bf16 : pl->d_atab, pl->d_pwide, K, pl->n_narrow, Nz, Ny, Nx,
+        P, d_mask, d_correl, d_profile, d_correl_min, part, true, &nzc, &pmax, &pmin,
+        pl->precision == 2 ? pl->d_atab_bf16_fold : pl->d_atab_fold, pl->d_rden_fold, pl->d_sden,
+        pl->order_ident, (long)y0 * Nx, (long)(y1 - y0) * Nx);
+  }
+  if (side) {
+    std::swap(ctx->stream, ctx->side_stream);
+    if (rc == ORIGIN_OK) rc = origin_side_end(ctx);
+  }
+  return rc;
+}
+
+int origin_glr_run_finish(origin_ctx *ctx, origin_glr_plan *pl, float *d_work, float *d_maxmap,
+                          float *d_minmap) {
+  ORIGIN_USE(ctx);
+  ORIGIN_CHECK_ARG(pl && pl->ctx == ctx && d_work, "bad argument");
+  if (int rc = origin_side_join(ctx)) return rc;  // bands on the side stream
+  if (!d_maxmap && !d_minmap) return ORIGIN_OK;
+  const long S = (long)pl->Ny * pl->Nx;
+  float *fsf = d_work + (size_t)MF_PAD_FRONT * S;
+  float *part = fsf + (size_t)pl->Nz * S + (size_t)MF_PAD_BACK * S;
+  const int nzc = origin_spectral_mfma_chunks(ctx->num_cu, pl->Nz, pl->Ny, pl->Nx);
+  ProfScope ps(ctx, K_SMALL);
+  hipLaunchKernelGGL(maxmap_final_kernel, dim3(cdiv(S, 256)), dim3(256), 0, ctx->stream, part,
+                     part + (size_t)nzc * S, nzc, S, d_maxmap, d_minmap);
+  ORIGIN_LAUNCH_CHECK();
+  return ORIGIN_OK;
+}
+
 int origin_glr_run(origin_ctx *ctx, origin_glr_plan *pl, const float *d_cube,
                    const uint8_t *d_mask, float *d_work, float *d_correl,
                    uint8_t *d_profile, float *d_correl_min, float *d_maxmap,

@@ -107,7 +107,8 @@ __global__ __launch_bounds__(512, 1) void spatial2_kernel(const float *__restric
                                                           const float *__restrict__ W,
                                                           const float *__restrict__ taps, int Nz,
                                                           int Ny, int Nx, int zper, int accf,
-                                                          float *__restrict__ out) {
+                                                          float *__restrict__ out, int ry0) {
+  // (ry0: first row of 64 x 64 regions of this launch -- a run may be split into row bands)
   using G = S2Geom<P>;
   extern __shared__ __align__(16) char s2_lds[];
   constexpr int c = P / 2;
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(512, 1) void spatial2_kernel(const float *__restric
   float *tapst = reinterpret_cast<float *>(tab_h + (TERMS == 3 ? 2 : 1) * G::TAB);
   unsigned *maxw = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(tapst) + G::TAPS);
 
-  const int x0 = blockIdx.x * S2_R, y0 = blockIdx.y * S2_R;
+  const int x0 = blockIdx.x * S2_R, y0 = (blockIdx.y + ry0) * S2_R;
   const long S = (long)Ny * Nx;
   const int z0 = blockIdx.z * zper, z1 = min(Nz, z0 + zper);
   const int n = lane & 31, h = lane >> 5;
@@ -380,7 +381,7 @@ int origin_spatial_mfma_ok(int Ny, int Nx, int P) {
 
 template <int P, int TERMS, bool VEC, bool WEIGHTED>
 static int s2_launch(origin_ctx *ctx, const float *A, const float *W, const float *taps, int Nz,
-                     int Ny, int Nx, int accf, float *out) {
+                     int Ny, int Nx, int accf, float *out, int ry0, int nry) {
   const size_t lds = 2 * s2_group_bytes<P, TERMS>();
   static bool attr_done = false;
   if (!attr_done) {
@@ -390,7 +391,8 @@ static int s2_launch(origin_ctx *ctx, const float *A, const float *W, const floa
   }
   // one block per CU at a time (LDS): choose the number of z chunks so that the blocks fill
   // whole rounds of the chip (an even number of channels per chunk keeps both groups busy)
-  const long regions = (long)cdiv(Nx, S2_R) * cdiv(Ny, S2_R);
+  if (nry <= 0) ry0 = 0, nry = cdiv(Ny, S2_R);
+  const long regions = (long)cdiv(Nx, S2_R) * nry;
   const int ncu = std::max(1, ctx->num_cu);
   int best_nzb = 1;
   double best_eff = 0.0;
@@ -405,9 +407,9 @@ static int s2_launch(origin_ctx *ctx, const float *A, const float *W, const floa
   }
   int zper = cdiv(Nz, best_nzb);
   zper += zper & 1;
-  dim3 grid(cdiv(Nx, S2_R), cdiv(Ny, S2_R), cdiv(Nz, zper));
+  dim3 grid(cdiv(Nx, S2_R), nry, cdiv(Nz, zper));
   hipLaunchKernelGGL((spatial2_kernel<P, TERMS, VEC, WEIGHTED>), grid, dim3(512), lds, ctx->stream,
-                     A, W, taps, Nz, Ny, Nx, zper, accf, out);
+                     A, W, taps, Nz, Ny, Nx, zper, accf, out, ry0);
   ORIGIN_LAUNCH_CHECK();
   return ORIGIN_OK;
 }
@@ -415,7 +417,7 @@ static int s2_launch(origin_ctx *ctx, const float *A, const float *W, const floa
 // W: weight map of the field or NULL; accf: add to `out` (fields after the first)
 int origin_spatial_mfma_launch(origin_ctx *ctx, int terms, const float *A, const float *W,
                                const float *taps, int Nz, int Ny, int Nx, int P, int accf,
-                               float *out) {
+                               float *out, int ry0, int nry) {
   // (tile loads start at x0 - P/2: float4-aligned only when P/2 is a multiple of four)
   const bool vec = (Nx & 3) == 0 && ((P / 2) & 3) == 0;
   if (!W && accf) {
@@ -423,8 +425,8 @@ int origin_spatial_mfma_launch(origin_ctx *ctx, int terms, const float *A, const
     return ORIGIN_E_ARG;
   }
 #define S2_GO(PP, TT, VV)                                                                      \
-  return W ? s2_launch<PP, TT, VV, true>(ctx, A, W, taps, Nz, Ny, Nx, accf, out)               \
-           : s2_launch<PP, TT, VV, false>(ctx, A, nullptr, taps, Nz, Ny, Nx, 0, out)
+  return W ? s2_launch<PP, TT, VV, true>(ctx, A, W, taps, Nz, Ny, Nx, accf, out, ry0, nry)     \
+           : s2_launch<PP, TT, VV, false>(ctx, A, nullptr, taps, Nz, Ny, Nx, 0, out, ry0, nry)
 #define S2_CASE(PP)                        \
   case PP:                                 \
     if (vec) {                             \

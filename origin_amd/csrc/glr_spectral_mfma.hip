@@ -666,7 +666,10 @@ __global__ __launch_bounds__(64 * MF_WAVES, 1) void spectral_mfma2_kernel(
     const float *__restrict__ rdi_s, int NzP, const uint4 *__restrict__ atab,
     const int *__restrict__ pinfo, int K, int NP, int Nz, int Ny, int Nx, int P, int zchunk, const uint8_t *__restrict__ mask, float *__restrict__ correl,
     uint8_t *__restrict__ profile, float *__restrict__ correl_min, float *__restrict__ part_max,
-    float *__restrict__ part_min, const float *__restrict__ sden, int zf0, int zf1, int nN) {
+    float *__restrict__ part_min, const float *__restrict__ sden, int zf0, int zf1, int nN,
+    long s_first, long s_end) {
+  // (s_first, s_end: the spaxels of this launch, in multiples of 32 from the field's first -- a run
+  // may be split into row bands; waves hold the same 32 spaxels as in a launch over the field)
   extern __shared__ __align__(16) char sm_lds[];
   const int Kp = K + (K & 1);  // slots in LDS: an odd K's last profile twice (its pair partner)
   {
@@ -680,8 +683,8 @@ __global__ __launch_bounds__(64 * MF_WAVES, 1) void spectral_mfma2_kernel(
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, in an SGPR
   const int r = lane & 31, h = lane >> 5;
-  const long s_base = ((long)blockIdx.x * MF_WAVES + wv) * 32;
-  if (s_base >= S) return;  // whole wave; no barrier follows
+  const long s_base = s_first + ((long)blockIdx.x * MF_WAVES + wv) * 32;
+  if (s_base >= s_end) return;  // whole wave; no barrier follows
   const int zc0 = blockIdx.y * zchunk, zc1 = min(Nz, zc0 + zchunk);
   // A rows: lane r is output channel zi = r & 15 of the pair's profile r >> 4; its fragment of
   // window block b starts at G[31 - zi + 8 h + 16 b]
@@ -690,9 +693,9 @@ __global__ __launch_bounds__(64 * MF_WAVES, 1) void spectral_mfma2_kernel(
   // this wave's [K][32] table of 1/sqrt(den) for the current tile (behind the tap copies), in
   // the order the profiles are processed
   char *rd_wave = sm_lds + Kp * MF_PROF_BYTES + wv * K * MF_RD_BYTES;
-  const bool sv = s_base + r < S;
-  const bool all_valid = s_base + 32 <= S;
-  const long sc = sv ? s_base + r : S - 1;
+  const bool sv = s_base + r < s_end;
+  const bool all_valid = s_base + 32 <= s_end;
+  const long sc = sv ? s_base + r : s_end - 1;
   const int rr = (int)(sc - s_base);  // r, clamped for lanes past the field
   float vmax = -INFINITY, vmin = INFINITY;
   // normalisation class of this lane's spaxel (how the field border clips the PSF window)
@@ -770,6 +773,14 @@ static void sm_geometry(int num_cu, int Nz, long S, long *bx_out, int *nzm_out, 
 // spaxel walks all 32-channel tiles of its chunk; a tile is two 16-channel halves, a half runs
 // every profile pair (slots 2p, 2p+1 of the processing order, narrow profiles first) with 3
 // k-steps (both narrow: window blocks 1..3) or 5, `terms` MFMAs per k-step.
+// z chunks (rows of the partial maps) of a launch
+int origin_spectral_mfma_chunks(int num_cu, int Nz, int Ny, int Nx) {
+  long bx;
+  int nzm, zcm;
+  sm_geometry(num_cu, Nz, (long)Ny * Nx, &bx, &nzm, &zcm);
+  return nzm;
+}
+
 long origin_spectral_mfma_count(int num_cu, int terms, int K, int n_narrow, int Nz, int Ny,
                                 int Nx) {
   const long S = (long)Ny * Nx;
@@ -797,11 +808,20 @@ int origin_spectral_mfma_launch(origin_ctx *ctx, int terms, const float *fsf, co
                                 float *correl, uint8_t *profile, float *correl_min, float *part,
                                 bool want_maps, int *nzc_out, float **pmax_out, float **pmin_out,
                                 const uint4 *atab_fold, const float *rden_fold, const float *sden,
-                                int ident) {
+                                int ident, long s_first, long s_count) {
   const long S = (long)Ny * Nx;
   long bx;
   int nzm, zcm;
+  // (the z chunks are those of a launch over the whole field, whatever part of it this one takes:
+  // the partial maps of all parts of a run share their layout)
   sm_geometry(ctx->num_cu, Nz, S, &bx, &nzm, &zcm);
+  if (s_count <= 0) s_first = 0, s_count = S;
+  if (s_first % 32 != 0 || s_first < 0 || s_first + s_count > S) {
+    origin_set_error("spectral MFMA kernel: bad spaxel range");
+    return ORIGIN_E_ARG;
+  }
+  bx = cdiv(s_count, 32 * MF_WAVES);
+  long s_end = s_first + s_count;
   float *pmax = want_maps ? part : nullptr;
   float *pmin = want_maps ? part + (size_t)nzm * S : nullptr;
   const int Kp = K + (K & 1);
@@ -840,7 +860,7 @@ int origin_spectral_mfma_launch(origin_ctx *ctx, int terms, const float *fsf, co
   const float *a_rden = fold ? rden_fold : rden;
   int a_NP = NP, a_zcm = zcm;
   void *args[] = {&fsf, &a_rden, &rdi_s, &NzP, &a_atab, &pinfo, &K, &a_NP, &Nz, &Ny, &Nx, &P, &a_zcm,
-                  &mask, &correl, &profile, &correl_min, &pmax, &pmin, &sden, &zf0, &zf1, &nN};
+                  &mask, &correl, &profile, &correl_min, &pmax, &pmin, &sden, &zf0, &zf1, &nN, &s_first, &s_end};
   ORIGIN_HIP(hipLaunchKernel(fn, dim3((unsigned)bx, (unsigned)nzm), dim3(64 * MF_WAVES), args,
                              fold ? std::max(lds, lds_fold) : lds, ctx->stream));
   ORIGIN_LAUNCH_CHECK();

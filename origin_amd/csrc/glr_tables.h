@@ -46,10 +46,11 @@ int origin_spectral_mfma_launch(origin_ctx *ctx, int terms, const float *fsf, co
                                 uint8_t *profile, float *correl_min, float *part, bool want_maps,
                                 int *nzc_out, float **pmax_out, float **pmin_out,
                                 const uint4 *atab_fold, const float *rden_fold, const float *sden,
-                                int ident);
+                                int ident, long s_first = 0, long s_count = 0);
 
 long origin_spectral_mfma_count(int num_cu, int terms, int K, int n_narrow, int Nz, int Ny,
                                 int Nx);
+int origin_spectral_mfma_chunks(int num_cu, int Nz, int Ny, int Nx);
 
 // glr_spectral_norm_mfma.hip: the same stage for plans with an explicit norm cube (weighted fields)
 int origin_spectral_norm_mfma_max_k();

@@ -2346,6 +2346,13 @@ __global__ __launch_bounds__(256) void uw_partial_kernel(const double *__restric
   }
 }
 
+#ifdef PCA_EXP_DUMMY
+// experiment: what one more dependent launch costs a tail iteration
+__global__ void pca_dummy_kernel(const long *__restrict__ D, int nw, double *__restrict__ out) {
+  if (threadIdx.x == 0) out[blockIdx.x] = (double)D[blockIdx.x % nw];
+}
+#endif
+
 // normalise u_k, store it as column T_k of U, and w_k[q] = u_k . U[:, q] for q < T_k
 __global__ __launch_bounds__(1024) void normalize_kernel(double *__restrict__ u, int Nz,
                                                          const long *__restrict__ D, int nw,
@@ -2745,6 +2752,15 @@ int origin_pca_eig_qrows(void) { return EIG_QROWS; }
 // element of an (Nz, S / out_nx, out_nx) box inside a larger cube with row pitch out_py and plane
 // pitch out_pz (elements) -- the interior of a halo-extended tile, so that the tiled path needs no
 // copy between the PCA and the halo exchange; d_X must then be a different, contiguous cube.
+int origin_pca_set_tail_hook(origin_ctx *ctx, void (*hook)(void *, int, const int *), void *user,
+                             int max_active) {
+  ORIGIN_CHECK_ARG(ctx && max_active >= 0, "bad argument");
+  ctx->pca_tail_hook = hook;
+  ctx->pca_tail_user = user;
+  ctx->pca_tail_max = max_active;
+  return ORIGIN_OK;
+}
+
 int origin_pca_run_into(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S, int na,
                         const int *d_spx, const long *h_spx_off, const double *d_test0,
                         const double *h_thr, double noise_pop, int itermax, int *d_mapO2,
@@ -2885,7 +2901,12 @@ int origin_pca_run_into(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, l
   // (strided output: a flush in the middle of the run -- an area used up its PCA_CAP slots -- goes
   // to a contiguous work cube the later passes read; only the final one writes d_F)
   float *d_work = nullptr;
-  auto flush = [&](bool final) -> int {
+  // Areas written to d_F ahead of the final flush (tail hook, below): they have stopped iterating
+  // for good -- the final flush leaves them alone.  only_done: write just the areas that are not
+  // in the work list any more (counts n_done[a] < 2); nothing else changes (src, T of the others).
+  std::vector<char> flushed(na, 0);
+  const int *n_done = nullptr;
+  auto flush = [&](bool final, bool only_done = false) -> int {
     float *dst = d_F;
     if (strided && !final) {
       int rw = W.b[20].reserve(ctx, (size_t)Nz * S * sizeof(float));
@@ -2900,7 +2921,10 @@ int origin_pca_run_into(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, l
     const bool all = src != dst;
     std::vector<long> fd;
     int nf = 0, nsmax = 0;
-    auto wanted = [&](int a) { return (all || T[a] > 0) && h_spx_off[a + 1] > h_spx_off[a]; };
+    auto wanted = [&](int a) {
+      if (flushed[a] || (only_done && n_done[a] >= 2)) return false;
+      return (all || T[a] > 0) && h_spx_off[a + 1] > h_spx_off[a];
+    };
     for (int a = 0; a < na; ++a) nf += wanted(a);
     if (nf > 0) {
       fd.assign((size_t)4 * nf, 0);
@@ -2930,6 +2954,11 @@ int origin_pca_run_into(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, l
                          Nz, S, d_spx, (const long *)b_fd.p, nf, d_U, d_C, ntot, nxb, nzb,
                          to_strided ? out_nx : 0, out_py, out_pz);
       ORIGIN_LAUNCH_CHECK();
+    }
+    if (only_done) {  // the areas that still iterate keep their vectors and go on reading src
+      for (int a = 0; a < na; ++a)
+        if (n_done[a] < 2) flushed[a] = 1, T[a] = 0;
+      return ORIGIN_OK;
     }
     for (int a = 0; a < na; ++a) T[a] = 0;
     std::fill(fb_off.begin(), fb_off.end(), -1L);  // (blocks refer to columns of U)
@@ -3004,6 +3033,7 @@ int origin_pca_run_into(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, l
   if ((rc = wait_select())) return rc;
   memcpy(n_lay.data(), h_nnb, 2 * (size_t)na * sizeof(int));
   bool exact = true;
+  bool tail_fired = false;
   // Default: selection, hand-shake, exact work list, chain.  ORIGIN_PCA_PIPELINED=1 lets the host
   // run one selection ahead (below).  Measured A/B at 3681 x 600 x 600 (57 iterations): 25.7-25.9
   // against 26.0-26.3 ms -- the loop is bound by the device (host: 2 ms of enqueueing, 20 ms of
@@ -3036,6 +3066,22 @@ int origin_pca_run_into(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, l
         full = full || T[a] >= PCA_CAP;
       }
     if (nw == 0) break;
+    // Tail hook: once, when few areas are left.  The areas that are done are written to d_F now
+    // (the pass they would have had at the end), then the caller learns which areas go on -- it may
+    // start the next stage on everything that does not depend on them (origin_glr_run_rows on the
+    // side stream).  Needs exact counts (the default, non-pipelined loop) and no work cube between
+    // the input and d_F.
+    if (ctx->pca_tail_hook && !tail_fired && exact && iters >= 1 && nw <= ctx->pca_tail_max &&
+        !d_work && !full) {
+      tail_fired = true;
+      n_done = n_lay.data();
+      if ((rc = flush(true, true))) return rc;
+      n_done = nullptr;
+      std::vector<int> act;
+      for (int a = 0; a < na; ++a)
+        if (n_lay[a] >= 2) act.push_back(a);
+      ctx->pca_tail_hook(ctx->pca_tail_user, (int)act.size(), act.data());
+    }
     if (full && (rc = flush(false))) return rc;  // an area used up its PCA_CAP slots
     D.assign((size_t)DF_COUNT * nw, 0);
     long xp = 0, c = 0, g = 0, q = 0, cb = 0;
@@ -3253,6 +3299,13 @@ int origin_pca_run_into(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, l
       hipLaunchKernelGGL(deflate_finish_kernel, dim3(cdiv(nsmax, 256), nw), dim3(256), 0, st, d_spx,
                          dD, nw, nzs, Nz, cb, cpart, d_wq, d_C, ntot, d_test);
     }
+#ifdef PCA_EXP_DUMMY
+    {
+      static const int nd = getenv("ORIGIN_PCA_EXP_DUMMY") ? atoi(getenv("ORIGIN_PCA_EXP_DUMMY")) : 0;
+      for (int i = 0; i < nd; ++i)
+        hipLaunchKernelGGL(pca_dummy_kernel, dim3(nw), dim3(64), 0, st, dD, nw, d_wq);
+    }
+#endif
     ORIGIN_LAUNCH_CHECK();
     // the real counts of this iteration (the device is busy with its chain meanwhile)
     const auto tp2 = now();

@@ -55,6 +55,32 @@ class Context:
     def sync(self):
         _capi.call("origin_sync", self._h)
 
+    # -- greedy PCA tail hook (include/origin_hip.h origin_pca_set_tail_hook) -----------------
+    _TAIL_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(C.c_int))
+
+    def set_pca_tail_hook(self, fn, max_active=2):
+        """``fn(areas)`` is called once per greedy-PCA run, from inside it, when at most
+        ``max_active`` areas still iterate and the others have been written to the output;
+        ``areas`` = indices of the areas that go on.  ``fn=None`` removes the hook."""
+        if fn is None:
+            self._tail_cb = None
+            _capi.call("origin_pca_set_tail_hook", self._h, None, None, 0)
+            return
+        self._tail_exc = None
+
+        def cb(_user, n, areas):
+            try:
+                fn([int(areas[i]) for i in range(n)])
+            except BaseException as e:   # (an exception cannot cross the C frames)
+                self._tail_exc = e
+        self._tail_cb = self._TAIL_CB(cb)
+        _capi.call("origin_pca_set_tail_hook", self._h, C.cast(self._tail_cb, C.c_void_p), None,
+                   int(max_active))
+
+    def pop_tail_hook_error(self):
+        e, self._tail_exc = getattr(self, "_tail_exc", None), None
+        return e
+
     def stream_ptr(self):
         s = C.c_void_p()
         _capi.call("origin_stream", self._h, C.byref(s))

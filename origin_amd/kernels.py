@@ -180,6 +180,34 @@ class GLRPlan:
             w is None or (self.precision == "f16x2" and len(self.tap_lengths) <= 26
                           and max(self.tap_lengths) <= 65))
 
+    # -- the same run in row bands (include/origin_hip.h origin_glr_run_rows) ---------------
+    def rows_supported(self):
+        """Whether the plan's two stages run the table kernels on the matrix cores (one field,
+        no weight maps, PSF 5..25, half widths <= 32): only those plans run in row bands."""
+        ok = C.c_int()
+        _capi.call("origin_glr_rows_supported", self._h, C.byref(ok))
+        return bool(ok.value)
+
+    def run_rows(self, cube, mask, correl, profile, correl_min, y0, y1, first=False, side=False):
+        """The rows [y0, y1) of a run (y0 a multiple of 64, y1 one or Ny): spatial stage (reads
+        cube rows [y0 - P//2, y1 + P//2)), spectral stage, partial maps.  ``first``: the first band
+        of a run; ``side``: enqueue on the context's side stream (all CUs but a reserve), behind
+        what the main stream holds now."""
+        assert cube.shape == self.shape and cube.dtype == np.float32
+        _capi.call("origin_glr_run_rows", self.ctx.handle, self._h, cube.p, _p(mask),
+                   self.workspace().p, correl.p, profile.p, correl_min.p, int(y0), int(y1),
+                   (1 if first else 0) | (2 if side else 0))
+
+    def run_finish(self, want_maps=True):
+        """Ends a run in row bands: the main stream waits for the side bands; returns
+        (maxmap, minmap) or (None, None)."""
+        Nz, Ny, Nx = self.shape
+        maxmap = self.ctx.empty((Ny, Nx), np.float32) if want_maps else None
+        minmap = self.ctx.empty((Ny, Nx), np.float32) if want_maps else None
+        _capi.call("origin_glr_run_finish", self.ctx.handle, self._h, self.workspace().p,
+                   _p(maxmap), _p(minmap))
+        return maxmap, minmap
+
     def mfma_count(self):
         """(spatial, spectral): matrix-core instructions (32768 flop each) one run issues per
         stage -- rocprofv3's SQ_INSTS_MFMA per launch; 0 for a stage on the fp32 kernels."""

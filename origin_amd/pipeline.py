@@ -106,6 +106,85 @@ def greedy_pca(ctx, cube_std, areamap, nbAreas, thresholds, testO2, Noise_popula
     return F, hmap.astype(np.float64).reshape(Ny, Nx), nstop, drv
 
 
+def glr_bands_for(active_rows, Ny, halo):
+    """(early, late): row bands [y0, y1) in units the row-band GLR accepts (multiples of 64, the
+    last one ends at Ny).  ``active_rows``: (ymin, ymax) inclusive of every area that still
+    iterates; a band is late when its spatial stage would read a row of one of them (+- halo)."""
+    nb = (Ny + 63) // 64
+    late = np.zeros(nb, bool)
+    for ymin, ymax in active_rows:
+        b0 = max(0, (ymin - halo) // 64)
+        b1 = min(nb - 1, (ymax + halo) // 64)
+        late[b0:b1 + 1] = True
+
+    def runs(flag):
+        out, b = [], 0
+        while b < nb:
+            if late[b] == flag:
+                e = b
+                while e < nb and late[e] == flag:
+                    e += 1
+                out.append((64 * b, min(Ny, 64 * e)))
+                b = e
+            else:
+                b += 1
+        return out
+    return runs(False), runs(True)
+
+
+def greedy_pca_then_glr(ctx, plan, cube_std, areamap, nbAreas, thresholds, testO2, mask,
+                        correl, profile, correl_min, cube_faint, Noise_population=50, itermax=100,
+                        spx=None, driver=None, o2_dev=None, max_active=2, area_rows=None):
+    """greedy PCA and GLR of one field with the GLR of the finished part of the field started in
+    the shadow of the PCA's tail: when at most ``max_active`` areas still iterate, the library
+    writes the others to ``cube_faint`` and calls back; the row bands whose spatial stage reads
+    none of the rows of the areas that go on run at once on the context's side stream (all CUs
+    but a reserve the PCA's small kernels keep), the remaining bands behind the PCA on the main
+    stream.  Same results as ``greedy_pca`` followed by ``plan.run`` (the bands run the same
+    kernels on the same waves and regions).  Returns (cube_faint, mapO2, nstop, driver, out)
+    with ``out`` as ``plan.run`` returns it, plus ``out["bands"] = (early, late)``."""
+    Nz, Ny, Nx = cube_std.shape
+    spx = area_lists(areamap, nbAreas) if spx is None else spx
+    if area_rows is None:
+        area_rows = [(int(s.min()) // Nx, int(s.max()) // Nx) if len(s) else None for s in spx]
+    halo = plan.P // 2
+    state = {"early": None, "late": None}
+
+    def hook(areas):
+        early, late = glr_bands_for([area_rows[a] for a in areas if area_rows[a]], Ny, halo)
+        for i, (y0, y1) in enumerate(early):
+            plan.run_rows(cube_faint, mask, correl, profile, correl_min, y0, y1, first=(i == 0),
+                          side=True)
+        state["early"], state["late"] = early, late
+
+    use = plan.rows_supported() and max_active > 0
+    if use:
+        ctx.set_pca_tail_hook(hook, max_active)
+    try:
+        F, mapO2, nstop, drv = greedy_pca(ctx, cube_std, areamap, nbAreas, thresholds, testO2,
+                                          Noise_population, itermax, spx=spx, driver=driver,
+                                          o2_dev=o2_dev, out=cube_faint)
+    finally:
+        if use:
+            ctx.set_pca_tail_hook(None)
+    err = ctx.pop_tail_hook_error() if use else None
+    if err is not None:
+        raise err
+    if state["early"] is None:     # the hook did not fire (every area finished together)
+        out = plan.run(F, mask=mask, correl=correl, profile=profile, correl_min=correl_min,
+                       want_maps=True)
+        out["bands"] = ([], [(0, Ny)])
+        return F, mapO2, nstop, drv, out
+    first = len(state["early"]) == 0
+    for y0, y1 in state["late"]:
+        plan.run_rows(F, mask, correl, profile, correl_min, y0, y1, first=first, side=False)
+        first = False
+    maxmap, minmap = plan.run_finish(want_maps=True)
+    out = dict(correl=correl, profile=profile, correl_min=correl_min, maxmap=maxmap,
+               minmap=minmap, bands=(state["early"], state["late"]))
+    return F, mapO2, nstop, drv, out
+
+
 def tglr(ctx, plan, cube_faint, mask, size=3, want_local=True):
     """``ComputeTGLR.run`` dense part (steps.py:770-802): GLR + mask glue + maps + local
     maxima, all on the device."""

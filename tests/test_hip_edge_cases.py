@@ -300,3 +300,102 @@ def test_pca_into_a_box_of_a_larger_cube(ctx, deep):
     assert np.array_equal(want[:, 0, :], cube[:, 0, :])       # outside every area: copied
     got[:, top:top + Ny, left:left + Nx] = -7.0
     assert np.all(got == -7.0)                                 # nothing else was written
+
+
+@pytest.mark.parametrize("precision", ["f16x2", "bf16"])
+def test_glr_row_bands_write_what_the_whole_run_writes(ctx, precision):
+    """origin_glr_run_rows: the run split into row bands (three on the main stream in shuffled
+    order, one on the CU-masked side stream) -- bit for bit the cubes and maps of origin_glr_run,
+    with a mask, a field height that is no multiple of 64 and a width that is no multiple of 32."""
+    from origin_amd import kernels
+    rng = np.random.default_rng(5)
+    Nz, Ny, Nx = 200, 230, 77
+    cube = rng.standard_normal((Nz, Ny, Nx)).astype(np.float32)
+    cube[40:90] *= 21.0
+    mask = (rng.random((Nz, Ny, Nx)) < 0.01).astype(np.uint8)
+    psf = synth.moffat_psf(3681, 9)[:Nz].astype(np.float64)
+    prof = synth.dico_fwhm(20)
+    plan = kernels.GLRPlan(ctx, cube.shape, psf, None, prof, 1e-8, True, precision=precision)
+    assert plan.rows_supported()
+    d_cube, d_mask = ctx.to_device(cube), ctx.to_device(mask)
+    whole = plan.run(d_cube, mask=d_mask, want_maps=True)
+    want = {k: whole[k].to_host() for k in ("correl", "correl_min", "profile", "maxmap", "minmap")}
+    correl = ctx.empty(cube.shape, np.float32)
+    cmin = ctx.empty(cube.shape, np.float32)
+    prof_i = ctx.empty(cube.shape, np.uint8)
+    for a in (correl, cmin, prof_i):
+        a.fill_bytes(0x7f)
+    plan.run_rows(d_cube, d_mask, correl, prof_i, cmin, 128, 192, first=True)
+    plan.run_rows(d_cube, d_mask, correl, prof_i, cmin, 0, 64, side=True)
+    plan.run_rows(d_cube, d_mask, correl, prof_i, cmin, 192, Ny)
+    plan.run_rows(d_cube, d_mask, correl, prof_i, cmin, 64, 128)
+    maxmap, minmap = plan.run_finish()
+    ctx.sync()
+    got = dict(correl=correl.to_host(), correl_min=cmin.to_host(), profile=prof_i.to_host(),
+               maxmap=maxmap.to_host(), minmap=minmap.to_host())
+    for k in want:
+        assert np.array_equal(got[k], want[k]), k
+    with pytest.raises(Exception):
+        plan.run_rows(d_cube, d_mask, correl, prof_i, cmin, 32, 128)   # not a multiple of 64
+    plan.close()
+
+
+@pytest.mark.parametrize("max_active", [1, 2])
+def test_pca_tail_hook_and_the_glr_started_in_its_shadow(ctx, max_active):
+    """pipeline.greedy_pca_then_glr: one area of six keeps iterating long after the others; when
+    at most max_active areas are left the library writes the finished ones out and calls back, the
+    row bands that do not touch the stragglers run on the side stream while the PCA goes on.
+    cube_faint, mapO2, nstop and every GLR output are bit for bit those of the sequential calls;
+    the bands are the ones the areas' rows imply."""
+    from origin_amd import kernels, pipeline
+    rng = np.random.default_rng(11)
+    Nz, Ny, Nx = 150, 300, 128
+    cube = rng.standard_normal((Nz, Ny, Nx)).astype(np.float32)
+    areamap = np.zeros((Ny, Nx), int)
+    for i in range(3):
+        for j in range(2):
+            areamap[100 * i:100 * (i + 1), 64 * j:64 * (j + 1)] = 2 * i + j + 1
+    nb = 6
+    flat = cube.reshape(Nz, -1)
+    # a few bright spectra per area; many more, of comparable strength, in area 4 (rows 100-199)
+    for a in range(nb):
+        idx = np.flatnonzero(areamap.reshape(-1) == a + 1)
+        for j in range(40 if a == 3 else 3):
+            flat[:, idx[17 * j + 5]] += (7.0 + 0.11 * j) * rng.standard_normal(Nz).astype(np.float32)
+    if max_active == 2:       # a second straggler, in the top band
+        idx = np.flatnonzero(areamap.reshape(-1) == 2)
+        for j in range(25):
+            flat[:, idx[13 * j + 7]] += (6.5 + 0.13 * j) * rng.standard_normal(Nz).astype(np.float32)
+    X = cube.astype(float)
+    tests = [cpu_ref.O2test(X[:, areamap == a + 1]) for a in range(nb)]
+    thr = [float(np.percentile(t, 99.0)) for t in tests]
+    mask = (rng.random((Nz, Ny, Nx)) < 0.005).astype(np.uint8)
+    psf = synth.moffat_psf(3681, 9)[:Nz].astype(np.float64)
+    plan = kernels.GLRPlan(ctx, cube.shape, psf, None, synth.dico_fwhm(20), 1e-8, True,
+                           precision="f16x2")
+    d, d_mask = ctx.to_device(cube), ctx.to_device(mask)
+    F0, map0, nstop0, _ = pipeline.greedy_pca(ctx, d, areamap, nb, thr, tests, 50, 100)
+    out0 = plan.run(F0, mask=d_mask, want_maps=True)
+    want = {k: out0[k].to_host() for k in ("correl", "correl_min", "profile", "maxmap", "minmap")}
+    it = [map0[areamap == a + 1].max() for a in range(nb)]
+    assert it[3] > 2 * max(it[i] for i in (0, 2, 4, 5))          # area 4 is a straggler
+    correl, cmin = ctx.empty(cube.shape, np.float32), ctx.empty(cube.shape, np.float32)
+    prof_i, faint = ctx.empty(cube.shape, np.uint8), ctx.empty(cube.shape, np.float32)
+    for a in (correl, cmin, prof_i, faint):
+        a.fill_bytes(0x7f)
+    F1, map1, nstop1, _, out1 = pipeline.greedy_pca_then_glr(
+        ctx, plan, d, areamap, nb, thr, tests, d_mask, correl, prof_i, cmin, faint,
+        max_active=max_active)
+    ctx.sync()
+    assert nstop0 == nstop1 and np.array_equal(map0, map1)
+    assert np.array_equal(F1.to_host(), F0.to_host())
+    for k in want:
+        assert np.array_equal(out1[k].to_host(), want[k]), k
+    early, late = out1["bands"]
+    assert early and late, (early, late)                         # the hook did fire
+    # area 4 = rows 100..199, halo 4: regions 64..255 wait; with the second straggler (area 2,
+    # rows 0..99) everything above row 256 does
+    assert late == ([(64, 256)] if max_active == 1 and it[1] < it[3] / 2 else late)
+    assert all(y0 % 64 == 0 for y0, _ in early + late)
+    assert sorted(early + late)[0][0] == 0 and sorted(early + late)[-1][1] == Ny
+    plan.close()

@@ -22,6 +22,14 @@ if os.environ.get("ORIGIN_OVERLAP_PRIO") == "1":
     os.environ["ORIGIN_CTX_PRIORITY"] = "low"
     b = Context(0)
     del os.environ["ORIGIN_CTX_PRIORITY"]
+elif os.environ.get("ORIGIN_OVERLAP_GLR_CUS"):
+    # the GLR's stream restricted to the first n compute units: the rest stays free for the PCA
+    os.environ["ORIGIN_CTX_PRIORITY"] = "high"
+    a = Context(0)
+    del os.environ["ORIGIN_CTX_PRIORITY"]
+    os.environ["ORIGIN_CTX_CUS"] = os.environ["ORIGIN_OVERLAP_GLR_CUS"]
+    b = Context(0)
+    del os.environ["ORIGIN_CTX_CUS"]
 else:
     a, b = Context(0), Context(0)
 f = synth.SyntheticField(Nz, N, N)
