@@ -322,16 +322,14 @@ def main():
             F, mapO2, nstop, drv, out = pipeline.greedy_pca_then_glr(
                 ctx, plan, cube_std, local_map, nb_local, thr["thresO2"], thr["testO2"], mask,
                 correl, profile, correl_min, cube_faint, 50, 100, spx=spx, driver=pca_driver,
-                o2_dev=pre["o2"], max_active=args.tail_max_active, area_rows=area_rows)
+                o2_dev=pre["o2"], max_active=args.tail_max_active, area_rows=area_rows,
+                local_max=(lmax_buf, lmin_buf) if do_lm else None)
             info["glr_bands"] = {"early": out["bands"][0], "late": out["bands"][1]}
             t3 = time.perf_counter()
-            if do_lm:
-                kernels.local_max(ctx, correl, correl_min, mask, 3, out_max=lmax_buf,
-                                  out_min=lmin_buf)
             ctx.sync()
             t4 = time.perf_counter()
             for k, v in (("dct_std", t1 - t0), ("threshold_fit_host", t2 - t1),
-                         ("greedy_pca_and_glr", t3 - t2), ("local_max_and_sync", t4 - t3)):
+                         ("greedy_pca_and_glr_enqueued", t3 - t2), ("glr_local_max_sync", t4 - t3)):
                 phase[k] = phase.get(k, 0.0) + v
             info["pca_iters"] = drv.iterations
             info["n_nuis_first"] = drv.trace[0][1] if drv.trace else 0

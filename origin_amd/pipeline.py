@@ -134,15 +134,21 @@ def glr_bands_for(active_rows, Ny, halo):
 
 def greedy_pca_then_glr(ctx, plan, cube_std, areamap, nbAreas, thresholds, testO2, mask,
                         correl, profile, correl_min, cube_faint, Noise_population=50, itermax=100,
-                        spx=None, driver=None, o2_dev=None, max_active=2, area_rows=None):
+                        spx=None, driver=None, o2_dev=None, max_active=2, area_rows=None,
+                        local_max=None):
     """greedy PCA and GLR of one field with the GLR of the finished part of the field started in
     the shadow of the PCA's tail: when at most ``max_active`` areas still iterate, the library
     writes the others to ``cube_faint`` and calls back; the row bands whose spatial stage reads
     none of the rows of the areas that go on run at once on the context's side stream (all CUs
     but a reserve the PCA's small kernels keep), the remaining bands behind the PCA on the main
     stream.  Same results as ``greedy_pca`` followed by ``plan.run`` (the bands run the same
-    kernels on the same waves and regions).  Returns (cube_faint, mapO2, nstop, driver, out)
-    with ``out`` as ``plan.run`` returns it, plus ``out["bands"] = (early, late)``."""
+    kernels on the same waves and regions).  ``local_max = (out_max, out_min)``: the 3x3x3 local
+    maxima of correl / correl_min behind the last band (steps.py:796).  (Their row bands on the
+    side stream behind the early GLR bands were built and measured in round 3: 51.98 against
+    51.9-52.1 ms per step -- the pass is HBM-bound and the GLR is not, but their workgroups do not
+    share a CU, so they take turns; dropped.)  Returns (cube_faint, mapO2, nstop, driver, out) with
+    ``out`` as ``plan.run`` returns it, plus ``out["bands"] = (early, late)`` (and ``local_max``
+    / ``local_min``)."""
     Nz, Ny, Nx = cube_std.shape
     spx = area_lists(areamap, nbAreas) if spx is None else spx
     if area_rows is None:
@@ -170,11 +176,18 @@ def greedy_pca_then_glr(ctx, plan, cube_std, areamap, nbAreas, thresholds, testO
     err = ctx.pop_tail_hook_error() if use else None
     if err is not None:
         raise err
+    def finish_local_max(out):
+        if local_max is not None:
+            kernels.local_max(ctx, correl, correl_min, mask, 3, out_max=local_max[0],
+                              out_min=local_max[1])
+            out["local_max"], out["local_min"] = local_max
+        return out
+
     if state["early"] is None:     # the hook did not fire (every area finished together)
         out = plan.run(F, mask=mask, correl=correl, profile=profile, correl_min=correl_min,
                        want_maps=True)
         out["bands"] = ([], [(0, Ny)])
-        return F, mapO2, nstop, drv, out
+        return F, mapO2, nstop, drv, finish_local_max(out)
     first = len(state["early"]) == 0
     for y0, y1 in state["late"]:
         plan.run_rows(F, mask, correl, profile, correl_min, y0, y1, first=first, side=False)
@@ -182,7 +195,7 @@ def greedy_pca_then_glr(ctx, plan, cube_std, areamap, nbAreas, thresholds, testO
     maxmap, minmap = plan.run_finish(want_maps=True)
     out = dict(correl=correl, profile=profile, correl_min=correl_min, maxmap=maxmap,
                minmap=minmap, bands=(state["early"], state["late"]))
-    return F, mapO2, nstop, drv, out
+    return F, mapO2, nstop, drv, finish_local_max(out)
 
 
 def tglr(ctx, plan, cube_faint, mask, size=3, want_local=True):

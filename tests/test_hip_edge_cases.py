@@ -383,10 +383,15 @@ def test_pca_tail_hook_and_the_glr_started_in_its_shadow(ctx, max_active):
     prof_i, faint = ctx.empty(cube.shape, np.uint8), ctx.empty(cube.shape, np.float32)
     for a in (correl, cmin, prof_i, faint):
         a.fill_bytes(0x7f)
+    lm0 = kernels.local_max(ctx, out0["correl"], out0["correl_min"], d_mask, 3)
+    want_lm = [a.to_host() for a in lm0]
+    lmax, lmin = ctx.empty(cube.shape, np.float32), ctx.empty(cube.shape, np.float32)
     F1, map1, nstop1, _, out1 = pipeline.greedy_pca_then_glr(
         ctx, plan, d, areamap, nb, thr, tests, d_mask, correl, prof_i, cmin, faint,
-        max_active=max_active)
+        max_active=max_active, local_max=(lmax, lmin))
     ctx.sync()
+    assert np.array_equal(out1["local_max"].to_host(), want_lm[0])
+    assert np.array_equal(out1["local_min"].to_host(), want_lm[1])
     assert nstop0 == nstop1 and np.array_equal(map0, map1)
     assert np.array_equal(F1.to_host(), F0.to_host())
     for k in want:
