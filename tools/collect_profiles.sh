@@ -8,7 +8,9 @@ tag=${1:-r02}
 out=gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-B="bench.py --steps 5 --warmup 2 --check off --no-cpu-baseline --e2e-size 0"
+# (--no-tail-overlap: the sequential form of the step -- one launch per kernel and step, every kernel
+# alone on the chip; the default form splits the GLR into row bands beside the PCA's tail)
+B="bench.py --steps 5 --warmup 2 --check off --no-cpu-baseline --e2e-size 0 --no-tail-overlap"
 python3 $B > $out/${tag}_bench_default.json 2> $out/${tag}_bench_default.err || exit 1
 rocprofv3 --kernel-trace --stats -f csv -d $out/${tag}_kt -- python3 $B > $out/${tag}_kt.log 2>&1 || exit 2
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $out/${tag}_fetch -- python3 $B > $out/${tag}_fetch.log 2>&1 || exit 3
