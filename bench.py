@@ -159,6 +159,9 @@ def main():
                     help="greedy PCA, then the GLR (rounds 1-2); default: the GLR of the row bands "
                          "that do not depend on the areas still iterating starts in the shadow of "
                          "the PCA's tail (pipeline.greedy_pca_then_glr; one rank only)")
+    ap.add_argument("--tail-early-budget", type=float, default=8.5e8,
+                    help="voxels of GLR handed to the side stream at the tail hook at most (0: all "
+                         "the bands that are ready)")
     ap.add_argument("--tail-max-active", type=int, default=2,
                     help="the tail hook fires when at most this many areas still iterate")
     ap.add_argument("--no-local-max", dest="local_max", action="store_false",
@@ -323,7 +326,8 @@ def main():
                 ctx, plan, cube_std, local_map, nb_local, thr["thresO2"], thr["testO2"], mask,
                 correl, profile, correl_min, cube_faint, 50, 100, spx=spx, driver=pca_driver,
                 o2_dev=pre["o2"], max_active=args.tail_max_active, area_rows=area_rows,
-                local_max=(lmax_buf, lmin_buf) if do_lm else None)
+                local_max=(lmax_buf, lmin_buf) if do_lm else None,
+                early_budget=args.tail_early_budget or None)
             info["glr_bands"] = {"early": out["bands"][0], "late": out["bands"][1]}
             t3 = time.perf_counter()
             ctx.sync()
@@ -349,7 +353,8 @@ def main():
         t3 = time.perf_counter()
         if world > 1:
             out = glr.run(None, mask, correl, profile, correl_min,
-                          local_max=(lmax_buf, lmin_buf) if do_lm else None)
+                          local_max=(lmax_buf, lmin_buf) if do_lm else None,
+                early_budget=args.tail_early_budget or None)
         else:
             out = plan.run(cube_faint, mask=mask, correl=correl, profile=profile,
                            correl_min=correl_min, want_maps=True)
@@ -754,6 +759,14 @@ def main():
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if comm is not None:
         comm.close()
+    # plans and the context go before the interpreter does (origin_amd.device closes contexts at
+    # exit anyway; a context left to the HIP runtime's static destructors aborts the process)
+    for obj in ([glr.plan] if world > 1 else [plan]):
+        try:
+            obj.close()
+        except Exception:
+            pass
+    ctx.close()
 
 
 if __name__ == "__main__":

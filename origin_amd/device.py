@@ -1,5 +1,7 @@
 """Device context and arrays on top of the C ABI (no PyTorch, no numpy-on-GPU library)."""
+import atexit
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -13,6 +15,23 @@ def device_count():
     return n.value
 
 
+# Contexts still open when the interpreter exits are closed from an atexit handler: a context that
+# survives into the HIP runtime's own static destructors (a reference cycle keeps it from __del__)
+# leaves streams behind -- the CU-masked side stream among them -- and the runtime aborts the
+# process there ("std::get: wrong index for variant"), after all the work is done but with a
+# non-zero exit status.
+_live_contexts = weakref.WeakSet()
+
+
+@atexit.register
+def _close_live_contexts():
+    for ctx in list(_live_contexts):
+        try:
+            ctx.close()
+        except Exception:
+            pass
+
+
 class Context:
     """One GPU, one stream (include/origin_hip.h: origin_ctx)."""
 
@@ -20,6 +39,7 @@ class Context:
         self._h = C.c_void_p()
         _capi.call("origin_ctx_create", int(device), C.byref(self._h))
         self.device = int(device)
+        _live_contexts.add(self)
 
     # -- lifetime ----------------------------------------------------------
     def close(self):

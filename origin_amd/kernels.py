@@ -225,7 +225,10 @@ class GLRPlan:
 
     def close(self):
         if self._h is not None and self._h.value:
-            _capi.load().origin_glr_plan_destroy(self._h)
+            # (a plan outliving its context -- interpreter exit closes contexts first -- is not
+            # destroyed through the dangling context pointer it holds: the process is ending)
+            if self.ctx.handle.value:
+                _capi.load().origin_glr_plan_destroy(self._h)
             self._h = C.c_void_p()
         self._work = None
 

@@ -135,7 +135,7 @@ def glr_bands_for(active_rows, Ny, halo):
 def greedy_pca_then_glr(ctx, plan, cube_std, areamap, nbAreas, thresholds, testO2, mask,
                         correl, profile, correl_min, cube_faint, Noise_population=50, itermax=100,
                         spx=None, driver=None, o2_dev=None, max_active=2, area_rows=None,
-                        local_max=None):
+                        local_max=None, early_budget=8.5e8):
     """greedy PCA and GLR of one field with the GLR of the finished part of the field started in
     the shadow of the PCA's tail: when at most ``max_active`` areas still iterate, the library
     writes the others to ``cube_faint`` and calls back; the row bands whose spatial stage reads
@@ -143,7 +143,11 @@ def greedy_pca_then_glr(ctx, plan, cube_std, areamap, nbAreas, thresholds, testO
     but a reserve the PCA's small kernels keep), the remaining bands behind the PCA on the main
     stream.  Same results as ``greedy_pca`` followed by ``plan.run`` (the bands run the same
     kernels on the same waves and regions).  ``local_max = (out_max, out_min)``: the 3x3x3 local
-    maxima of correl / correl_min behind the last band (steps.py:796).  (Their row bands on the
+    maxima of correl / correl_min behind the last band (steps.py:796).  ``early_budget``: voxels
+    of GLR given to the side stream at most (None: every band that is ready).  The PCA's tail
+    is a few milliseconds of mostly idle device; GLR work beyond what fits beside it only keeps
+    the PCA's small kernels on the reserved CUs for longer (3681x900x900: 139.6 ms per step with
+    every ready band early, against 135.1 in sequence; 8.5e8 voxels ~ 12 ms of GLR on an MI355X).  (Their row bands on the
     side stream behind the early GLR bands were built and measured in round 3: 51.98 against
     51.9-52.1 ms per step -- the pass is HBM-bound and the GLR is not, but their workgroups do not
     share a CU, so they take turns; dropped.)  Returns (cube_faint, mapO2, nstop, driver, out) with
@@ -158,6 +162,23 @@ def greedy_pca_then_glr(ctx, plan, cube_std, areamap, nbAreas, thresholds, testO
 
     def hook(areas):
         early, late = glr_bands_for([area_rows[a] for a in areas if area_rows[a]], Ny, halo)
+        if early_budget is not None:   # the largest bands first, cut at multiples of 64 rows
+            rows_left = max(64, int(early_budget / (Nz * Nx)) // 64 * 64)
+            kept, moved, late_in = [], [], late
+            for y0, y1 in sorted(early, key=lambda b: b[0] - b[1]):
+                take = min(y1 - y0, rows_left)
+                take = take if y0 + take == y1 else take // 64 * 64
+                if take > 0:
+                    kept.append((y0, y0 + take))
+                    rows_left -= take
+                if y0 + take < y1:
+                    moved.append((y0 + take, y1))
+            early, late = sorted(kept), []
+            for y0, y1 in sorted(late_in + moved):      # adjacent late bands run as one
+                if late and late[-1][1] == y0:
+                    late[-1] = (late[-1][0], y1)
+                else:
+                    late.append((y0, y1))
         for i, (y0, y1) in enumerate(early):
             plan.run_rows(cube_faint, mask, correl, profile, correl_min, y0, y1, first=(i == 0),
                           side=True)
