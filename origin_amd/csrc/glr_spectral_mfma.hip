@@ -626,14 +626,12 @@ __device__ __forceinline__ void sm_tiles(
         for (int i = 0; i < 8; ++i) {
           const int zu = zh + (i & 3) + 8 * (i >> 2);  // uniform part of the channel
           if (STRAIGHT || zu + 4 * h < zc1) {
-            float b = st.best[i] * inv;
-            float w = st.worst[i] * inv;
+            // (FOLD: the class factor s(z) of the lane's channel times the power of two that
+            // undoes the tile scale -- one product per output instead of two, the same bits)
+            const float f = FOLD ? sg[i >> 2][i & 3] * inv : inv;
+            float b = st.best[i] * f;
+            float w = st.worst[i] * f;
             int kk = 31 - (int)(__float_as_uint(st.key[i]) & 31u);
-            if constexpr (FOLD) {
-              // the class factor s(z) of the lane's channel
-              b *= sg[i >> 2][i & 3];
-              w *= sg[i >> 2][i & 3];
-            }
             // profiles run narrow-first, not in index order: when every T is the same number (a
             // spaxel of zeros) the first maximum is index 0 (np.argmax semantics, lib :1210)
             if (st.best[i] == st.worst[i]) kk = 0;
