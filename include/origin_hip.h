@@ -235,8 +235,9 @@ int origin_pca_run(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, long S
                    double noise_pop, int itermax, int *d_mapO2, int *h_nstop, int *h_iters,
                    long *h_trace, int trace_cap);
 /* Tail hook of the greedy PCA: `hook(user, n_active, areas)` is called ONCE per run, from inside
- * origin_pca_run / origin_pca_run_into on the calling thread, at the first iteration (after the
- * first) at which at most max_active areas still iterate.  Before the call the areas that have
+ * origin_pca_run / origin_pca_run_into on the calling thread, once at most max_active areas have
+ * been iterating for three iterations in a row without their nuisance count falling below 0.6 of
+ * what it was at the first of them (stragglers; a run that is about to end does not call).  Before the call the areas that have
  * finished -- they never iterate again -- are written to d_F (the pass they would have had at the
  * end, on the context's stream); `areas` lists the indices of those that go on.  The caller may
  * enqueue the next stage for everything that does not depend on them (origin_glr_run_rows with

@@ -3034,6 +3034,7 @@ int origin_pca_run_into(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, l
   memcpy(n_lay.data(), h_nnb, 2 * (size_t)na * sizeof(int));
   bool exact = true;
   bool tail_fired = false;
+  int tail_run = 0, tail_n0 = 0;  // iterations in a row with few areas; their nuisance count at the first
   // Default: selection, hand-shake, exact work list, chain.  ORIGIN_PCA_PIPELINED=1 lets the host
   // run one selection ahead (below).  Measured A/B at 3681 x 600 x 600 (57 iterations): 25.7-25.9
   // against 26.0-26.3 ms -- the loop is bound by the device (host: 2 ms of enqueueing, 20 ms of
@@ -3071,8 +3072,23 @@ int origin_pca_run_into(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, l
     // start the next stage on everything that does not depend on them (origin_glr_run_rows on the
     // side stream).  Needs exact counts (the default, non-pipelined loop) and no work cube between
     // the input and d_F.
-    if (ctx->pca_tail_hook && !tail_fired && exact && iters >= 1 && nw <= ctx->pca_tail_max &&
-        !d_work && !full) {
+    // It fires only when the few areas left look like stragglers: three iterations in a row with
+    // at most pca_tail_max areas, whose nuisance count has not fallen below 0.6 of what it was at
+    // the first of them.  (Bench fields, (areas, nuisance spaxels) per iteration: 600^2 ... (3,50)
+    // (2,31) (2,28) (1,24) (1,21) (1,20) and 44 more down to (1,12); 200^2 ... (2,74) (2,58) (1,52)
+    // (1,51) and 34 more; 300^2 ... (7,93) (1,23) (1,13) (1,3), end -- there the run is over
+    // before anything started beside it could pay: 17.5 ms per step with the hook at the first
+    // iteration with one area, 16.3 without it.)
+    int n_active_sum = 0;
+    for (int a = 0; a < na; ++a)
+      if (n_lay[a] >= 2) n_active_sum += n_lay[a];
+    if (nw > 0 && nw <= ctx->pca_tail_max && iters >= 1) {
+      if (tail_run++ == 0) tail_n0 = n_active_sum;
+    } else {
+      tail_run = 0;
+    }
+    if (ctx->pca_tail_hook && !tail_fired && exact && tail_run >= 3 &&
+        10 * (long)n_active_sum >= 6 * (long)tail_n0 && !d_work && !full) {
       tail_fired = true;
       n_done = n_lay.data();
       if ((rc = flush(true, true))) return rc;
