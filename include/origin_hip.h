@@ -328,8 +328,9 @@ int origin_glr_plan_destroy(origin_glr_plan *plan);
  * "bf16 GLR"; |dT| ~1e-2); 0 = fp32 FMA chain (~1e-7).  Eligible: the spatial stage for odd PSF
  * sizes 5..25 (one field, or a mosaic of weighted fields: per-field accumulation); the spectral
  * stage for profile half widths <= 32 and K <= 26 -- through the border-class table without
- * weight maps, through a second Toeplitz product on the plan's norm cube with them (precision 1
- * only; that cube, [Nz + 96][Ny][Nx] float32, is allocated and filled by the plan's first run).
+ * weight maps, through the plan's norm cube with them (that cube, [Nz + 96][Ny][Nx] float32, is
+ * allocated and filled by the plan's first run): the FOLD form where the cube is smooth along z
+ * (origin_glr_plan_fold_eps; precision 1 or 2), else a second Toeplitz product (precision 1 only).
  * A stage that is not eligible runs the fp32 kernels; plans where neither stage is (a field
  * smaller than the PSF without weight maps, longer / more profiles) always report 0.  get
  * returns the plan's setting. */
@@ -348,6 +349,11 @@ int origin_glr_plan_mfma_count(origin_glr_plan *plan, long *spatial, long *spect
  * the stage compares the profiles through accumulators that carry a_k and applies s(z) to the
  * maximum and the minimum (*active = 1): correl and correl_min carry a relative error <= eps, the
  * profile index is that of a maximum up to the same eps.
+ * Plans with weight maps (an explicit norm cube): den_k[z, s] = norm[z, s] sum p_k^2 (1 + e)^2; eps
+ * is measured by the plan's FIRST run on the norm cube it makes (+inf and inactive before), and
+ * where it passes the stage is the same FOLD kernel with rsq(norm) of each voxel behind the loop
+ * instead of a second Toeplitz product (the 32 channels at either end keep the two-product
+ * kernel); bf16 plans included.
  * ORIGIN_GLR_NO_FOLD=1 in the environment runs the exact form everywhere. */
 int origin_glr_plan_fold_eps(origin_glr_plan *plan, float *eps, int *active);
 /* The same arithmetic without a plan or a device (host only: num_cu compute units, `terms` = 3

@@ -64,6 +64,9 @@ struct origin_glr_plan {
   uint4 *d_atab_fold, *d_atab_bf16_fold;
   float *d_rden_fold, *d_sden;
   float fold_eps;
+  // mode 1 (explicit norm cube): 1 once the first run has measured eps on the norm cube (then
+  // fold_eps holds it) -- NORMW runs where it is <= MF_FOLD_EPS
+  int normw_checked;
   std::vector<int> *h_order;  // processing order on the host (plan creation only)
   int precision;   // 0 = fp32 FMA kernels, 1 = split-f16 MFMA stages, 2 = bf16 MFMA stages
   float *d_normc;  // mode 1: norm_fsf [Nz][Ny][Nx], a constant of the plan (PSFs and weight maps
@@ -327,6 +330,66 @@ __global__ __launch_bounds__(256) void norm_classes_kernel(const float *__restri
   for (int dy = dy0; dy <= dy1; ++dy)
     for (int dx = dx0; dx <= dx1; ++dx) acc += (double)kz[dy * P + dx];
   ncls[i] = acc;
+}
+
+// eps of the FOLD form on an explicit norm cube (NORMW): over every voxel of the channels
+// [zf0, zf1) and every profile, |sqrt(den_k / (norm sum_j p_k[j]^2)) - 1| with den_k the true
+// smoothed norm (lib_origin.py:1055: conv of norm_fsf with p_k^2); a spaxel no field covers has
+// norm = 0 and den = 0 in both forms.  norm: channel 0 of the padded cube.  A thread takes
+// NE_ZT consecutive channels of one spaxel (their common window in registers), the squared taps
+// sit in LDS as dense 65-slot rows (slot u = channel offset u - 32); float bits through atomicMax
+// (values >= 0).  Runs once per plan, in its first run: ~0.1 s at 3681 x 600 x 600.
+constexpr int NE_ZT = 4;
+__global__ __launch_bounds__(256) void normw_eps_kernel(const float *__restrict__ norm,
+                                                        const float *__restrict__ taps2,
+                                                        const int *__restrict__ tap_off, int K,
+                                                        long S, int zf0, int zf1,
+                                                        unsigned *__restrict__ eps_bits) {
+  __shared__ float tt[MF_MAX_K][65];
+  __shared__ float ts2[MF_MAX_K];
+  for (int i = threadIdx.x; i < K * 65; i += 256) {
+    const int k = i / 65, u = i - 65 * k;
+    const int o = tap_off[k], L = tap_off[k + 1] - o, lw = (L - 1) / 2;
+    const int j = 32 + lw - u;  // window slot u = channel z - 32 + u = z + lw - j
+    tt[k][u] = (j >= 0 && j < L) ? taps2[o + j] : 0.0f;
+  }
+  __syncthreads();
+  if (threadIdx.x < K) {
+    float a = 0.0f;
+    for (int u = 0; u < 65; ++u) a += tt[threadIdx.x][u];
+    ts2[threadIdx.x] = a;
+  }
+  __syncthreads();
+  const long sp = (long)blockIdx.x * 256 + threadIdx.x;
+  const int z = zf0 + NE_ZT * (int)blockIdx.y;
+  float eps = 0.0f;
+  if (sp < S) {
+    float w[64 + NE_ZT];  // channels z - 32 .. z + NE_ZT + 31 (the pads of the cube cover the ends)
+#pragma unroll
+    for (int j = 0; j < 64 + NE_ZT; ++j) w[j] = norm[(long)(z - 32 + j) * S + sp];
+    for (int k = 0; k < K; ++k) {
+      float den[NE_ZT];
+#pragma unroll
+      for (int c = 0; c < NE_ZT; ++c) den[c] = 0.0f;
+#pragma unroll
+      for (int u = 0; u < 65; ++u) {
+        const float t = tt[k][u];
+#pragma unroll
+        for (int c = 0; c < NE_ZT; ++c) den[c] += t * w[u + c];
+      }
+#pragma unroll
+      for (int c = 0; c < NE_ZT; ++c) {
+        if (z + c >= zf1) continue;
+        const float ref = w[32 + c] * ts2[k];
+        const float e = ref > 0.0f ? fabsf(sqrtf(den[c] / ref) - 1.0f)
+                                   : (den[c] > 0.0f ? INFINITY : 0.0f);
+        eps = fmaxf(eps, e);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) eps = fmaxf(eps, __shfl_xor(eps, o));
+  if ((threadIdx.x & 63) == 0 && eps > 0.0f) atomicMax(eps_bits, __float_as_uint(eps));
 }
 
 // FOLD tables of the matrix-core spectral stage (glr_spectral_mfma.hip): rden_fold = rden / a_k,
@@ -1018,9 +1081,10 @@ int origin_glr_plan_create(origin_ctx *ctx, int Nz, int Ny, int Nx, int nfields,
     std::vector<_Float16> at((size_t)K * MF_PROF_BYTES / 2, (_Float16)0.0f);
     std::vector<_Float16> at2(pl->mode == 1 ? at.size() : 0, (_Float16)0.0f);
     std::vector<unsigned short> ab((size_t)K * MF_PROF_BYTES / 2, 0);
-    // FOLD: the same tables with the taps times a_k = 1/sqrt(sum p_k^2) (mode 0 only)
-    std::vector<_Float16> atf(pl->mode == 0 ? at.size() : 0, (_Float16)0.0f);
-    std::vector<unsigned short> abf(pl->mode == 0 ? ab.size() : 0, 0);
+    // FOLD: the same tables with the taps times a_k = 1/sqrt(sum p_k^2) (plans with an explicit
+    // norm cube use them too: NORMW, glr_spectral_mfma.hip)
+    std::vector<_Float16> atf(mf_fold_fits(K) ? at.size() : 0, (_Float16)0.0f);
+    std::vector<unsigned short> abf(mf_fold_fits(K) ? ab.size() : 0, 0);
     fold_a.assign(K, 1.0);
     for (int kk = 0; kk < K; ++kk) {
       double s2 = 0.0;
@@ -1228,7 +1292,11 @@ int origin_glr_plan_get_precision(origin_glr_plan *plan, int *precision) {
 int origin_glr_plan_fold_eps(origin_glr_plan *plan, float *eps, int *active) {
   ORIGIN_CHECK_ARG(plan && eps && active, "null argument");
   *eps = plan->fold_eps;
-  *active = plan->d_rden_fold != nullptr && !getenv("ORIGIN_GLR_NO_FOLD");
+  // (a plan with a norm cube measures eps in its first run: +inf and inactive before that)
+  *active = (plan->mode == 0 ? plan->d_rden_fold != nullptr
+                             : plan->normw_checked && plan->d_atab_fold != nullptr &&
+                                   plan->fold_eps <= MF_FOLD_EPS) &&
+            !getenv("ORIGIN_GLR_NO_FOLD");
   return ORIGIN_OK;
 }
 
@@ -1437,6 +1505,26 @@ int origin_glr_run(origin_ctx *ctx, origin_glr_plan *pl, const float *d_cube,
     }
   }
   if (pl->mode == 1) pl->normc_ready = 1;
+  // NORMW: the first run measures eps of the FOLD form on the norm cube it has just made
+  if (pl->mode == 1 && !pl->normw_checked && pl->d_atab_fold) {
+    pl->normw_checked = 1;
+    pl->fold_eps = INFINITY;
+    int zf0, zf1;
+    mf_fold_range(Nz, &zf0, &zf1);
+    if (zf1 > zf0 && pl->lwmax <= 32) {
+      void *scr = nullptr;
+      if (int rc = origin_scratch(ctx, 256, &scr)) return rc;
+      unsigned *d_eps = (unsigned *)scr, bits = 0x7f800000u;
+      ORIGIN_HIP(hipMemsetAsync(d_eps, 0, sizeof(unsigned), ctx->stream));
+      hipLaunchKernelGGL(normw_eps_kernel,
+                         dim3((unsigned)cdiv(S, 256), (unsigned)cdiv(zf1 - zf0, NE_ZT)), dim3(256), 0,
+                         ctx->stream, norm, pl->d_taps2, pl->d_tap_off, K, S, zf0, zf1, d_eps);
+      ORIGIN_LAUNCH_CHECK();
+      ORIGIN_HIP(hipMemcpyAsync(&bits, d_eps, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+      ORIGIN_HIP(hipStreamSynchronize(ctx->stream));
+      memcpy(&pl->fold_eps, &bits, sizeof(float));
+    }
+  }
   ORIGIN_LAUNCH_CHECK();
 
   // ---- spectral stage
@@ -1463,7 +1551,33 @@ int origin_glr_run(origin_ctx *ctx, origin_glr_plan *pl, const float *d_cube,
   const bool mfma_norm = gen && pl->precision == 1 && pl->d_atab && pl->d_atab2 &&
                          K <= origin_spectral_norm_mfma_max_k();
   const bool packed = !mfma && !gen && (S & 1) == 0 && pl->lwt;
-  if (mfma_norm) {
+  // NORMW: the FOLD form of the table kernel on the norm cube where the plan's eps allows it, the
+  // two-product kernel for the 32 channels at either end of the cube
+  int zf0 = 0, zf1 = 0;
+  mf_fold_range(Nz, &zf0, &zf1);
+  const int end_rows = cdiv(zf0, 32) + cdiv(Nz - zf1, 32);
+  // (bf16 plans too: one bf16 MFMA per product between the ends, the ends on the f16 split)
+  const bool norm_tables = gen && pl->precision >= 1 && pl->d_atab && pl->d_atab2 &&
+                           K <= origin_spectral_norm_mfma_max_k();
+  const bool normw = norm_tables && pl->normw_checked && pl->fold_eps <= MF_FOLD_EPS &&
+                     pl->d_atab_fold && zf1 > zf0 && !getenv("ORIGIN_GLR_NO_FOLD") &&
+                     origin_spectral_mfma_chunks(ctx->num_cu, Nz, Ny, Nx) + end_rows <= 64;
+  if (normw) {
+    const int rows = origin_spectral_mfma_chunks(ctx->num_cu, Nz, Ny, Nx) + end_rows;
+    const bool b16 = pl->precision == 2;
+    int rc = origin_spectral_mfma_launch(
+        ctx, b16 ? 1 : 3, fsf, nullptr, nullptr, pl->NzP, b16 ? pl->d_atab_bf16 : pl->d_atab,
+        pl->d_pwide, K, pl->n_narrow, Nz, Ny, Nx, P, d_mask, d_correl, d_profile, d_correl_min, part,
+        want_maps, &nzc, &pmax, &pmin, b16 ? pl->d_atab_bf16_fold : pl->d_atab_fold, nullptr,
+        nullptr, pl->order_ident, 0, 0, norm, rows);
+    if (rc) return rc;
+    int got = 0;
+    rc = origin_spectral_norm_mfma_launch_ends(ctx, fsf, norm, pl->d_atab, pl->d_atab2, pl->d_pwide, K,
+                                               Nz, Ny, Nx, d_mask, d_correl, d_profile,
+                                               d_correl_min, pmax, pmin, zf0, zf1, nzc, &got);
+    if (rc) return rc;
+    nzc += got;
+  } else if (mfma_norm) {
     int rc = origin_spectral_norm_mfma_launch(ctx, fsf, norm, pl->d_atab, pl->d_atab2, pl->d_pwide, K,
                                               Nz, Ny, Nx, d_mask, d_correl, d_profile, d_correl_min,
                                               part, want_maps, &nzc, &pmax, &pmin);

@@ -247,13 +247,16 @@ __device__ __forceinline__ void sm_drain(const f32x16 &pacc, const f32x4v (&pfa)
 // run-time test inside the loop: with a test the two kinds of pointer merge into flat loads.
 // PODD: the number of profile pairs is odd (the two accumulators alternate per pair; the pair
 // loop is unrolled by two, and an odd count leaves one stage behind it).
-template <int TERMS, bool BW, bool PODD, bool FOLD, bool IDENT = false>
+template <int TERMS, bool BW, bool PODD, bool FOLD, bool IDENT = false, bool NORMW = false>
 __device__ __forceinline__ void sm_tiles(
     const float *__restrict__ sdl, const float *__restrict__ fsf, const float *__restrict__ rdb, const float *__restrict__ rdi_s,
     int NzP, const int *__restrict__ pinfo, int K, int NP, int Nz, long S, long s_base, int rr,
     bool sv, bool all_valid, int h, int lane, const char *a_lane, char *rd_wave, int zc0, int zc1,
     const uint8_t *__restrict__ mask, float *__restrict__ correl, uint8_t *__restrict__ profile,
     float *__restrict__ correl_min, float &vmax, float &vmin, int nN, char *stage = nullptr) {
+  // (NORMW, with FOLD: plans with an explicit norm cube -- weighted mosaics.  sdl is that cube
+  // (channel 0): den_k[z, s] = a_k^-2 norm[z, s] (1 + eps)^-2 away from the cube's ends, so the
+  // factor behind the loop is rsq(norm) of the lane's own voxels instead of a class table's.)
   // (IDENT: the processing order is the caller's order -- slot = index, wide from slot nN on: no
   // look-up per pair, and with no scalar load outstanding the waits for LDS are counted ones)
   // (stage: FOLD, the wave's 16 staging rows of 256 bytes in LDS)
@@ -531,7 +534,17 @@ __device__ __forceinline__ void sm_tiles(
       // FOLD: s(z) of the lane's border class for its eight channels (two 16-byte loads, requested
       // in front of the pairs like the mask bytes; zero beyond Nz like the 1/sqrt(den) table)
       f32x4v sg[2] = {(f32x4v){0.f, 0.f, 0.f, 0.f}, (f32x4v){0.f, 0.f, 0.f, 0.f}};
-      if constexpr (FOLD) {
+      if constexpr (FOLD && NORMW) {
+        // norm[z, s] at the lane's eight outputs (the addresses of its stores)
+        const float *qp = sdl + (long)zh * S + s_base;
+        unsigned on4 = off_out4;
+        SM_PIN(on4);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          sg[i >> 2][i & 3] = ldf(qp, on4);
+          qp += (i & 3) == 3 ? 5 * S : S;
+        }
+      } else if constexpr (FOLD) {
 #pragma unroll
         for (int g = 0; g < 2; ++g) sg[g] = *reinterpret_cast<const f32x4v *>(sdl + zh + 8 * g);
       }
@@ -628,7 +641,13 @@ __device__ __forceinline__ void sm_tiles(
           if (STRAIGHT || zu + 4 * h < zc1) {
             // (FOLD: the class factor s(z) of the lane's channel times the power of two that
             // undoes the tile scale -- one product per output instead of two, the same bits)
-            const float f = FOLD ? sg[i >> 2][i & 3] * inv : inv;
+            float f = inv;
+            if constexpr (FOLD && NORMW) {  // (norm <= 0: no field covers the spaxel, T = 0)
+              const float nv = sg[i >> 2][i & 3];
+              f = nv > 0.0f ? __builtin_amdgcn_rsqf(nv) * inv : 0.0f;
+            } else if constexpr (FOLD) {
+              f = sg[i >> 2][i & 3] * inv;
+            }
             float b = st.best[i] * f;
             float w = st.worst[i] * f;
             int kk = 31 - (int)(__float_as_uint(st.key[i]) & 31u);
@@ -654,7 +673,9 @@ __device__ __forceinline__ void sm_tiles(
   }
 }
 
-// VARIANT bit 0: odd number of profile pairs; bit 2 (with FOLD): IDENT; bit 1: FOLD -- atab holds the taps times a_k, rden
+// VARIANT bit 0: odd number of profile pairs; bit 2 (with FOLD): IDENT; bit 3 (with FOLD): NORMW,
+// sden is the plan's norm cube and the tiles outside [zf0, zf1) are left to
+// glr_spectral_norm_mfma.hip; bit 1: FOLD -- atab holds the taps times a_k, rden
 // the table 1/(a_k sqrt(den)), sden the class factors s; tiles in [zf0, zf1) (multiples of 32)
 // run the FOLD pair loop, the tiles at the cube's ends the exact one (with each lane reading its
 // own class from global memory, interior or not: the block's LDS holds no 1/sqrt(den) table).
@@ -707,16 +728,17 @@ __global__ __launch_bounds__(64 * MF_WAVES, 1) void spectral_mfma2_kernel(
   constexpr bool PODD = (VARIANT & 1) != 0;  // odd number of profile pairs
   constexpr bool FOLD = (VARIANT & 2) != 0;
   constexpr bool IDENT = (VARIANT & 4) != 0;
+  constexpr bool NORMW = (VARIANT & 8) != 0;
   if constexpr (FOLD) {
-    const float *sdl = sden + (long)cls * NzP + 4 * h;
+    const float *sdl = NORMW ? sden : sden + (long)cls * NzP + 4 * h;
     const int f0 = max(zc0, zf0), f1 = min(zc1, zf1);
     if (f0 < f1)
-      sm_tiles<TERMS, false, PODD, true, IDENT>(sdl, fsf, rdb, rden + (long)ccls * K * NzP, NzP, pinfo, K,
+      sm_tiles<TERMS, false, PODD, true, IDENT, NORMW>(sdl, fsf, rdb, rden + (long)ccls * K * NzP, NzP, pinfo, K,
                                          NP, Nz, S, s_base, rr, sv, all_valid, h, lane, a_lane,
                                          rd_wave, f0, f1, mask, correl, profile, correl_min, vmax,
                                          vmin, nN,
                                          sm_lds + Kp * MF_PROF_BYTES + wv * MF_STAGE_BYTES);
-    for (int e = 0; e < 2; ++e) {  // the chunk's tiles in front of / behind the FOLD range
+    for (int e = 0; e < (NORMW ? 0 : 2); ++e) {  // the chunk's tiles in front of / behind the FOLD range
       const int a = e ? max(zc0, zf1) : zc0, b = e ? zc1 : min(zc1, zf0);
       if (a < b)
         sm_tiles<TERMS, true, PODD, false>(nullptr, fsf, rdb, rdi_s, NzP, pinfo, K, NP, Nz, S,
@@ -806,7 +828,8 @@ int origin_spectral_mfma_launch(origin_ctx *ctx, int terms, const float *fsf, co
                                 float *correl, uint8_t *profile, float *correl_min, float *part,
                                 bool want_maps, int *nzc_out, float **pmax_out, float **pmin_out,
                                 const uint4 *atab_fold, const float *rden_fold, const float *sden,
-                                int ident, long s_first, long s_count) {
+                                int ident, long s_first, long s_count, const float *normc,
+                                int part_rows) {
   const long S = (long)Ny * Nx;
   long bx;
   int nzm, zcm;
@@ -820,8 +843,9 @@ int origin_spectral_mfma_launch(origin_ctx *ctx, int terms, const float *fsf, co
   }
   bx = cdiv(s_count, 32 * MF_WAVES);
   long s_end = s_first + s_count;
+  // (part_rows: rows of each partial map when other launches add theirs behind this one's)
   float *pmax = want_maps ? part : nullptr;
-  float *pmin = want_maps ? part + (size_t)nzm * S : nullptr;
+  float *pmin = want_maps ? part + (size_t)std::max(nzm, part_rows) * S : nullptr;
   const int Kp = K + (K & 1);
   // (+ one profile of slack: the last stage requests the fragments of a pair that is not there)
   const size_t lds = std::max((size_t)Kp * MF_PROF_BYTES + (size_t)K * MF_WAVES * MF_RD_BYTES,
@@ -829,18 +853,20 @@ int origin_spectral_mfma_launch(origin_ctx *ctx, int terms, const float *fsf, co
   // pairs of slots (2p, 2p+1); an odd last profile pairs with itself
   const int NP = (K + 1) / 2;
   auto pick = [&](int fold) -> const void * {
-    const int variant = (NP & 1) | (fold << 1) | ((fold && ident) << 2);
+    const int variant = (NP & 1) | (fold << 1) | ((fold && ident) << 2) | ((fold && normc) << 3);
 #define SM_PICK(T, V) \
   if (terms == T && variant == V) return (const void *)spectral_mfma2_kernel<T, V>
     SM_PICK(3, 0); SM_PICK(3, 1); SM_PICK(3, 2); SM_PICK(3, 3); SM_PICK(3, 6); SM_PICK(3, 7);
     SM_PICK(1, 0); SM_PICK(1, 1); SM_PICK(1, 2); SM_PICK(1, 3); SM_PICK(1, 6); SM_PICK(1, 7);
+    SM_PICK(3, 10); SM_PICK(3, 11); SM_PICK(3, 14); SM_PICK(3, 15);
+    SM_PICK(1, 10); SM_PICK(1, 11); SM_PICK(1, 14); SM_PICK(1, 15);
 #undef SM_PICK
     return nullptr;
   };
   // FOLD for the tiles whose profile supports lie inside the cube (plans whose eps test passed
   // bring the folded tables), the exact form for the tiles at the ends
   int zf0 = 0, zf1 = 0;
-  if (atab_fold && rden_fold && sden && !getenv("ORIGIN_GLR_NO_FOLD")) {
+  if (atab_fold && ((rden_fold && sden) || normc) && !getenv("ORIGIN_GLR_NO_FOLD")) {
     mf_fold_range(Nz, &zf0, &zf1);
   }
   // (LDS: the tap copies and the staging rows -- K <= 24 with twelve waves)
@@ -856,6 +882,11 @@ int origin_spectral_mfma_launch(origin_ctx *ctx, int terms, const float *fsf, co
                                  MF_MAX_K * (MF_PROF_BYTES + MF_WAVES * MF_RD_BYTES)));
   const uint4 *a_atab = fold ? atab_fold : atab;
   const float *a_rden = fold ? rden_fold : rden;
+  if (fold && normc) sden = normc;  // (NORMW: the kernel's sden argument is the norm cube)
+  if (normc && !fold) {
+    origin_set_error("spectral MFMA kernel: the norm-cube form needs the FOLD range");
+    return ORIGIN_E_STATE;
+  }
   int a_NP = NP, a_zcm = zcm;
   void *args[] = {&fsf, &a_rden, &rdi_s, &NzP, &a_atab, &pinfo, &K, &a_NP, &Nz, &Ny, &Nx, &P, &a_zcm,
                   &mask, &correl, &profile, &correl_min, &pmax, &pmin, &sden, &zf0, &zf1, &nN, &s_first, &s_end};

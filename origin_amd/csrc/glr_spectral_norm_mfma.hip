@@ -20,6 +20,13 @@
 // its arg-max key and compares keys).  Mask glue and the per-chunk maxima / minima of the maps
 // belong to the last launch.
 //
+// Round 3: where the norm cube is smooth along z -- den_k[z, s] = norm[z, s] sum_j p_k[j]^2 up to
+// a relative eps the plan measures in its first run -- the table kernel's FOLD form takes over
+// between the cube's ends (glr_spectral_mfma.hip, NORMW: one Toeplitz product, rsq(norm) of each
+// voxel behind the profile loop; 28.6 -> 10.4 ms for two fields at 3681 x 600 x 600) and this
+// kernel keeps the 32 channels at either end (origin_spectral_norm_mfma_launch_ends) and the plans
+// whose eps is too large.
+//
 // This is the straightforward form: no software pipelining of the epilogue under the next pair's
 // MFMAs, the whole 96-channel window of both cubes converted per tile, two waves per SIMD.  It
 // replaces an fp32 kernel that took 110 ms for two fields at 3681 x 600 x 600.
@@ -126,7 +133,10 @@ __global__ __launch_bounds__(64 * NW, 1) void spectral_norm_mfma_kernel(
     const uint4 *__restrict__ atab2, const int *__restrict__ pinfo, int K, int Nz, int Ny, int Nx,
     int zchunk, const uint8_t *__restrict__ mask, float *__restrict__ correl,
     uint8_t *__restrict__ profile, float *__restrict__ correl_min, float *__restrict__ part_max,
-    float *__restrict__ part_min) {
+    float *__restrict__ part_min, int zstart, int zstop, int prow0) {
+  // (zstart, zstop: the channels of this launch, chunk c = [zstart + c zchunk, ...); prow0: row of
+  // the partial maps that chunk 0 writes -- the FOLD form of the table kernel leaves the 32
+  // channels at either end of the cube to this kernel)
   extern __shared__ __align__(16) char nm_lds[];
   {
     const int nvec = K * (MF_PROF_BYTES / 16);
@@ -142,7 +152,7 @@ __global__ __launch_bounds__(64 * NW, 1) void spectral_norm_mfma_kernel(
   const int r = lane & 31, h = lane >> 5;
   const long s_base = ((long)blockIdx.x * NW + wv) * 32;
   if (s_base >= S) return;  // whole wave; no barrier follows
-  const int zc0 = blockIdx.y * zchunk, zc1 = min(Nz, zc0 + zchunk);
+  const int zc0 = zstart + blockIdx.y * zchunk, zc1 = min(zstop, zc0 + zchunk);
   const int E0 = 8 * h - (r & 15) + 31;
   const char *a_lane = nm_lds + (E0 & 7) * MF_COPY_BYTES + (E0 >> 3) * 16;
   const char *a2_lane = a_lane + K * MF_PROF_BYTES;
@@ -286,13 +296,57 @@ __global__ __launch_bounds__(64 * NW, 1) void spectral_norm_mfma_kernel(
     const float a = fmaxf(vmax, __shfl_xor(vmax, 32));
     const float b = fminf(vmin, __shfl_xor(vmin, 32));
     if (h == 0 && sv) {
-      part_max[(long)blockIdx.y * S + sc] = a;
-      part_min[(long)blockIdx.y * S + sc] = b;
+      part_max[(long)(prow0 + blockIdx.y) * S + sc] = a;
+      part_min[(long)(prow0 + blockIdx.y) * S + sc] = b;
     }
   }
 }
 
 }  // namespace
+
+// the launches over the halves of the profile list for the channels [zstart, zstop) in chunks of
+// zcm (grid.y = nchunks); partial maps from row prow0 on
+static int nm_passes(origin_ctx *ctx, const float *fsf, const float *norm, const uint4 *atab,
+                     const uint4 *atab2, const int *pinfo, int K, int Nz, int Ny, int Nx,
+                     const uint8_t *mask, float *correl, uint8_t *profile, float *correl_min,
+                     float *pmax, float *pmin, long bx, int nchunks, int zcm, int zstart, int zstop,
+                     int prow0) {
+  if (K > 2 * NM_MAX_K) {
+    origin_set_error("spectral norm MFMA kernel: %d profiles (at most %d)", K, 2 * NM_MAX_K);
+    return ORIGIN_E_ARG;
+  }
+  const int npass = K > NM_MAX_K ? 2 : 1;
+  const int K0 = npass == 2 ? (K / 2 + 1) / 2 * 2 : K;  // an even count first: whole pairs
+  static bool attr_done = false;
+  if (!attr_done) {
+    const int dyn = NM_MAX_K * 2 * MF_PROF_BYTES;
+    ORIGIN_HIP(hipFuncSetAttribute((const void *)spectral_norm_mfma_kernel<false>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
+    ORIGIN_HIP(hipFuncSetAttribute((const void *)spectral_norm_mfma_kernel<true>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
+    attr_done = true;
+  }
+  for (int pass = 0; pass < npass; ++pass) {
+    const int s0 = pass == 0 ? 0 : K0, Kl = pass == 0 ? K0 : K - K0;
+    const bool last = pass == npass - 1;
+    const size_t lds = (size_t)Kl * 2 * MF_PROF_BYTES;
+    const uint4 *ta = atab + (size_t)s0 * (MF_PROF_BYTES / 16);
+    const uint4 *tb = atab2 + (size_t)s0 * (MF_PROF_BYTES / 16);
+    const uint8_t *mk = last ? mask : nullptr;
+    float *qmax = last ? pmax : nullptr, *qmin = last ? pmin : nullptr;
+    dim3 grid((unsigned)bx, nchunks), block(64 * NW);
+    if (pass == 0)
+      hipLaunchKernelGGL(spectral_norm_mfma_kernel<false>, grid, block, lds, ctx->stream, fsf, norm,
+                         ta, tb, pinfo + s0, Kl, Nz, Ny, Nx, zcm, mk, correl, profile, correl_min,
+                         qmax, qmin, zstart, zstop, prow0);
+    else
+      hipLaunchKernelGGL(spectral_norm_mfma_kernel<true>, grid, block, lds, ctx->stream, fsf, norm,
+                         ta, tb, pinfo + s0, Kl, Nz, Ny, Nx, zcm, mk, correl, profile, correl_min,
+                         qmax, qmin, zstart, zstop, prow0);
+    ORIGIN_LAUNCH_CHECK();
+  }
+  return ORIGIN_OK;
+}
 
 int origin_spectral_norm_mfma_max_k() { return 2 * NM_MAX_K; }
 
@@ -321,42 +375,41 @@ int origin_spectral_norm_mfma_launch(origin_ctx *ctx, const float *fsf, const fl
   nzm = cdiv(Nz, zcm);
   float *pmax = want_maps ? part : nullptr;
   float *pmin = want_maps ? part + (size_t)nzm * S : nullptr;
-  if (K > 2 * NM_MAX_K) {
-    origin_set_error("spectral norm MFMA kernel: %d profiles (at most %d)", K, 2 * NM_MAX_K);
-    return ORIGIN_E_ARG;
-  }
-  const int npass = K > NM_MAX_K ? 2 : 1;
-  const int K0 = npass == 2 ? (K / 2 + 1) / 2 * 2 : K;  // an even count first: whole pairs
-  static bool attr_done = false;
-  if (!attr_done) {
-    const int dyn = NM_MAX_K * 2 * MF_PROF_BYTES;
-    ORIGIN_HIP(hipFuncSetAttribute((const void *)spectral_norm_mfma_kernel<false>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
-    ORIGIN_HIP(hipFuncSetAttribute((const void *)spectral_norm_mfma_kernel<true>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
-    attr_done = true;
-  }
-  for (int pass = 0; pass < npass; ++pass) {
-    const int s0 = pass == 0 ? 0 : K0, Kl = pass == 0 ? K0 : K - K0;
-    const bool last = pass == npass - 1;
-    const size_t lds = (size_t)Kl * 2 * MF_PROF_BYTES;
-    const uint4 *ta = atab + (size_t)s0 * (MF_PROF_BYTES / 16);
-    const uint4 *tb = atab2 + (size_t)s0 * (MF_PROF_BYTES / 16);
-    const uint8_t *mk = last ? mask : nullptr;
-    float *qmax = last ? pmax : nullptr, *qmin = last ? pmin : nullptr;
-    dim3 grid((unsigned)bx, nzm), block(64 * NW);
-    if (pass == 0)
-      hipLaunchKernelGGL(spectral_norm_mfma_kernel<false>, grid, block, lds, ctx->stream, fsf, norm,
-                         ta, tb, pinfo + s0, Kl, Nz, Ny, Nx, zcm, mk, correl, profile, correl_min,
-                         qmax, qmin);
-    else
-      hipLaunchKernelGGL(spectral_norm_mfma_kernel<true>, grid, block, lds, ctx->stream, fsf, norm,
-                         ta, tb, pinfo + s0, Kl, Nz, Ny, Nx, zcm, mk, correl, profile, correl_min,
-                         qmax, qmin);
-    ORIGIN_LAUNCH_CHECK();
-  }
+  int rc = nm_passes(ctx, fsf, norm, atab, atab2, pinfo, K, Nz, Ny, Nx, mask, correl, profile,
+                     correl_min, pmax, pmin, bx, nzm, zcm, 0, Nz, 0);
+  if (rc) return rc;
   *nzc_out = nzm;
   *pmax_out = pmax;
   *pmin_out = pmin;
+  return ORIGIN_OK;
+}
+
+// The 32-channel tiles at either end of the cube only -- [0, zf0) and [zf1, Nz) -- for plans whose
+// other channels run the FOLD form of the table kernel (glr_spectral_mfma.hip, NORMW).  Partial
+// maps go to rows prow0 (front) and prow0 + 1 .. (back, chunks of 32).
+int origin_spectral_norm_mfma_launch_ends(origin_ctx *ctx, const float *fsf, const float *norm,
+                                          const uint4 *atab, const uint4 *atab2, const int *pinfo,
+                                          int K, int Nz, int Ny, int Nx, const uint8_t *mask,
+                                          float *correl, uint8_t *profile, float *correl_min,
+                                          float *pmax, float *pmin, int zf0, int zf1, int prow0,
+                                          int *rows_out) {
+  const long S = (long)Ny * Nx;
+  const long bx = cdiv(S, 32 * NW);
+  int rows = 0;
+  if (zf0 > 0) {
+    const int n = cdiv(zf0, 32);
+    int rc = nm_passes(ctx, fsf, norm, atab, atab2, pinfo, K, Nz, Ny, Nx, mask, correl, profile,
+                       correl_min, pmax, pmin, bx, n, 32, 0, zf0, prow0);
+    if (rc) return rc;
+    rows += n;
+  }
+  if (zf1 < Nz) {
+    const int n = cdiv(Nz - zf1, 32);
+    int rc = nm_passes(ctx, fsf, norm, atab, atab2, pinfo, K, Nz, Ny, Nx, mask, correl, profile,
+                       correl_min, pmax, pmin, bx, n, 32, zf1, Nz, prow0 + rows);
+    if (rc) return rc;
+    rows += n;
+  }
+  *rows_out = rows;
   return ORIGIN_OK;
 }

@@ -46,7 +46,15 @@ int origin_spectral_mfma_launch(origin_ctx *ctx, int terms, const float *fsf, co
                                 uint8_t *profile, float *correl_min, float *part, bool want_maps,
                                 int *nzc_out, float **pmax_out, float **pmin_out,
                                 const uint4 *atab_fold, const float *rden_fold, const float *sden,
-                                int ident, long s_first = 0, long s_count = 0);
+                                int ident, long s_first = 0, long s_count = 0,
+                                const float *normc = nullptr, int part_rows = 0);
+// glr_spectral_norm_mfma.hip: the end tiles [0, zf0) and [zf1, Nz) of a plan with a norm cube
+int origin_spectral_norm_mfma_launch_ends(origin_ctx *ctx, const float *fsf, const float *norm,
+                                          const uint4 *atab, const uint4 *atab2, const int *pinfo,
+                                          int K, int Nz, int Ny, int Nx, const uint8_t *mask,
+                                          float *correl, uint8_t *profile, float *correl_min,
+                                          float *pmax, float *pmin, int zf0, int zf1, int prow0,
+                                          int *rows_out);
 
 long origin_spectral_mfma_count(int num_cu, int terms, int K, int n_narrow, int Nz, int Ny,
                                 int Nx);

@@ -415,6 +415,71 @@ def test_glr_weighted_fields_on_matrix_cores(ctx, shape, P, nf, nprof):
     assert np.max(np.abs(got["f16x2"] - got["f32"])) <= 1e-4
 
 
+@pytest.mark.parametrize("precision", ["f16x2", "bf16"])
+def test_glr_weighted_fields_fold_form_on_the_norm_cube(ctx, monkeypatch, precision):
+    """NORMW: a mosaic whose PSFs vary smoothly with the channel.  den_k[z, s] is the plan's norm
+    cube smoothed by p_k^2, = norm[z, s] sum p_k^2 (1 + eps)^2 away from the cube's ends; the first
+    run measures eps over every voxel and profile, and where it is <= 2e-6 the spectral stage is
+    the FOLD form of the table kernel with rsq(norm) of each voxel behind the profile loop -- one
+    Toeplitz product instead of two, one launch instead of two -- and the two-product kernel only
+    for the 32 channels at either end.  Checked: eps and `active` as the plan reports them, the
+    form against the two-product form of the same plan (ORIGIN_GLR_NO_FOLD=1) within eps, both
+    against the float64 oracle, maps, a corner no field covers (T = 0), a second run bit for bit
+    the first.  bf16 plans take the same road (one bf16 MFMA per product between the ends, the
+    ends on the f16 split): bf16 bounds."""
+    from scipy.ndimage import maximum_filter1d
+    from origin_amd import kernels
+    rng = np.random.default_rng(41)
+    Nz, Ny, Nx, P = 330, 40, 70, 9
+    cube = rng.standard_normal((Nz, Ny, Nx)).astype(np.float32)
+    cube[150:190] *= 23.0
+    x = np.linspace(0, 1, Nx)[None, :] * np.ones((Ny, 1))
+    raww = [0.3 + x, 1.1 - x]
+    tot = sum(raww)
+    psfs = [synth.moffat_psf(3681, P, fwhm0=3.6 - 0.3 * f, fwhm1=3.0 + 0.2 * f)[:Nz].astype(np.float64)
+            for f in range(2)]
+    ws = [(raww[f] / tot).astype(np.float32).astype(np.float64) for f in range(2)]
+    ws[0][:5, :7] = 0.0
+    ws[1][-9:, -10:] = 0.0
+    ws[0][-9:, -10:] = 0.0                    # a corner NO field covers: norm = 0 -> T = 0 where
+    prof = synth.dico_fwhm(20)                # the whole 9 x 9 window lies in it
+    ref = cpu_ref.Correlation_GLR_test(cube.astype(np.float64), psfs, ws, prof, nthreads=1,
+                                       pcut=1e-8, pmeansub=True)
+    monkeypatch.delenv("ORIGIN_GLR_NO_FOLD", raising=False)
+    plan = kernels.GLRPlan(ctx, cube.shape, psfs, ws, prof, 1e-8, True, precision=precision)
+    assert plan.precision == precision
+    assert plan.fold_eps()[1] is False        # (measured by the first run)
+    d = ctx.to_device(cube)
+    out = plan.run(d, mask=None, want_maps=True)
+    eps, active = plan.fold_eps()
+    assert active and 0.0 < eps <= 2e-6
+    fold = {k: out[k].to_host() for k in ("correl", "correl_min", "profile", "maxmap", "minmap")}
+    out = plan.run(d, mask=None, want_maps=True)
+    assert np.array_equal(out["correl"].to_host(), fold["correl"])
+    monkeypatch.setenv("ORIGIN_GLR_NO_FOLD", "1")
+    out = plan.run(d, mask=None, want_maps=True)
+    exact = {k: out[k].to_host() for k in ("correl", "correl_min", "profile", "maxmap", "minmap")}
+    monkeypatch.delenv("ORIGIN_GLR_NO_FOLD")
+    plan.close()
+    local = maximum_filter1d(np.abs(ref[0]).max(axis=(1, 2)), size=193, mode="nearest")
+    rnd = 1.2e-2 if precision == "bf16" else 3e-6   # (as in the test of the table kernel's FOLD)
+    tol = ((eps + rnd) * local)[:, None, None]
+    for k, r in (("correl", ref[0]), ("correl_min", ref[2])):
+        assert np.all(np.abs(fold[k] - exact[k]) <= 2 * tol), k
+        assert np.all(np.abs(fold[k] - r) <= tol), k
+    assert np.all(fold["correl"][:, -5:, -6:] == 0.0)        # the uncovered corner's interior
+    assert np.all(fold["correl_min"][:, -5:, -6:] == 0.0)
+    assert np.max(np.abs(fold["maxmap"] - fold["correl"].max(axis=0))) == 0.0
+    assert np.max(np.abs(fold["minmap"] - fold["correl_min"].min(axis=0))) == 0.0
+    # (where no field reaches, every T is 0 and the index is whatever the oracle's FFT noise makes
+    # it: compare the rest)
+    sel = np.ones((Ny, Nx), bool)
+    sel[-9:, -10:] = False
+    if precision == "f16x2":
+        assert np.mean(fold["profile"][:, sel] != ref[1][:, sel]) <= 1e-4
+        assert np.mean(exact["profile"][:, sel] != ref[1][:, sel]) <= 1e-4
+
+
 def test_glr_bf16_precision_meets_the_bf16_tolerance(ctx):
     """precision="bf16" (BASELINE config 4): one bf16 MFMA per product in the spectral stage.
     SURVEY 8c tolerance for bf16 operands with wide accumulation: |dT| <= 5e-2, rms <= 5e-3,
