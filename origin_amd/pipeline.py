@@ -106,30 +106,52 @@ def greedy_pca(ctx, cube_std, areamap, nbAreas, thresholds, testO2, Noise_popula
     return F, hmap.astype(np.float64).reshape(Ny, Nx), nstop, drv
 
 
-def glr_bands_for(active_rows, Ny, halo):
+def glr_bands_for(active_rows, Ny, halo, max_early_rows=None):
     """(early, late): row bands [y0, y1) in units the row-band GLR accepts (multiples of 64, the
-    last one ends at Ny).  ``active_rows``: (ymin, ymax) inclusive of every area that still
-    iterates; a band is late when its spatial stage would read a row of one of them (+- halo)."""
+    last one ends at Ny) that together cover [0, Ny).  ``active_rows``: (ymin, ymax) inclusive of
+    every area that still iterates; a band is late when its spatial stage would read a row of one
+    of them (+- halo).  ``max_early_rows``: at most that many rows early (rounded down to a
+    multiple of 64, at least 64) -- the largest ready bands first, cut at multiples of 64, the rest
+    joins the late bands; adjacent late bands are merged."""
     nb = (Ny + 63) // 64
-    late = np.zeros(nb, bool)
+    blocked = np.zeros(nb, bool)
     for ymin, ymax in active_rows:
         b0 = max(0, (ymin - halo) // 64)
         b1 = min(nb - 1, (ymax + halo) // 64)
-        late[b0:b1 + 1] = True
+        blocked[b0:b1 + 1] = True
 
     def runs(flag):
         out, b = [], 0
         while b < nb:
-            if late[b] == flag:
+            if blocked[b] == flag:
                 e = b
-                while e < nb and late[e] == flag:
+                while e < nb and blocked[e] == flag:
                     e += 1
                 out.append((64 * b, min(Ny, 64 * e)))
                 b = e
             else:
                 b += 1
         return out
-    return runs(False), runs(True)
+    early, late = runs(False), runs(True)
+    if max_early_rows is not None:
+        rows_left = max(64, int(max_early_rows) // 64 * 64)
+        kept, moved = [], []
+        for y0, y1 in sorted(early, key=lambda band: band[0] - band[1]):
+            take = min(y1 - y0, rows_left)
+            take = take if y0 + take == y1 else take // 64 * 64
+            if take > 0:
+                kept.append((y0, y0 + take))
+                rows_left -= take
+            if y0 + take < y1:
+                moved.append((y0 + take, y1))
+        early, merged = sorted(kept), []
+        for y0, y1 in sorted(late + moved):
+            if merged and merged[-1][1] == y0:
+                merged[-1] = (merged[-1][0], y1)
+            else:
+                merged.append((y0, y1))
+        late = merged
+    return early, late
 
 
 def greedy_pca_then_glr(ctx, plan, cube_std, areamap, nbAreas, thresholds, testO2, mask,
@@ -161,24 +183,9 @@ def greedy_pca_then_glr(ctx, plan, cube_std, areamap, nbAreas, thresholds, testO
     state = {"early": None, "late": None}
 
     def hook(areas):
-        early, late = glr_bands_for([area_rows[a] for a in areas if area_rows[a]], Ny, halo)
-        if early_budget is not None:   # the largest bands first, cut at multiples of 64 rows
-            rows_left = max(64, int(early_budget / (Nz * Nx)) // 64 * 64)
-            kept, moved, late_in = [], [], late
-            for y0, y1 in sorted(early, key=lambda b: b[0] - b[1]):
-                take = min(y1 - y0, rows_left)
-                take = take if y0 + take == y1 else take // 64 * 64
-                if take > 0:
-                    kept.append((y0, y0 + take))
-                    rows_left -= take
-                if y0 + take < y1:
-                    moved.append((y0 + take, y1))
-            early, late = sorted(kept), []
-            for y0, y1 in sorted(late_in + moved):      # adjacent late bands run as one
-                if late and late[-1][1] == y0:
-                    late[-1] = (late[-1][0], y1)
-                else:
-                    late.append((y0, y1))
+        early, late = glr_bands_for(
+            [area_rows[a] for a in areas if area_rows[a]], Ny, halo,
+            None if early_budget is None else early_budget / (Nz * Nx))
         for i, (y0, y1) in enumerate(early):
             plan.run_rows(cube_faint, mask, correl, profile, correl_min, y0, y1, first=(i == 0),
                           side=True)
