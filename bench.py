@@ -264,9 +264,10 @@ def main():
     cube_std = ctx.empty((Nz, ny, nx), np.float32)
     cont_dct = ctx.empty((Nz, ny, nx), np.float32)
     cube_faint = ctx.empty((Nz, ny, nx), np.float32) if world == 1 else None  # (tiled: in glr.ext)
-    correl = ctx.empty((Nz, ny, nx), np.float32)
-    correl_min = ctx.empty((Nz, ny, nx), np.float32)
-    profile = ctx.empty((Nz, ny, nx), np.uint8)
+    # (tiled: the GLR's outputs and the local maxima stay in the tile's halo-extended arrays)
+    correl = ctx.empty((Nz, ny, nx), np.float32) if world == 1 else None
+    correl_min = ctx.empty((Nz, ny, nx), np.float32) if world == 1 else None
+    profile = ctx.empty((Nz, ny, nx), np.uint8) if world == 1 else None
     ima_dct = ctx.empty((ny, nx), np.float32)
     ima_std = ctx.empty((ny, nx), np.float32)
     o2_buf = ctx.empty((ny, nx), np.float64)
@@ -283,8 +284,8 @@ def main():
 
     # (outputs of --local-max, allocated once: a 5 GB hipMalloc / hipFree per step is slower than
     # the kernel)
-    lmax_buf = ctx.empty(correl.shape, np.float32) if args.local_max else None
-    lmin_buf = ctx.empty(correl.shape, np.float32) if args.local_max else None
+    lmax_buf = ctx.empty((Nz, ny, nx), np.float32) if args.local_max and world == 1 else None
+    lmin_buf = ctx.empty((Nz, ny, nx), np.float32) if args.local_max and world == 1 else None
 
     glr_key = "glr_and_local_max" if args.local_max else "glr"
 
@@ -352,9 +353,9 @@ def main():
                                                    into=glr.faint_target() if world > 1 else None)
         t3 = time.perf_counter()
         if world > 1:
-            out = glr.run(None, mask, correl, profile, correl_min,
-                          local_max=(lmax_buf, lmin_buf) if do_lm else None,
-                early_budget=args.tail_early_budget or None)
+            # (no crop: correl / correl_min / profile and the local maxima stay in the tile's
+            # halo-extended arrays, out["box"] is the tile inside them)
+            out = glr.run(None, mask, None, None, None, local_max=True if do_lm else None)
         else:
             out = plan.run(cube_faint, mask=mask, correl=correl, profile=profile,
                            correl_min=correl_min, want_maps=True)

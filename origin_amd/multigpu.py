@@ -459,6 +459,13 @@ class TiledGLR:
         two maps are DeviceArrays OWNED BY THIS OBJECT and rewritten by the next call: copy them
         (``.to_host()`` / ``.copy()``) to keep them across steps.
 
+        ``correl = profile = correl_min = None`` (and ``local_max=True``): NO crop.  The results
+        stay in the halo-extended arrays this object owns -- ``res["correl"]`` etc. have the
+        extended shape and ``res["box"] = (top, left, ny, nx)`` is the tile inside them (read it
+        with ``DeviceArray.window`` or hand kernels the strides); cropping three cubes and
+        the two local-maxima cubes on the device is 34 B/voxel of extra traffic per step, more
+        than a third of what the whole path moves.
+
         ``local_max``: None, or a pair of tile-shaped DeviceArrays that receive
         ``compute_local_max(correl, correl_min, mask, size)`` (reference steps.py:796).  The
         maximum filter looks size // 2 spaxels beyond the tile, so the tiling's halo must be at
@@ -475,17 +482,24 @@ class TiledGLR:
         o = self.plan.run(self.ext, mask=self.emask if mask is not None else None,
                           correl=self.out["correl"], profile=self.out["profile"],
                           correl_min=self.out["correl_min"], want_maps=True)
-        for name, dst in (("correl", correl), ("correl_min", correl_min), ("profile", profile)):
-            _copy_box(ctx, dst, dst.shape, (0, 0, 0), o[name], self.eshape, (0, top, left),
-                      (Nz, ny, nx))
+        crop = correl is not None
+        if crop:
+            for name, dst in (("correl", correl), ("correl_min", correl_min), ("profile", profile)):
+                _copy_box(ctx, dst, dst.shape, (0, 0, 0), o[name], self.eshape, (0, top, left),
+                          (Nz, ny, nx))
+        else:
+            if profile is not None or correl_min is not None:
+                raise ValueError("pass all three output cubes or none of them")
+            correl, correl_min, profile = o["correl"], o["correl_min"], o["profile"]
         # the maps of the kept spaxels, cropped on the device (no host round trip per step)
         e_ny, e_nx = self.eshape[1:]
         for name in ("maxmap", "minmap"):
             _copy_box(ctx, self.maps[name], (1, ny, nx), (0, 0, 0), o[name], (1, e_ny, e_nx),
                       (0, top, left), (1, ny, nx))
         res = dict(correl=correl, profile=profile, correl_min=correl_min,
-                   maxmap=self.maps["maxmap"], minmap=self.maps["minmap"])
-        if local_max is not None:
+                   maxmap=self.maps["maxmap"], minmap=self.maps["minmap"],
+                   box=(top, left, ny, nx) if not crop else (0, 0, ny, nx))
+        if local_max is not None and local_max is not False:
             need = self.plan.P // 2 + int(size) // 2
             if self.tiling.halo < need:
                 raise ValueError(f"local maxima of size {size} on tiles need a halo of {need} "
@@ -495,8 +509,13 @@ class TiledGLR:
             kernels.local_max(ctx, o["correl"], o["correl_min"],
                               self.emask if mask is not None else None, size,
                               out_max=self._lm[0], out_min=self._lm[1])
-            for src, dst in zip(self._lm, local_max):
-                _copy_box(ctx, dst, dst.shape, (0, 0, 0), src, self.eshape, (0, top, left),
-                          (Nz, ny, nx))
-            res["local_max"], res["local_min"] = local_max
+            if local_max is True:   # no crop: the extended cubes (valid inside res["box"])
+                if crop:
+                    raise ValueError("local_max=True goes with correl=None (no crop at all)")
+                res["local_max"], res["local_min"] = self._lm
+            else:
+                for src, dst in zip(self._lm, local_max):
+                    _copy_box(ctx, dst, dst.shape, (0, 0, 0), src, self.eshape, (0, top, left),
+                              (Nz, ny, nx))
+                res["local_max"], res["local_min"] = local_max
         return res

@@ -127,6 +127,18 @@ def main():
         prof = ctx.empty(shape, np.uint8)
         lm = (ctx.empty(shape, np.float32), ctx.empty(shape, np.float32))
         o = glr.run(faint, d_mask, correl, prof, cmin, local_max=lm)
+        if os.environ.get("TILED_NOCROP", "1") == "1":
+            # the same step without the crop (what bench.py times on tiles): the results stay in
+            # the halo-extended arrays, res["box"] is the tile inside them -- bit for bit the
+            # cropped cubes
+            o2 = glr.run(faint, d_mask, None, None, None, local_max=True)
+            by, bx, bny, bnx = o2["box"]
+            assert (bny, bnx) == shape[1:]
+            for name, ref_arr in (("correl", correl), ("correl_min", cmin), ("profile", prof),
+                                  ("local_max", lm[0]), ("local_min", lm[1])):
+                got = o2[name].window(by, by + bny, bx, bx + bnx)
+                assert np.array_equal(got, ref_arr.to_host()), name
+            assert np.array_equal(o2["maxmap"].to_host(), o["maxmap"].to_host())
         if into:   # the tile lives inside the extended buffer
             top, _, left, _ = glr.halos
             faint_host = glr.ext.window(top, top + shape[1], left, left + shape[2])
