@@ -178,3 +178,24 @@ def test_config5_900_f16x2_glr_windows_only():
     assert line["dtype"] == "f32+f16x2" and len(chk["glr"]) == 3 and not chk["pca"]
     print(json.dumps(chk, indent=1))
     assert chk["ok"]
+
+
+def test_bench_two_ranks_on_one_gpu_prints_its_line():
+    """`python bench.py --gpus 2` end to end on ONE device (ORIGIN_BENCH_SHARE_GPU=1: the ranks
+    share the GPU and the halo strips go through the host -- the transport is not what is tested):
+    the parent spawns its ranks, every rank runs the tiled step (PCA into the extended tile, halo
+    exchange, GLR and local maxima without a crop), rank 0's line comes back with the per-rank
+    table, exit status 0.  A change to the step that breaks the multi-rank branch shows up here and
+    not first on the multi-GPU node."""
+    env = dict(os.environ, ORIGIN_BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "200",
+           "--steps", "2", "--warmup", "1", "--check", "off", "--no-cpu-baseline", "--e2e-size", "0"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=ROOT,
+                       env=env)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert line["config"]["tiles"] == 2 and line["n_gpus"] == 1   # (one device, honestly reported)
+    assert line["value"] > 0 and line["sequential"] is None
+    pr = line["per_rank"]
+    assert len(pr["pca_iterations"]) == 2 and sum(pr["areas"]) == 4
+    assert set(pr["phases_ms"]) >= {"dct_std", "greedy_pca"}
