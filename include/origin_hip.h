@@ -379,6 +379,14 @@ int origin_glr_rows_supported(origin_glr_plan *plan, int *ok);
 int origin_glr_run_rows(origin_ctx *ctx, origin_glr_plan *plan, const float *d_cube,
                         const uint8_t *d_mask, float *d_work, float *d_correl, uint8_t *d_profile,
                         float *d_correl_min, int y0, int y1, int flags);
+/* The same for a RECTANGLE of the field: rows [y0, y1), columns [x0, x1), each a multiple of 64 or
+ * the field's end (origin_glr_run_rows = all columns).  A tile of a tiled field runs the rectangles
+ * that stay clear of its halo while the halo strips are on their way (origin_amd/multigpu.py).
+ * With x0 > 0 or x1 < Nx a wave of the spectral stage holds 32 columns of ONE row (rows are not
+ * multiples of 32 long in general): results agree with origin_glr_run to rounding, not bit for bit. */
+int origin_glr_run_rect(origin_ctx *ctx, origin_glr_plan *plan, const float *d_cube,
+                        const uint8_t *d_mask, float *d_work, float *d_correl, uint8_t *d_profile,
+                        float *d_correl_min, int y0, int y1, int x0, int x1, int flags);
 int origin_glr_run_finish(origin_ctx *ctx, origin_glr_plan *plan, float *d_work, float *d_maxmap,
                           float *d_minmap);
 

@@ -89,6 +89,7 @@ SIGNATURES = {
     "origin_glr_run": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "origin_glr_rows_supported": [vp, PP(i32)],
     "origin_glr_run_rows": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32],
+    "origin_glr_run_rect": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32],
     "origin_glr_run_finish": [vp, vp, vp, vp, vp],
     "origin_pca_set_tail_hook": [vp, vp, vp, i32],
     "origin_local_max": [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp],

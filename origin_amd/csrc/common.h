@@ -133,10 +133,10 @@ int origin_scratch(origin_ctx *ctx, size_t bytes, void **out);
 // glr_spatial_mfma.hip: matrix-core spatial GLR stage (one field, or one weighted field of a
 // mosaic: W its weight map, accf = add to what the fields before left in out)
 int origin_spatial_mfma_ok(int Ny, int Nx, int P);
-// (ry0, nry: rows of 64 x 64 regions to run, nry <= 0 = the whole field)
+// (ry0, nry / rx0, nrx: rows / columns of 64 x 64 regions to run, <= 0 = all of them)
 int origin_spatial_mfma_launch(origin_ctx *ctx, int terms, const float *A, const float *W,
                                const float *taps, int Nz, int Ny, int Nx, int P, int accf,
-                               float *out, int ry0 = 0, int nry = 0);
+                               float *out, int ry0 = 0, int nry = 0, int rx0 = 0, int nrx = 0);
 long origin_spatial_mfma_count(int terms, int Nz, int Ny, int Nx, int P);
 
 #define ORIGIN_CHECK_ARG(cond, ...)       \

@@ -1356,12 +1356,22 @@ int origin_glr_rows_supported(origin_glr_plan *plan, int *ok) {
 int origin_glr_run_rows(origin_ctx *ctx, origin_glr_plan *pl, const float *d_cube,
                         const uint8_t *d_mask, float *d_work, float *d_correl, uint8_t *d_profile,
                         float *d_correl_min, int y0, int y1, int flags) {
+  return origin_glr_run_rect(ctx, pl, d_cube, d_mask, d_work, d_correl, d_profile, d_correl_min, y0,
+                             y1, 0, pl ? pl->Nx : 0, flags);
+}
+
+int origin_glr_run_rect(origin_ctx *ctx, origin_glr_plan *pl, const float *d_cube,
+                        const uint8_t *d_mask, float *d_work, float *d_correl, uint8_t *d_profile,
+                        float *d_correl_min, int y0, int y1, int x0, int x1, int flags) {
   ORIGIN_USE(ctx);
   ORIGIN_CHECK_ARG(pl && pl->ctx == ctx, "plan does not belong to this context");
   ORIGIN_CHECK_ARG(d_cube && d_work && d_correl && d_profile && d_correl_min, "null pointer");
   const int Nz = pl->Nz, Ny = pl->Ny, Nx = pl->Nx, P = pl->P, K = pl->K;
   ORIGIN_CHECK_ARG(y0 >= 0 && y0 < y1 && y1 <= Ny && y0 % 64 == 0 && (y1 % 64 == 0 || y1 == Ny),
                    "row band must start at a multiple of 64 and end at one or at Ny");
+  ORIGIN_CHECK_ARG(x0 >= 0 && x0 < x1 && x1 <= Nx && x0 % 64 == 0 && (x1 % 64 == 0 || x1 == Nx),
+                   "column range must start at a multiple of 64 and end at one or at Nx");
+  const bool whole_rows = x0 == 0 && x1 == Nx;  // (then the waves are those of a run over the field)
   if (!glr_rows_ok(pl)) {
     origin_set_error("origin_glr_run_rows: the plan's stages do not run the matrix-core table kernels");
     return ORIGIN_E_STATE;
@@ -1384,7 +1394,8 @@ int origin_glr_run_rows(origin_ctx *ctx, origin_glr_plan *pl, const float *d_cub
   {
     ProfScope ps(ctx, K_GLR_SPATIAL);
     rc = origin_spatial_mfma_launch(ctx, pl->precision == 2 ? 1 : 3, d_cube, nullptr, pl->d_k, Nz, Ny,
-                                    Nx, P, 0, fsf, y0 / 64, cdiv(y1 - y0, 64));
+                                    Nx, P, 0, fsf, y0 / 64, cdiv(y1 - y0, 64), x0 / 64,
+                                    cdiv(x1 - x0, 64));
   }
   if (rc == ORIGIN_OK) {
     ProfScope ps(ctx, K_GLR_SPECTRAL);
@@ -1395,7 +1406,8 @@ int origin_glr_run_rows(origin_ctx *ctx, origin_glr_plan *pl, const float *d_cub
         pl->precision == 2 ? pl->d_atab_bf16 : pl->d_atab, pl->d_pwide, K, pl->n_narrow, Nz, Ny, Nx,
         P, d_mask, d_correl, d_profile, d_correl_min, part, true, &nzc, &pmax, &pmin,
         pl->precision == 2 ? pl->d_atab_bf16_fold : pl->d_atab_fold, pl->d_rden_fold, pl->d_sden,
-        pl->order_ident, (long)y0 * Nx, (long)(y1 - y0) * Nx);
+        pl->order_ident, (long)y0 * Nx, (long)(y1 - y0) * Nx, nullptr, 0, whole_rows ? 0 : x0,
+        whole_rows ? 0 : x1);
   }
   if (side) {
     std::swap(ctx->stream, ctx->side_stream);

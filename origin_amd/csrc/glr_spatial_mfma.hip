@@ -107,8 +107,10 @@ __global__ __launch_bounds__(512, 1) void spatial2_kernel(const float *__restric
                                                           const float *__restrict__ W,
                                                           const float *__restrict__ taps, int Nz,
                                                           int Ny, int Nx, int zper, int accf,
-                                                          float *__restrict__ out, int ry0) {
-  // (ry0: first row of 64 x 64 regions of this launch -- a run may be split into row bands)
+                                                          float *__restrict__ out, int ry0,
+                                                          int rx0) {
+  // (ry0, rx0: first row / column of 64 x 64 regions of this launch -- a run may be split into
+  // rectangles of regions)
   using G = S2Geom<P>;
   extern __shared__ __align__(16) char s2_lds[];
   constexpr int c = P / 2;
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(512, 1) void spatial2_kernel(const float *__restric
   float *tapst = reinterpret_cast<float *>(tab_h + (TERMS == 3 ? 2 : 1) * G::TAB);
   unsigned *maxw = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(tapst) + G::TAPS);
 
-  const int x0 = blockIdx.x * S2_R, y0 = (blockIdx.y + ry0) * S2_R;
+  const int x0 = (blockIdx.x + rx0) * S2_R, y0 = (blockIdx.y + ry0) * S2_R;
   const long S = (long)Ny * Nx;
   const int z0 = blockIdx.z * zper, z1 = min(Nz, z0 + zper);
   const int n = lane & 31, h = lane >> 5;
@@ -381,7 +383,7 @@ int origin_spatial_mfma_ok(int Ny, int Nx, int P) {
 
 template <int P, int TERMS, bool VEC, bool WEIGHTED>
 static int s2_launch(origin_ctx *ctx, const float *A, const float *W, const float *taps, int Nz,
-                     int Ny, int Nx, int accf, float *out, int ry0, int nry) {
+                     int Ny, int Nx, int accf, float *out, int ry0, int nry, int rx0, int nrx) {
   const size_t lds = 2 * s2_group_bytes<P, TERMS>();
   static bool attr_done = false;
   if (!attr_done) {
@@ -392,7 +394,8 @@ static int s2_launch(origin_ctx *ctx, const float *A, const float *W, const floa
   // one block per CU at a time (LDS): choose the number of z chunks so that the blocks fill
   // whole rounds of the chip (an even number of channels per chunk keeps both groups busy)
   if (nry <= 0) ry0 = 0, nry = cdiv(Ny, S2_R);
-  const long regions = (long)cdiv(Nx, S2_R) * nry;
+  if (nrx <= 0) rx0 = 0, nrx = cdiv(Nx, S2_R);
+  const long regions = (long)nrx * nry;
   const int ncu = std::max(1, ctx->num_cu);
   int best_nzb = 1;
   double best_eff = 0.0;
@@ -407,9 +410,9 @@ static int s2_launch(origin_ctx *ctx, const float *A, const float *W, const floa
   }
   int zper = cdiv(Nz, best_nzb);
   zper += zper & 1;
-  dim3 grid(cdiv(Nx, S2_R), nry, cdiv(Nz, zper));
+  dim3 grid(nrx, nry, cdiv(Nz, zper));
   hipLaunchKernelGGL((spatial2_kernel<P, TERMS, VEC, WEIGHTED>), grid, dim3(512), lds, ctx->stream,
-                     A, W, taps, Nz, Ny, Nx, zper, accf, out, ry0);
+                     A, W, taps, Nz, Ny, Nx, zper, accf, out, ry0, rx0);
   ORIGIN_LAUNCH_CHECK();
   return ORIGIN_OK;
 }
@@ -417,7 +420,7 @@ static int s2_launch(origin_ctx *ctx, const float *A, const float *W, const floa
 // W: weight map of the field or NULL; accf: add to `out` (fields after the first)
 int origin_spatial_mfma_launch(origin_ctx *ctx, int terms, const float *A, const float *W,
                                const float *taps, int Nz, int Ny, int Nx, int P, int accf,
-                               float *out, int ry0, int nry) {
+                               float *out, int ry0, int nry, int rx0, int nrx) {
   // (tile loads start at x0 - P/2: float4-aligned only when P/2 is a multiple of four)
   const bool vec = (Nx & 3) == 0 && ((P / 2) & 3) == 0;
   if (!W && accf) {
@@ -425,8 +428,10 @@ int origin_spatial_mfma_launch(origin_ctx *ctx, int terms, const float *A, const
     return ORIGIN_E_ARG;
   }
 #define S2_GO(PP, TT, VV)                                                                      \
-  return W ? s2_launch<PP, TT, VV, true>(ctx, A, W, taps, Nz, Ny, Nx, accf, out, ry0, nry)     \
-           : s2_launch<PP, TT, VV, false>(ctx, A, nullptr, taps, Nz, Ny, Nx, 0, out, ry0, nry)
+  return W ? s2_launch<PP, TT, VV, true>(ctx, A, W, taps, Nz, Ny, Nx, accf, out, ry0, nry, rx0,  \
+                                         nrx)                                                      \
+           : s2_launch<PP, TT, VV, false>(ctx, A, nullptr, taps, Nz, Ny, Nx, 0, out, ry0, nry, rx0, \
+                                          nrx)
 #define S2_CASE(PP)                        \
   case PP:                                 \
     if (vec) {                             \

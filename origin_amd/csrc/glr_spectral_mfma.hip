@@ -686,9 +686,11 @@ __global__ __launch_bounds__(64 * MF_WAVES, 1) void spectral_mfma2_kernel(
     const int *__restrict__ pinfo, int K, int NP, int Nz, int Ny, int Nx, int P, int zchunk, const uint8_t *__restrict__ mask, float *__restrict__ correl,
     uint8_t *__restrict__ profile, float *__restrict__ correl_min, float *__restrict__ part_max,
     float *__restrict__ part_min, const float *__restrict__ sden, int zf0, int zf1, int nN,
-    long s_first, long s_end) {
+    long s_first, long s_end, int rx0, int rx1) {
   // (s_first, s_end: the spaxels of this launch, in multiples of 32 from the field's first -- a run
-  // may be split into row bands; waves hold the same 32 spaxels as in a launch over the field)
+  // may be split into row bands; waves hold the same 32 spaxels as in a launch over the field.
+  // rx1 > 0: a RECTANGLE instead -- the rows s_first / Nx .. s_end / Nx, columns rx0 .. rx1 - 1 of
+  // each; a wave holds 32 consecutive columns of one row)
   extern __shared__ __align__(16) char sm_lds[];
   const int Kp = K + (K & 1);  // slots in LDS: an odd K's last profile twice (its pair partner)
   {
@@ -702,7 +704,15 @@ __global__ __launch_bounds__(64 * MF_WAVES, 1) void spectral_mfma2_kernel(
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, in an SGPR
   const int r = lane & 31, h = lane >> 5;
-  const long s_base = s_first + ((long)blockIdx.x * MF_WAVES + wv) * 32;
+  long s_base = s_first + ((long)blockIdx.x * MF_WAVES + wv) * 32;
+  if (rx1 > 0) {
+    const int wpr = (rx1 - rx0 + 31) / 32;  // waves per row
+    const long w = (long)blockIdx.x * MF_WAVES + wv;
+    const long row = s_first / Nx + w / wpr;
+    if (row >= s_end / Nx) return;  // (whole wave)
+    s_base = row * Nx + rx0 + 32 * (int)(w % wpr);
+    s_end = row * Nx + rx1;
+  }
   if (s_base >= s_end) return;  // whole wave; no barrier follows
   const int zc0 = blockIdx.y * zchunk, zc1 = min(Nz, zc0 + zchunk);
   // A rows: lane r is output channel zi = r & 15 of the pair's profile r >> 4; its fragment of
@@ -829,7 +839,7 @@ int origin_spectral_mfma_launch(origin_ctx *ctx, int terms, const float *fsf, co
                                 bool want_maps, int *nzc_out, float **pmax_out, float **pmin_out,
                                 const uint4 *atab_fold, const float *rden_fold, const float *sden,
                                 int ident, long s_first, long s_count, const float *normc,
-                                int part_rows) {
+                                int part_rows, int rx0, int rx1) {
   const long S = (long)Ny * Nx;
   long bx;
   int nzm, zcm;
@@ -837,12 +847,19 @@ int origin_spectral_mfma_launch(origin_ctx *ctx, int terms, const float *fsf, co
   // the partial maps of all parts of a run share their layout)
   sm_geometry(ctx->num_cu, Nz, S, &bx, &nzm, &zcm);
   if (s_count <= 0) s_first = 0, s_count = S;
-  if (s_first % 32 != 0 || s_first < 0 || s_first + s_count > S) {
+  if ((rx1 <= 0 && s_first % 32 != 0) || s_first < 0 || s_first + s_count > S) {
     origin_set_error("spectral MFMA kernel: bad spaxel range");
     return ORIGIN_E_ARG;
   }
   bx = cdiv(s_count, 32 * MF_WAVES);
   long s_end = s_first + s_count;
+  if (rx1 > 0) {  // rectangle: whole rows s_first / Nx .. , columns rx0 .. rx1 - 1
+    if (s_first % Nx != 0 || s_count % Nx != 0 || rx0 < 0 || rx0 >= rx1 || rx1 > Nx) {
+      origin_set_error("spectral MFMA kernel: bad rectangle");
+      return ORIGIN_E_ARG;
+    }
+    bx = cdiv((s_count / Nx) * (long)cdiv(rx1 - rx0, 32), MF_WAVES);
+  }
   // (part_rows: rows of each partial map when other launches add theirs behind this one's)
   float *pmax = want_maps ? part : nullptr;
   float *pmin = want_maps ? part + (size_t)std::max(nzm, part_rows) * S : nullptr;
@@ -889,7 +906,7 @@ int origin_spectral_mfma_launch(origin_ctx *ctx, int terms, const float *fsf, co
   }
   int a_NP = NP, a_zcm = zcm;
   void *args[] = {&fsf, &a_rden, &rdi_s, &NzP, &a_atab, &pinfo, &K, &a_NP, &Nz, &Ny, &Nx, &P, &a_zcm,
-                  &mask, &correl, &profile, &correl_min, &pmax, &pmin, &sden, &zf0, &zf1, &nN, &s_first, &s_end};
+                  &mask, &correl, &profile, &correl_min, &pmax, &pmin, &sden, &zf0, &zf1, &nN, &s_first, &s_end, &rx0, &rx1};
   ORIGIN_HIP(hipLaunchKernel(fn, dim3((unsigned)bx, (unsigned)nzm), dim3(64 * MF_WAVES), args,
                              fold ? std::max(lds, lds_fold) : lds, ctx->stream));
   ORIGIN_LAUNCH_CHECK();

@@ -47,7 +47,8 @@ int origin_spectral_mfma_launch(origin_ctx *ctx, int terms, const float *fsf, co
                                 int *nzc_out, float **pmax_out, float **pmin_out,
                                 const uint4 *atab_fold, const float *rden_fold, const float *sden,
                                 int ident, long s_first = 0, long s_count = 0,
-                                const float *normc = nullptr, int part_rows = 0);
+                                const float *normc = nullptr, int part_rows = 0, int rx0 = 0,
+                                int rx1 = 0);
 // glr_spectral_norm_mfma.hip: the end tiles [0, zf0) and [zf1, Nz) of a plan with a norm cube
 int origin_spectral_norm_mfma_launch_ends(origin_ctx *ctx, const float *fsf, const float *norm,
                                           const uint4 *atab, const uint4 *atab2, const int *pinfo,

@@ -198,6 +198,16 @@ class GLRPlan:
                    self.workspace().p, correl.p, profile.p, correl_min.p, int(y0), int(y1),
                    (1 if first else 0) | (2 if side else 0))
 
+    def run_rect(self, cube, mask, correl, profile, correl_min, y0, y1, x0, x1, first=False,
+                 side=False):
+        """Rows [y0, y1) x columns [x0, x1) of a run (each a multiple of 64 or the field's end);
+        see ``run_rows``.  With a proper column range the results agree with ``run`` to rounding
+        (the spectral stage's waves hold 32 columns of one row), not bit for bit."""
+        assert cube.shape == self.shape and cube.dtype == np.float32
+        _capi.call("origin_glr_run_rect", self.ctx.handle, self._h, cube.p, _p(mask),
+                   self.workspace().p, correl.p, profile.p, correl_min.p, int(y0), int(y1), int(x0),
+                   int(x1), (1 if first else 0) | (2 if side else 0))
+
     def run_finish(self, want_maps=True):
         """Ends a run in row bands: the main stream waits for the side bands; returns
         (maxmap, minmap) or (None, None)."""

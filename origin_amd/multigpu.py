@@ -411,6 +411,56 @@ def exchange_halo_host(comm, tiling, rank, tile):
     return ext
 
 
+def region_rects(ok, Ny, Nx, R=64):
+    """Rectangles (y0, y1, x0, x1) in pixels that cover exactly the True cells of ``ok`` (a bool
+    array over the R x R regions of a (Ny, Nx) field): runs of cells per region row, merged with
+    the row above when they span the same columns."""
+    ok = np.asarray(ok, bool)
+    nry, nrx = ok.shape
+    rects, open_ = [], {}     # open_: (rx0, rx1) -> index of a rect that ended on the row above
+    for ry in range(nry):
+        runs, rx = [], 0
+        while rx < nrx:
+            if ok[ry, rx]:
+                e = rx
+                while e < nrx and ok[ry, e]:
+                    e += 1
+                runs.append((rx, e))
+                rx = e
+            else:
+                rx += 1
+        now = {}
+        for run in runs:
+            if run in open_:
+                i = open_[run]
+                rects[i][1] = ry + 1
+            else:
+                i = len(rects)
+                rects.append([ry, ry + 1, run[0], run[1]])
+            now[run] = i
+        open_ = now
+    return [(R * a, min(Ny, R * b), R * c, min(Nx, R * d)) for a, b, c, d in rects]
+
+
+def interior_regions(Ny, Nx, halos, reach, R=64):
+    """Bool array over the R x R regions of a halo-extended tile: True where the region's GLR
+    needs no halo data -- its spatial stage reads rows / columns within ``reach`` (P // 2) of the
+    region, none of them in a halo strip.  ``halos`` = (top, bottom, left, right) widths."""
+    top, bot, left, right = halos
+    nry, nrx = (Ny + R - 1) // R, (Nx + R - 1) // R
+
+    def clear(n, N, lo_h, hi_h):
+        out = np.ones(n, bool)
+        for r in range(n):
+            a, b = R * r - reach, min(N, R * r + R) + reach     # rows read: [a, b)
+            if lo_h and a < lo_h:
+                out[r] = False
+            if hi_h and b > N - hi_h:
+                out[r] = False
+        return out
+    return np.outer(clear(nry, Ny, top, bot), clear(nrx, Nx, left, right))
+
+
 class TiledGLR:
     """GLR of one tile of a tiled field: halo exchange + plan on the extended tile + crop."""
 
@@ -473,15 +523,42 @@ class TiledGLR:
         ctx = self.ctx
         top, bot, left, right = self.halos
         Nz, ny, nx = self.shape
-        # cube_faint None: the greedy PCA wrote this step's tile straight into self.ext's interior
-        exchange_halo(ctx, self.comm, self.tiling, self.rank, cube_faint, self.ext, self._strips)
         if mask is not None and not self._mask_set:  # halo spaxels are discarded: mask 0 there
             _copy_box(ctx, self.emask, self.eshape, (0, top, left), mask, mask.shape, (0, 0, 0),
                       (Nz, ny, nx))
             self._mask_set = True
-        o = self.plan.run(self.ext, mask=self.emask if mask is not None else None,
-                          correl=self.out["correl"], profile=self.out["profile"],
-                          correl_min=self.out["correl_min"], want_maps=True)
+        emask = self.emask if mask is not None else None
+        # Interior first: the regions of the extended tile whose GLR reads no halo data run on the
+        # context's side stream WHILE the strips travel (and while this rank waits for a neighbour
+        # that is still iterating); the regions along the halo follow the exchange on the main
+        # stream.  Needs the tile in self.ext already (cube_faint None: the PCA wrote it there)
+        # and a plan whose stages take rectangles; ORIGIN_TILED_INTERIOR_FIRST=0 turns it off.
+        early = []
+        if (cube_faint is None and self.plan.rows_supported()
+                and os.environ.get("ORIGIN_TILED_INTERIOR_FIRST", "1") != "0"):
+            e_ny, e_nx = self.eshape[1:]
+            ok = interior_regions(e_ny, e_nx, self.halos, self.plan.P // 2)
+            early = region_rects(ok, e_ny, e_nx)
+            late = region_rects(~ok, e_ny, e_nx)
+        if early:
+            oc, op, om = self.out["correl"], self.out["profile"], self.out["correl_min"]
+            for i, (y0, y1, x0, x1) in enumerate(early):
+                self.plan.run_rect(self.ext, emask, oc, op, om, y0, y1, x0, x1, first=(i == 0),
+                                   side=True)
+            exchange_halo(ctx, self.comm, self.tiling, self.rank, None, self.ext, self._strips)
+            for y0, y1, x0, x1 in late:
+                self.plan.run_rect(self.ext, emask, oc, op, om, y0, y1, x0, x1)
+            maxmap, minmap = self.plan.run_finish(want_maps=True)
+            o = dict(correl=oc, profile=op, correl_min=om, maxmap=maxmap, minmap=minmap)
+        else:
+            # cube_faint None: the greedy PCA wrote this step's tile straight into self.ext's
+            # interior
+            exchange_halo(ctx, self.comm, self.tiling, self.rank, cube_faint, self.ext,
+                          self._strips)
+            o = self.plan.run(self.ext, mask=emask, correl=self.out["correl"],
+                              profile=self.out["profile"], correl_min=self.out["correl_min"],
+                              want_maps=True)
+        self.last_rects = (early, late if early else [])
         crop = correl is not None
         if crop:
             for name, dst in (("correl", correl), ("correl_min", correl_min), ("profile", profile)):

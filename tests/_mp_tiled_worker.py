@@ -23,6 +23,17 @@ from origin_amd import multigpu, synth  # noqa: E402
 
 
 def field():
+    if os.environ.get("TILED_FIELD") == "big":
+        # tiles wide enough for 64 x 64 regions that need no halo data (TiledGLR runs those on
+        # the side stream while the strips travel)
+        f = synth.SyntheticField(64, 150, 320, seed=6, psf_size=9, nprof=3, blob_density=1 / 200,
+                                 emitter_density=1 / 900, area_size=50)
+        raw, var, mask = f.arrays()
+        mask[10:14, 3, 7] = True
+        mask[:, 125, 241] = True
+        raw[mask] = 0
+        var[mask] = np.inf
+        return f, raw, var, mask
     f = synth.SyntheticField(96, 40, 60, seed=5, psf_size=9, nprof=3, blob_density=1 / 80,
                              emitter_density=1 / 300, area_size=20)
     raw, var, mask = f.arrays()
@@ -56,7 +67,8 @@ def main():
     f, raw, var, mask = field()
     Nz, Ny, Nx = raw.shape
     # (+1: the 3x3x3 local maxima of the tile look one spaxel beyond it)
-    tiling = multigpu.Tiling(Ny, Nx, world, area_size=20, halo=f.PSF.shape[1] // 2 + 1)
+    tiling = multigpu.Tiling(Ny, Nx, world, halo=f.PSF.shape[1] // 2 + 1,
+                             area_size=50 if os.environ.get("TILED_FIELD") == "big" else 20)
     t = tiling.tile(rank)
     sl = (slice(None), slice(t.y0, t.y1), slice(t.x0, t.x1))
     traw, tvar, tmask = raw[sl], var[sl], mask[sl]
@@ -147,7 +159,8 @@ def main():
         res = dict(cube_std=pre["cube_std"].to_host(), cube_faint=faint_host,
                    correl=correl.to_host(), correl_min=cmin.to_host(), mapO2=mapO2,
                    maxmap=o["maxmap"].to_host(), thr=np.array(thr["thresO2"]),
-                   local_max=lm[0].to_host(), local_min=lm[1].to_host())
+                   local_max=lm[0].to_host(), local_min=lm[1].to_host(),
+                   n_early=len(glr.last_rects[0]))   # rectangles run ahead of the halo exchange
     np.savez(f"{out}.rank{rank}.npz", y0=t.y0, y1=t.y1, x0=t.x0, x1=t.x1, **res)
     comm.barrier()
     comm.close()

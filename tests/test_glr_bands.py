@@ -56,3 +56,56 @@ def test_early_bands_never_read_a_row_of_an_active_area(seed):
         assert sum(y1 - y0 for y0, y1 in early) <= max(64, budget // 64 * 64)
     if not active:
         assert late == [] or budget is not None
+
+
+# ---- tiles: which 64 x 64 regions of a halo-extended tile need no halo data (multigpu.py) ----
+def test_interior_regions_of_the_bench_tilings():
+    from origin_amd import multigpu as m
+    # two ranks at 600^2: tiles 600 x 300, one halo column strip of 12
+    ok = m.interior_regions(600, 312, (0, 0, 0, 12), 12)
+    assert m.region_rects(ok, 600, 312) == [(0, 600, 0, 256)]
+    assert m.region_rects(~ok, 600, 312) == [(0, 600, 256, 312)]
+    # four ranks: 300 x 300 tiles, halos on two sides
+    ok = m.interior_regions(312, 312, (12, 0, 12, 0), 12)
+    assert m.region_rects(ok, 312, 312) == [(64, 312, 64, 312)]
+    assert m.region_rects(~ok, 312, 312) == [(0, 64, 0, 312), (64, 312, 0, 64)]
+    # eight ranks: 100-wide tiles have no halo-free region
+    ok = m.interior_regions(524, 124, (12, 12, 12, 12), 12)
+    assert not ok.any() and m.region_rects(~ok, 524, 124) == [(0, 524, 0, 124)]
+    # no neighbours at all: everything is interior
+    ok = m.interior_regions(600, 600, (0, 0, 0, 0), 12)
+    assert ok.all()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_region_rects_cover_the_mask_exactly(seed):
+    from origin_amd import multigpu as m
+    rng = np.random.default_rng(seed)
+    Ny, Nx = int(rng.integers(1, 700)), int(rng.integers(1, 700))
+    nry, nrx = (Ny + 63) // 64, (Nx + 63) // 64
+    ok = rng.random((nry, nrx)) < 0.6
+    cover = np.zeros((Ny, Nx), int)
+    for y0, y1, x0, x1 in m.region_rects(ok, Ny, Nx):
+        assert y0 % 64 == 0 and x0 % 64 == 0 and (y1 % 64 == 0 or y1 == Ny)
+        assert (x1 % 64 == 0 or x1 == Nx) and y0 < y1 and x0 < x1
+        cover[y0:y1, x0:x1] += 1
+    want = np.kron(ok.astype(int), np.ones((64, 64), int))[:Ny, :Nx]
+    assert np.array_equal(cover, want)                   # every True cell once, no False cell
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_interior_regions_read_no_halo_row_or_column(seed):
+    from origin_amd import multigpu as m
+    rng = np.random.default_rng(100 + seed)
+    Ny, Nx = int(rng.integers(30, 700)), int(rng.integers(30, 700))
+    reach = int(rng.integers(0, 13))
+    halos = tuple(int(h) for h in rng.choice([0, 12, 13], 4))
+    ok = m.interior_regions(Ny, Nx, halos, reach)
+    top, bot, left, right = halos
+    for ry in range(ok.shape[0]):
+        for rx in range(ok.shape[1]):
+            a, b = 64 * ry - reach, min(Ny, 64 * ry + 64) + reach
+            c, d = 64 * rx - reach, min(Nx, 64 * rx + 64) + reach
+            touches = ((top and a < top) or (bot and b > Ny - bot) or
+                       (left and c < left) or (right and d > Nx - right))
+            assert ok[ry, rx] == (not touches)

@@ -404,3 +404,44 @@ def test_pca_tail_hook_and_the_glr_started_in_its_shadow(ctx, max_active):
     assert all(y0 % 64 == 0 for y0, _ in early + late)
     assert sorted(early + late)[0][0] == 0 and sorted(early + late)[-1][1] == Ny
     plan.close()
+
+
+def test_glr_rectangles_agree_with_the_whole_run(ctx):
+    """origin_glr_run_rect: the field in four rectangles of 64 x 64 regions (one on the side
+    stream) -- what a tile of a tiled field does around its halo exchange.  A rectangle that spans
+    all columns is bit for bit the whole run's; one that does not holds 32 columns of one row per
+    wave of the spectral stage (other tile scales): equal to rounding, arg-max but for near ties."""
+    from origin_amd import kernels
+    rng = np.random.default_rng(8)
+    Nz, Ny, Nx = 160, 150, 170
+    cube = rng.standard_normal((Nz, Ny, Nx)).astype(np.float32)
+    cube[30:70] *= 19.0
+    mask = (rng.random((Nz, Ny, Nx)) < 0.01).astype(np.uint8)
+    psf = synth.moffat_psf(3681, 9)[:Nz].astype(np.float64)
+    plan = kernels.GLRPlan(ctx, cube.shape, psf, None, synth.dico_fwhm(20), 1e-8, True,
+                           precision="f16x2")
+    d_cube, d_mask = ctx.to_device(cube), ctx.to_device(mask)
+    whole = plan.run(d_cube, mask=d_mask, want_maps=True)
+    want = {k: whole[k].to_host() for k in ("correl", "correl_min", "profile", "maxmap", "minmap")}
+    correl, cmin = ctx.empty(cube.shape, np.float32), ctx.empty(cube.shape, np.float32)
+    prof_i = ctx.empty(cube.shape, np.uint8)
+    for a in (correl, cmin, prof_i):
+        a.fill_bytes(0x7f)
+    plan.run_rect(d_cube, d_mask, correl, prof_i, cmin, 64, Ny, 64, Nx, first=True, side=True)
+    plan.run_rect(d_cube, d_mask, correl, prof_i, cmin, 0, 64, 0, Nx)          # all columns
+    plan.run_rect(d_cube, d_mask, correl, prof_i, cmin, 64, 128, 0, 64)
+    plan.run_rect(d_cube, d_mask, correl, prof_i, cmin, 128, Ny, 0, 64)
+    maxmap, minmap = plan.run_finish()
+    ctx.sync()
+    got = dict(correl=correl.to_host(), correl_min=cmin.to_host(), profile=prof_i.to_host(),
+               maxmap=maxmap.to_host(), minmap=minmap.to_host())
+    for k in ("correl", "correl_min", "profile"):
+        assert np.array_equal(got[k][:, :64], want[k][:, :64]), k     # the band of whole rows
+    scale = np.abs(want["correl"]).max()
+    for k in ("correl", "correl_min", "maxmap", "minmap"):
+        assert np.max(np.abs(got[k] - want[k])) <= 3e-6 * scale, k
+    assert np.mean(got["profile"] != want["profile"]) <= 1e-4
+    assert np.max(np.abs(got["maxmap"] - got["correl"].max(axis=0))) == 0.0
+    with pytest.raises(Exception):
+        plan.run_rect(d_cube, d_mask, correl, prof_i, cmin, 0, 64, 32, Nx)     # x0 not a multiple of 64
+    plan.close()

@@ -194,6 +194,41 @@ def test_tiled_hip_equals_single_hip(tmp_path, world):
     assert np.max(np.abs(stitch(tiles, "maxmap", shape[1:]) - ref["maxmap"])) <= 2e-4
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_tiled_hip_interior_regions_ahead_of_the_halo_exchange(tmp_path, world, monkeypatch):
+    """A field whose tiles hold 64 x 64 regions that need no halo data: TiledGLR runs their GLR on
+    the side stream while the strips travel and the regions along the halo behind the exchange
+    (the worker asserts that such regions exist).  Stitched tiles against the single-GPU run and
+    against the oracle, as in the test above; and the same tiles with
+    ORIGIN_TILED_INTERIOR_FIRST=0 (exchange first, one GLR run): equal to rounding."""
+    monkeypatch.setenv("TILED_FIELD", "big")
+    from _mp_tiled_worker import field
+    from oracle import cpu_ref
+    f, raw, var, mask = field()
+    tiles = run_ranks("gpu", world, str(tmp_path / "gpu"))
+    assert sum(int(t["n_early"]) for t in tiles) > 0      # some rank did run regions ahead
+    single = run_ranks("gpu", 1, str(tmp_path / "one"))
+    monkeypatch.setenv("ORIGIN_TILED_INTERIOR_FIRST", "0")
+    plain = run_ranks("gpu", world, str(tmp_path / "plain"))
+    assert sum(int(t["n_early"]) for t in plain) == 0
+    shape = raw.shape
+    for key, tol in (("cube_std", 1e-6), ("cube_faint", 1e-5), ("correl", 1e-4),
+                     ("correl_min", 1e-4)):
+        got, one = stitch(tiles, key, shape), stitch(single, key, shape)
+        assert np.max(np.abs(got - one)) <= tol, (key, float(np.max(np.abs(got - one))))
+        d_plain = float(np.max(np.abs(got - stitch(plain, key, shape))))
+        assert d_plain <= tol, (key, d_plain)
+    assert np.array_equal(stitch(tiles, "mapO2", shape[1:]), stitch(single, "mapO2", shape[1:]))
+    for key in ("local_max", "local_min"):
+        got, one = stitch(tiles, key, shape), stitch(single, key, shape)
+        assert np.mean((got != 0) != (one != 0)) <= 1e-4, key
+    ref = cpu_ref.run_chain(raw.astype(float), var.astype(float), mask, f.PSF.astype(float), None,
+                            f.profiles, f.areamap, f.nbAreas)
+    assert np.max(np.abs(stitch(tiles, "correl", shape) - ref["cube_correl"])) <= 2e-4
+    assert np.max(np.abs(stitch(tiles, "maxmap", shape[1:]) - ref["maxmap"])) <= 2e-4
+
+
 def _device_count():
     import ctypes as C
     from origin_amd import _capi
