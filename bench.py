@@ -290,6 +290,8 @@ def main():
     glr_key = "glr_and_local_max" if args.local_max else "glr"
 
     area_rows = [(int(s_.min()) // nx, int(s_.max()) // nx) if len(s_) else None for s_ in spx]
+    area_boxes = [(int(s_.min()) // nx, int(s_.max()) // nx, int((s_ % nx).min()),
+                   int((s_ % nx).max())) if len(s_) else None for s_ in spx]
 
     def one_step(with_local_max=None, overlap=None):
         do_lm = args.local_max if with_local_max is None else with_local_max
@@ -344,18 +346,33 @@ def main():
             last.update(thr=thr, mapO2=mapO2, out=out)
             return out
         # tiled: cube_faint is written straight into the interior of the GLR's halo-extended tile
-        # (origin_pca_run_into) -- the tile lives there, no copy before the halo exchange
-        F, mapO2, nstop, drv = pipeline.greedy_pca(ctx, cube_std, local_map, nb_local,
-                                                   thr["thresO2"], thr["testO2"], 50, 100,
-                                                   spx=spx, inplace=False, driver=pca_driver,
-                                                   o2_dev=pre["o2"],
-                                                   out=cube_faint if world == 1 else None,
-                                                   into=glr.faint_target() if world > 1 else None)
+        # (origin_pca_run_into) -- the tile lives there, no copy before the halo exchange; and the
+        # regions of that tile which depend neither on a halo strip nor on the areas still
+        # iterating start their GLR inside the PCA's tail (TiledGLR.make_tail_hook)
+        hook = None
+        if world > 1 and (args.tail_overlap if overlap is None else overlap):
+            hook = glr.make_tail_hook(area_boxes, mask, args.tail_early_budget or None)
+        if hook is not None:
+            ctx.set_pca_tail_hook(hook, args.tail_max_active)
+        try:
+            F, mapO2, nstop, drv = pipeline.greedy_pca(
+                ctx, cube_std, local_map, nb_local, thr["thresO2"], thr["testO2"], 50, 100, spx=spx,
+                inplace=False, driver=pca_driver, o2_dev=pre["o2"],
+                out=cube_faint if world == 1 else None,
+                into=glr.faint_target() if world > 1 else None)
+        finally:
+            if hook is not None:
+                ctx.set_pca_tail_hook(None)
+        if hook is not None and ctx.pop_tail_hook_error() is not None:
+            raise RuntimeError("the tail hook of the tiled GLR failed")
         t3 = time.perf_counter()
         if world > 1:
             # (no crop: correl / correl_min / profile and the local maxima stay in the tile's
             # halo-extended arrays, out["box"] is the tile inside them)
             out = glr.run(None, mask, None, None, None, local_max=True if do_lm else None)
+            info["glr_rects"] = {"ahead_of_exchange": len(glr.last_rects[0]),
+                                 "behind_exchange": len(glr.last_rects[1]),
+                                 "regions_in_pca_tail": glr.last_rects[2]}
         else:
             out = plan.run(cube_faint, mask=mask, correl=correl, profile=profile,
                            correl_min=correl_min, want_maps=True)

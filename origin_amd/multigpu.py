@@ -495,6 +495,7 @@ class TiledGLR:
         self.maps = dict(maxmap=ctx.empty(self.shape[1:], np.float32),
                          minmap=ctx.empty(self.shape[1:], np.float32))
         self._mask_set = False
+        self._early_done = None   # regions whose GLR the tail hook has started (this step)
         self._strips = {}
         self._lm = None   # extended local-maxima cubes, allocated by the first run that wants them
 
@@ -503,6 +504,53 @@ class TiledGLR:
         that writes there is followed by ``run(None, ...)`` -- no copy of the tile in between."""
         top, _, left, _ = self.halos
         return (self.ext, top, left)
+
+    def _set_mask(self, mask):
+        if mask is not None and not self._mask_set:  # halo spaxels are discarded: mask 0 there
+            top, _, left, _ = self.halos
+            Nz, ny, nx = self.shape
+            _copy_box(self.ctx, self.emask, self.eshape, (0, top, left), mask, mask.shape,
+                      (0, 0, 0), (Nz, ny, nx))
+            self._mask_set = True
+        return self.emask if mask is not None else None
+
+    def make_tail_hook(self, area_boxes, mask, early_budget=8.5e8):
+        """A function for ``Context.set_pca_tail_hook`` around the greedy PCA that writes this
+        tile (``into=faint_target()``): when few areas still iterate, the regions of the extended
+        tile that read neither halo data nor a row / column of those areas start their GLR on the
+        side stream, in the shadow of the PCA's tail (pipeline.greedy_pca_then_glr does the same
+        on an untiled field).  ``area_boxes[a]`` = (ymin, ymax, xmin, xmax) of area ``a`` in TILE
+        coordinates, inclusive; ``early_budget``: voxels of GLR started that way at most.  The
+        next ``run(None, ...)`` finishes the step."""
+        if not self.plan.rows_supported():
+            return None
+        top, _, left, _ = self.halos
+        e_ny, e_nx = self.eshape[1:]
+        reach = self.plan.P // 2
+
+        def hook(areas):
+            ok = interior_regions(e_ny, e_nx, self.halos, reach)
+            for a in areas:
+                if area_boxes[a] is None:
+                    continue
+                ymin, ymax, xmin, xmax = area_boxes[a]
+                r0, r1 = max(0, (ymin + top - reach) // 64), (ymax + top + reach) // 64
+                c0, c1 = max(0, (xmin + left - reach) // 64), (xmax + left + reach) // 64
+                ok[r0:r1 + 1, c0:c1 + 1] = False
+            if early_budget is not None:     # the first regions in row order, up to the budget
+                keep = max(1, int(early_budget / (self.Nz * 64 * 64)))
+                flat = np.flatnonzero(ok)
+                ok.reshape(-1)[flat[keep:]] = False
+            rects = region_rects(ok, e_ny, e_nx)
+            if not rects:
+                return
+            emask = self._set_mask(mask)
+            oc, op, om = self.out["correl"], self.out["profile"], self.out["correl_min"]
+            for i, (y0, y1, x0, x1) in enumerate(rects):
+                self.plan.run_rect(self.ext, emask, oc, op, om, y0, y1, x0, x1, first=(i == 0),
+                                   side=True)
+            self._early_done = ok
+        return hook
 
     def run(self, cube_faint, mask, correl, profile, correl_min, local_max=None, size=3):
         """Returns the caller's correl / profile / correl_min and the tile's maxmap / minmap.  The
@@ -523,28 +571,37 @@ class TiledGLR:
         ctx = self.ctx
         top, bot, left, right = self.halos
         Nz, ny, nx = self.shape
-        if mask is not None and not self._mask_set:  # halo spaxels are discarded: mask 0 there
-            _copy_box(ctx, self.emask, self.eshape, (0, top, left), mask, mask.shape, (0, 0, 0),
-                      (Nz, ny, nx))
-            self._mask_set = True
-        emask = self.emask if mask is not None else None
+        emask = self._set_mask(mask)
         # Interior first: the regions of the extended tile whose GLR reads no halo data run on the
         # context's side stream WHILE the strips travel (and while this rank waits for a neighbour
         # that is still iterating); the regions along the halo follow the exchange on the main
         # stream.  Needs the tile in self.ext already (cube_faint None: the PCA wrote it there)
         # and a plan whose stages take rectangles; ORIGIN_TILED_INTERIOR_FIRST=0 turns it off.
-        early = []
+        early, done = [], self._early_done   # (done: regions the tail hook started, this step)
+        self._early_done = None
+        if cube_faint is not None and done is not None:
+            raise ValueError("the tail hook started this step's GLR on the extended tile: "
+                             "run(None, ...) must finish it")
         if (cube_faint is None and self.plan.rows_supported()
-                and os.environ.get("ORIGIN_TILED_INTERIOR_FIRST", "1") != "0"):
+                and (done is not None
+                     or os.environ.get("ORIGIN_TILED_INTERIOR_FIRST", "1") != "0")):
             e_ny, e_nx = self.eshape[1:]
             ok = interior_regions(e_ny, e_nx, self.halos, self.plan.P // 2)
-            early = region_rects(ok, e_ny, e_nx)
+            if os.environ.get("ORIGIN_TILED_INTERIOR_FIRST", "1") == "0":
+                ok[:] = False                 # (only what the hook started runs ahead)
+            if done is not None:
+                ok |= done
             late = region_rects(~ok, e_ny, e_nx)
+            early = region_rects(ok & ~done if done is not None else ok, e_ny, e_nx)
+            if not early and done is not None:
+                early = [None]                # (nothing more ahead, but the step is in rectangles)
         if early:
             oc, op, om = self.out["correl"], self.out["profile"], self.out["correl_min"]
-            for i, (y0, y1, x0, x1) in enumerate(early):
-                self.plan.run_rect(self.ext, emask, oc, op, om, y0, y1, x0, x1, first=(i == 0),
-                                   side=True)
+            for i, rect in enumerate(r for r in early if r is not None):
+                y0, y1, x0, x1 = rect
+                self.plan.run_rect(self.ext, emask, oc, op, om, y0, y1, x0, x1,
+                                   first=(i == 0 and done is None), side=True)
+            early = [r for r in early if r is not None]
             exchange_halo(ctx, self.comm, self.tiling, self.rank, None, self.ext, self._strips)
             for y0, y1, x0, x1 in late:
                 self.plan.run_rect(self.ext, emask, oc, op, om, y0, y1, x0, x1)
@@ -558,7 +615,8 @@ class TiledGLR:
             o = self.plan.run(self.ext, mask=emask, correl=self.out["correl"],
                               profile=self.out["profile"], correl_min=self.out["correl_min"],
                               want_maps=True)
-        self.last_rects = (early, late if early else [])
+        self.last_rects = (early, late if (early or done is not None) else [],
+                           0 if done is None else int(done.sum()))
         crop = correl is not None
         if crop:
             for name, dst in (("correl", correl), ("correl_min", correl_min), ("profile", profile)):

@@ -29,6 +29,13 @@ def field():
         f = synth.SyntheticField(64, 150, 320, seed=6, psf_size=9, nprof=3, blob_density=1 / 200,
                                  emitter_density=1 / 900, area_size=50)
         raw, var, mask = f.arrays()
+        # one area (rows 50-99, columns 100-149) with many spectra of comparable strength: its
+        # PCA goes on long after the others (the tail hook of TiledGLR has something to shadow)
+        rng = np.random.default_rng(9)
+        for j in range(40):
+            y, x = 52 + (7 * j) % 46, 101 + (11 * j) % 47
+            raw[:, y, x] += ((6.5 + 0.1 * j) * np.sqrt(var[:, y, x]) *
+                             rng.standard_normal(raw.shape[0])).astype(raw.dtype)
         mask[10:14, 3, 7] = True
         mask[:, 125, 241] = True
         raw[mask] = 0
@@ -131,14 +138,31 @@ def main():
         # TILED_INTO=1: the PCA writes cube_faint straight into the interior of the GLR's
         # halo-extended tile (origin_pca_run_into), no copy in between -- what bench.py does
         into = os.environ.get("TILED_INTO", "1") == "1"
+        # TILED_HOOK=1: the regions that depend neither on the halo nor on the areas still
+        # iterating start their GLR inside the PCA's tail (TiledGLR.make_tail_hook)
+        hook = None
+        if into and os.environ.get("TILED_HOOK") == "1":
+            nx_t = shape[2]
+            boxes = [(int(s_.min()) // nx_t, int(s_.max()) // nx_t, int((s_ % nx_t).min()),
+                      int((s_ % nx_t).max())) if len(s_) else None for s_ in spx]
+            hook = glr.make_tail_hook(boxes, d_mask)
+        if hook is not None:
+            ctx.set_pca_tail_hook(hook, 2)
         faint, mapO2, nstop, _ = pipeline.greedy_pca(ctx, pre["cube_std"], lmap, len(labels),
                                                      thr["thresO2"], thr["testO2"], spx=spx,
                                                      into=glr.faint_target() if into else None)
+        if hook is not None:
+            ctx.set_pca_tail_hook(None)
+            err = ctx.pop_tail_hook_error()
+            if err is not None:
+                raise err
         correl = ctx.empty(shape, np.float32)
         cmin = ctx.empty(shape, np.float32)
         prof = ctx.empty(shape, np.uint8)
         lm = (ctx.empty(shape, np.float32), ctx.empty(shape, np.float32))
         o = glr.run(faint, d_mask, correl, prof, cmin, local_max=lm)
+        n_hook = glr.last_rects[2]
+        n_early = len(glr.last_rects[0])
         if os.environ.get("TILED_NOCROP", "1") == "1":
             # the same step without the crop (what bench.py times on tiles): the results stay in
             # the halo-extended arrays, res["box"] is the tile inside them -- bit for bit the
@@ -160,7 +184,8 @@ def main():
                    correl=correl.to_host(), correl_min=cmin.to_host(), mapO2=mapO2,
                    maxmap=o["maxmap"].to_host(), thr=np.array(thr["thresO2"]),
                    local_max=lm[0].to_host(), local_min=lm[1].to_host(),
-                   n_early=len(glr.last_rects[0]))   # rectangles run ahead of the halo exchange
+                   n_early=n_early,   # rectangles run ahead of the halo exchange
+                   n_hook=n_hook)     # regions the tail hook started
     np.savez(f"{out}.rank{rank}.npz", y0=t.y0, y1=t.y1, x0=t.x0, x1=t.x1, **res)
     comm.barrier()
     comm.close()

