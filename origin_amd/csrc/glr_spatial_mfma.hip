@@ -81,6 +81,9 @@ struct S2Geom {
   static constexpr int TAB = TROWS * 8 * S2_ENTRY;      // one table (hi or lo)
   static constexpr int NQ = (IW / 4 * IH + 255) / 256;  // staged float4 per thread of a group
   static constexpr int NT = (P * P + 255) / 256;        // staged taps per thread
+  // (staged taps, row pitch P: the table build's reads of four rows per 32-lane group meet on banks
+  // for P = 25; a pitch of 40 floats -- banks 8 dy + copy, all distinct -- was measured in round 3:
+  // 8.15-8.2 ms either way, the conversion group's conflicts are not on the critical path)
   static constexpr int TAPS = (P * P * 4 + 15) / 16 * 16;
   static_assert(IW % 4 == 0 && WCOLS <= 32 && PITCH >= 2 * IW + 16, "geometry");
 };
