@@ -68,7 +68,14 @@ int origin_side_begin(origin_ctx *ctx) {
     reserve = std::max(0, std::min(reserve, ncu - 8));
     uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = 0; i < ncu - reserve; ++i) mask[i >> 5] |= 1u << (i & 31);
-    ORIGIN_HIP(hipExtStreamCreateWithCUMask(&ctx->side_stream, 8, mask));
+    if (hipExtStreamCreateWithCUMask(&ctx->side_stream, 8, mask) != hipSuccess) {
+      // (no CU masks on this runtime: a stream of the lowest priority still gives correct results,
+      // only less of an overlap -- the main stream's small kernels wait for CUs)
+      (void)hipGetLastError();
+      int lo = 0, hi = 0;
+      ORIGIN_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      ORIGIN_HIP(hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, lo));
+    }
     ORIGIN_HIP(hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
     ORIGIN_HIP(hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming));
   }
