@@ -576,6 +576,11 @@ def main():
         roofline = dict(bound=bound, kernel=dominant, achieved=round(ach, 3), peak=peak,
                         unit=unit, frac=round(ach / peak, 4), traffic=traffic,
                         avg_launch_ms=round(tot_ms / launches, 4), launches=launches, **extra)
+        roofline["timed_in"] = (
+            "HIP events around the kernel's launches in the sequential steps of this run (`sequential`: "
+            "one launch per step, the kernel alone on the chip); in the chained steps that `value` "
+            "times the stage runs as row bands beside the greedy PCA's last iterations"
+            if sequential is not None else "HIP events around the kernel's launches in the timed steps")
 
     # ---- whole path against the HBM roofline (the second half of BASELINE.json's metric):
     # SURVEY 8(d) algorithmic bytes per voxel, A = 17 (DCT + standardise), C = 14 (GLR),
