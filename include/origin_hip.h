@@ -76,6 +76,15 @@ int origin_d2d(origin_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
 int origin_copy_box(origin_ctx *ctx, int kind, void *dst, long dst_pitch_y, long dst_pitch_z,
                     const void *src, long src_pitch_y, long src_pitch_z, int nz, int ny,
                     int nx, int elem);
+/* Spaxel-list moves (csrc/columns.hip): packed[z][i] = cube[z][idx[i]] and back, for `elem`-byte
+ * elements (1 or 4) of an (Nz, S) cube and a contiguous (Nz, n) buffer; idx: n int32 spaxel
+ * indices on the device, each < S.  What the tiled path exchanges when PCA areas (irregular sets of
+ * spaxels, steps.py:492-569) are handed to ranks as wholes: the spaxels a rank's GLR reads around
+ * its own (lib_origin.py:1027-1043) are a list, not a rectangle.  Asynchronous on the stream. */
+int origin_gather_columns(origin_ctx *ctx, const void *d_cube, int Nz, long S, const int *d_idx,
+                          long n, int elem, void *d_packed);
+int origin_scatter_columns(origin_ctx *ctx, void *d_cube, int Nz, long S, const int *d_idx, long n,
+                           int elem, const void *d_packed);
 
 /* ---- purity threshold reductions -----------------------------------
  * Device side of Compute_threshold_purity (lib_origin.py:1391-1479, called by

@@ -37,6 +37,8 @@ SIGNATURES = {
     "origin_h2d_f64_as_f32": [vp, vp, vp, sz],
     "origin_d2d": [vp, vp, vp, sz],
     "origin_copy_box": [vp, i32, vp, i64, i64, vp, i64, i64, i32, i32, i32, i32],
+    "origin_gather_columns": [vp, vp, i32, i64, vp, i64, i32, vp],
+    "origin_scatter_columns": [vp, vp, i32, i64, vp, i64, i32, vp],
     "origin_zmax_map": [vp, vp, vp, i32, i64, vp],
     "origin_count_above": [vp, vp, vp, i32, i64, i32, vp, vp],
     "origin_where_above": [vp, vp, vp, i32, i32, i32, C.c_double, i64, vp, vp, vp, vp, vp, vp],

@@ -161,6 +161,180 @@ class Tiling:
     def min_tile_side(self):
         return min(min(t.y1 - t.y0, t.x1 - t.x0) for t in self.tiles)
 
+    def check_halo(self):
+        # a strip must come from ONE neighbour: every tile at least a halo wide
+        if self.min_tile_side() < self.halo:
+            raise ValueError(f"a tile is narrower than the halo {self.halo}: a halo must come "
+                             "from the tiles next to this one, not from beyond them")
+
+    def owned_ext(self, rank):
+        """None: every spaxel of the tile (the interior of the extended box) is this rank's."""
+        return None
+
+    def local_regions(self, rank, reach, R=64):
+        """Bool array over the R x R regions of the extended tile: True where the region's GLR
+        reads no spaxel of another rank (interior_regions)."""
+        (y0, y1, x0, x1), halos = self.extended(rank)
+        return interior_regions(y1 - y0, x1 - x0, halos, reach, R)
+
+
+class OwnerTiling:
+    """Partition of the field by an OWNER MAP: ``owner[y, x]`` = the rank that keeps spaxel
+    (y, x).  What a field cut along irregular PCA areas needs (reference steps.py:492-569: areas
+    come out of a segmentation, convex hulls and growing, not off a grid): every area goes to one
+    rank as a whole, so the greedy PCA needs no communication, and a rank works on the BOUNDING
+    BOX of its spaxels plus ``halo`` spaxels on every side (clipped to the field).  Inside that
+    extended box it owns some spaxels; of the others it needs those within ``halo`` (Chebyshev
+    distance) of an owned one -- they arrive as lists of spaxel columns from their owners
+    (``column_plan`` / ``exchange_columns``); the rest of the box never influences a kept result.
+
+    Same accessors as ``Tiling`` (tile, extended, halo, balance) so that ``TiledGLR`` takes either.
+    """
+
+    def __init__(self, owner, world, halo, n_areas=None):
+        owner = np.ascontiguousarray(owner).astype(np.int32)
+        if owner.ndim != 2 or owner.min() < 0 or owner.max() >= world:
+            raise ValueError("owner must be a (Ny, Nx) map of ranks 0 .. world - 1")
+        self.owner, self.world, self.halo = owner, int(world), int(halo)
+        self.Ny, self.Nx = owner.shape
+        self.tiles, self._count = [], []
+        for r in range(world):
+            rows = np.flatnonzero((owner == r).any(axis=1))
+            cols = np.flatnonzero((owner == r).any(axis=0))
+            if not len(rows):
+                raise ValueError(f"rank {r} owns no spaxel: fewer areas than ranks?")
+            self.tiles.append(Tile(r, 0, r, int(rows[0]), int(rows[-1]) + 1, int(cols[0]),
+                                   int(cols[-1]) + 1))
+            self._count.append(int(np.count_nonzero(owner == r)))
+        self._areas = list(n_areas) if n_areas is not None else [1] * world
+        self._need = {}
+
+    # -- constructors ------------------------------------------------------------
+    @classmethod
+    def row_bands(cls, Ny, Nx, world, halo):
+        """Bands of whole rows with (almost) the same number of rows each: the partition of the
+        steps that know no areas yet (Preprocessing runs before CreateAreas, origin.py:193-208)."""
+        if world > Ny:
+            raise ValueError(f"{world} ranks for {Ny} rows")
+        owner = np.repeat(np.arange(Ny, dtype=np.int64) * world // Ny, Nx).reshape(Ny, Nx)
+        return cls(owner, world, halo)
+
+    @classmethod
+    def from_areamap(cls, areamap, world, halo):
+        """Areas to ranks as wholes, balanced by spaxel count, compact in space: the labelled
+        areas are split recursively along the longer side of the box of their centroids, at the
+        cut that comes closest to the share of spaxels the ranks on either side stand for
+        (world = 5: 2 + 3 ranks, shares 2/5 and 3/5).  Label 0 (spaxels no exposure covers,
+        steps.py:560-563: cube_faint keeps cube_std there, lib_origin.py:799) goes with the
+        nearest labelled spaxel."""
+        from scipy import ndimage as ndi
+        amap = np.asarray(getattr(areamap, "_data", areamap)).astype(np.int64)
+        labels = np.unique(amap)
+        labels = labels[labels > 0]
+        if len(labels) < world:
+            raise ValueError(f"{len(labels)} areas cannot be spread over {world} ranks")
+        idx = np.arange(1, len(labels) + 1)
+        comp = np.searchsorted(labels, amap) + 1          # labels -> 1 .. n (0 stays 0 below)
+        comp[amap <= 0] = 0
+        size = ndi.sum(np.ones_like(comp), comp, idx)
+        cy, cx = np.array(ndi.center_of_mass(np.ones_like(comp), comp, idx)).T
+        rank_of = np.zeros(len(labels), dtype=np.int32)
+
+        def split(members, r0, nr):
+            if nr == 1:
+                rank_of[members] = r0
+                return
+            nl = nr // 2
+            ys, xs = cy[members], cx[members]
+            key = ys if (ys.max() - ys.min()) >= (xs.max() - xs.min()) else xs
+            order = members[np.argsort(key, kind="stable")]
+            csum = np.cumsum(size[order])
+            want = csum[-1] * nl / nr
+            # at least nl areas left of the cut and nr - nl right of it
+            lo, hi = nl, len(order) - (nr - nl)
+            cut = int(np.argmin(np.abs(csum[lo - 1:hi] - want))) + lo
+            split(order[:cut], r0, nl)
+            split(order[cut:], r0 + nl, nr - nl)
+
+        split(np.arange(len(labels)), 0, world)
+        table = np.concatenate([[0], rank_of])
+        owner = table[comp]
+        if np.any(comp == 0):   # label 0: with the nearest labelled spaxel
+            _, (iy, ix) = ndi.distance_transform_edt(comp == 0, return_indices=True)
+            owner = owner[iy, ix]
+        n_areas = [int(np.count_nonzero(rank_of == r)) for r in range(world)]
+        t = cls(owner, world, halo, n_areas)
+        t.rank_of_label = {int(l): int(r) for l, r in zip(labels, rank_of)}
+        return t
+
+    # -- Tiling's accessors --------------------------------------------------------
+    def tile(self, rank):
+        return self.tiles[rank]
+
+    def extended(self, rank):
+        t, h = self.tiles[rank], self.halo
+        top, bot = min(h, t.y0), min(h, self.Ny - t.y1)
+        left, right = min(h, t.x0), min(h, self.Nx - t.x1)
+        return (t.y0 - top, t.y1 + bot, t.x0 - left, t.x1 + right), (top, bot, left, right)
+
+    def check_halo(self):
+        pass    # (columns come from whoever owns them, however thin a rank's share is)
+
+    def balance(self):
+        """max / mean over the ranks of the owned spaxels (what the areas cost the PCA, to first
+        order), of the areas, and of the extended boxes (what DCT-free stages -- GLR, local
+        maxima -- run on: a box also holds spaxels of other ranks)."""
+        own = np.array(self._count, dtype=float)
+        box = np.array([float((e[1] - e[0]) * (e[3] - e[2]))
+                        for e in (self.extended(r)[0] for r in range(self.world))])
+        ar = np.array(self._areas, dtype=float)
+        return dict(spaxels=float(own.max() / own.mean()), areas=float(ar.max() / ar.mean()),
+                    boxes=float(box.max() / box.mean()),
+                    box_over_owned=float(box.sum() / own.sum()),
+                    owned=[int(v) for v in own], areas_per_rank=[int(v) for v in ar])
+
+    def owned_tile(self, rank):
+        """Bool (ny, nx): the spaxels of the rank's bounding box that are its own."""
+        t = self.tiles[rank]
+        return self.owner[t.y0:t.y1, t.x0:t.x1] == rank
+
+    def owned_ext(self, rank):
+        (y0, y1, x0, x1), _ = self.extended(rank)
+        return self.owner[y0:y1, x0:x1] == rank
+
+    def needed(self, rank):
+        """Bool (Ny, Nx): spaxels of OTHER ranks within ``halo`` of one of this rank's."""
+        got = self._need.get(rank)
+        if got is None:
+            from scipy import ndimage as ndi
+            own = self.owner == rank
+            (y0, y1, x0, x1), _ = self.extended(rank)
+            grown = np.zeros_like(own)
+            k = 2 * self.halo + 1
+            grown[y0:y1, x0:x1] = ndi.maximum_filter(own[y0:y1, x0:x1].astype(np.uint8), size=k,
+                                                     mode="constant", cval=0) > 0
+            got = self._need[rank] = grown & ~own
+        return got
+
+    def local_regions(self, rank, reach, R=64):
+        """Bool array over the R x R regions of the extended box: True where everything the
+        region's GLR reads (the region grown by ``reach``, clipped to the field) is this rank's."""
+        own = self.owned_ext(rank)
+        e_ny, e_nx = own.shape
+        nry, nrx = (e_ny + R - 1) // R, (e_nx + R - 1) // R
+        (y0, y1, x0, x1), _ = self.extended(rank)
+        ok = np.zeros((nry, nrx), bool)
+        for ry in range(nry):
+            a, b = R * ry - reach, min(e_ny, R * ry + R) + reach
+            if (a < 0 and y0 > 0) or (b > e_ny and y1 < self.Ny):
+                continue    # would read beyond the box where the field goes on
+            for rx in range(nrx):
+                c, d = R * rx - reach, min(e_nx, R * rx + R) + reach
+                if (c < 0 and x0 > 0) or (d > e_nx and x1 < self.Nx):
+                    continue
+                ok[ry, rx] = own[max(a, 0):b, max(c, 0):d].all()
+        return ok
+
 
 # ------------------------------------------------------------------------------- comm
 class TileComm:
@@ -299,7 +473,7 @@ class TileComm:
             nr, rp, rb, rl = pack(recvs)
             _capi.call("origin_comm_exchange", self._native, ns, sp, sb, sl, nr, rp, rb, rl)
             return
-        host_recv = [(peer, np.empty(buf.shape, np.float32), buf) for peer, buf in recvs]
+        host_recv = [(peer, np.empty(buf.shape, buf.dtype), buf) for peer, buf in recvs]
         self.group.exchange([(peer, buf.to_host()) for peer, buf in sends],
                             [(peer, h) for peer, h, _ in host_recv])
         for _, h, buf in host_recv:
@@ -360,24 +534,29 @@ def exchange_halo(ctx, comm, tiling, rank, cube, ext=None, bufs=None):
     """Fill the halo of this rank's extended device tile (Nz, ny + top + bot, nx + left + right).
     ``cube``: the bare (Nz, ny, nx) tile, copied into the interior first -- or None when the
     interior of ``ext`` already holds it (the greedy PCA can write there directly).  ``bufs``: a
-    dict the caller keeps between calls so that the strip buffers are allocated once."""
+    dict the caller keeps between calls so that the strip buffers are allocated once.  Any
+    element type (float32 cubes, the uint8 mask); with an ``OwnerTiling`` the halo is the list of
+    spaxel columns of ``column_plan`` instead of strips."""
     t = tiling.tile(rank)
     ny, nx = t.y1 - t.y0, t.x1 - t.x0
     (_, _, _, _), (top, bot, left, right) = tiling.extended(rank)
     Nz = (cube if cube is not None else ext).shape[0]
     eshape = (Nz, ny + top + bot, nx + left + right)
+    dtype = (cube if cube is not None else ext).dtype
     if ext is None:
-        ext = ctx.empty(eshape, np.float32)
+        ext = ctx.zeros(eshape, dtype)
     if cube is not None:
         _copy_box(ctx, ext, eshape, (0, top, left), cube, cube.shape, (0, 0, 0), (Nz, ny, nx))
+    if isinstance(tiling, OwnerTiling):
+        return exchange_columns(ctx, comm, tiling, rank, ext, bufs)
     plan_s, plan_r = halo_plan(tiling, rank)
     sends, recvs, unpack = [], [], []
     for kind, items in (("s", plan_s), ("r", plan_r)):
         for peer, (oy, ox), (by, bx) in items:
-            key = (kind, peer, Nz, by, bx)
+            key = (kind, peer, Nz, by, bx, dtype.str)
             buf = bufs.get(key) if bufs is not None else None
             if buf is None:
-                buf = ctx.empty((Nz, by, bx), np.float32)
+                buf = ctx.empty((Nz, by, bx), dtype)
                 if bufs is not None:
                     bufs[key] = buf
             if kind == "s":   # cut from the interior of ext (tile coordinates + halo offset)
@@ -393,6 +572,63 @@ def exchange_halo(ctx, comm, tiling, rank, cube, ext=None, bufs=None):
     return ext
 
 
+def column_plan(tiling, rank):
+    """The exchange of one rank of an ``OwnerTiling`` as index lists (no data): rank r sends every
+    other rank t the columns of its own spaxels that t needs (``tiling.needed(t)``) and receives
+    from every u the columns u owns among the ones it needs itself.  Returns (sends, recvs): lists
+    of (peer, flat int32 indices into THIS rank's extended box), ordered by peer, indices in C
+    order of the field -- what r sends to t is, column for column, what t receives from r."""
+    (ey0, ey1, ex0, ex1), _ = tiling.extended(rank)
+    e_nx = ex1 - ex0
+    own = tiling.owner == rank
+    mine = tiling.needed(rank)
+    sends, recvs = [], []
+    for other in range(tiling.world):
+        if other == rank:
+            continue
+        ys, xs = np.nonzero(tiling.needed(other) & own)
+        if len(ys):
+            sends.append((other, ((ys - ey0) * e_nx + (xs - ex0)).astype(np.int32)))
+        ys, xs = np.nonzero(mine & (tiling.owner == other))
+        if len(ys):
+            recvs.append((other, ((ys - ey0) * e_nx + (xs - ex0)).astype(np.int32)))
+    return sends, recvs
+
+
+def exchange_columns(ctx, comm, tiling, rank, ext, bufs=None):
+    """Halo exchange of an ``OwnerTiling``: gather the columns the peers need from this rank's
+    extended device tile, exchange, scatter what arrives (origin_gather_columns /
+    origin_scatter_columns).  The owned part of ``ext`` must be in place."""
+    Nz, e_ny, e_nx = ext.shape
+    bufs = {} if bufs is None else bufs
+    plan = bufs.get(("plan", rank))
+    if plan is None:
+        ps, pr = column_plan(tiling, rank)
+        plan = bufs[("plan", rank)] = (
+            [(peer, ctx.to_device(ix)) for peer, ix in ps],
+            [(peer, ctx.to_device(ix)) for peer, ix in pr])
+    es = ext.dtype.itemsize
+    S = e_ny * e_nx
+
+    def packed(kind, peer, n):
+        key = (kind, peer, Nz, n, ext.dtype.str)
+        b = bufs.get(key)
+        if b is None:
+            b = bufs[key] = ctx.empty((Nz, n), ext.dtype)
+        return b
+    sends, recvs = [], []
+    for peer, ix in plan[0]:
+        b = packed("cs", peer, ix.size)
+        _capi.call("origin_gather_columns", ctx.handle, ext.p, Nz, S, ix.p, ix.size, es, b.p)
+        sends.append((peer, b))
+    for peer, ix in plan[1]:
+        recvs.append((peer, packed("cr", peer, ix.size)))
+    comm.exchange(ctx, sends, recvs)
+    for (peer, ix), (_, b) in zip(plan[1], recvs):
+        _capi.call("origin_scatter_columns", ctx.handle, ext.p, Nz, S, ix.p, ix.size, es, b.p)
+    return ext
+
+
 def exchange_halo_host(comm, tiling, rank, tile):
     """Same exchange on host ndarrays (float64 allowed) -- used by the CPU tests to check the
     tiling arithmetic against the untiled oracle."""
@@ -400,6 +636,16 @@ def exchange_halo_host(comm, tiling, rank, tile):
     (_, _, _, _), (top, bot, left, right) = tiling.extended(rank)
     ext = np.zeros((Nz, ny + top + bot, nx + left + right), dtype=tile.dtype)
     ext[:, top: top + ny, left: left + nx] = tile
+    if isinstance(tiling, OwnerTiling):
+        ps, pr = column_plan(tiling, rank)
+        flat = ext.reshape(Nz, -1)
+        sends = [(peer, np.ascontiguousarray(flat[:, ix])) for peer, ix in ps]
+        recvs = [(peer, np.empty((Nz, len(ix)), dtype=tile.dtype)) for peer, ix in pr]
+        if sends or recvs:
+            comm.group.exchange(sends, recvs)
+        for (peer, ix), (_, rbuf) in zip(pr, recvs):
+            flat[:, ix] = rbuf
+        return ext
     plan_s, plan_r = halo_plan(tiling, rank)
     sends = [(peer, np.ascontiguousarray(tile[:, oy: oy + by, ox: ox + bx]))
              for peer, (oy, ox), (by, bx) in plan_s]
@@ -475,9 +721,7 @@ class TiledGLR:
         need = int(np.asarray(psf0).shape[-1]) // 2
         if tiling.halo < need:
             raise ValueError(f"tiling halo {tiling.halo} is smaller than the PSF half width {need}")
-        if tiling.min_tile_side() < tiling.halo:
-            raise ValueError(f"a tile is narrower than the halo {tiling.halo}: a halo must come "
-                             "from the tiles next to this one, not from beyond them")
+        tiling.check_halo()
         (y0, y1, x0, x1), self.halos = tiling.extended(rank)
         self.eshape = (Nz, y1 - y0, x1 - x0)
         wext = None
@@ -487,7 +731,9 @@ class TiledGLR:
         self.plan = kernels.GLRPlan(ctx, self.eshape, PSF, wext, profiles, pcut, pmeansub)
         t = tiling.tile(rank)
         self.shape = (Nz, t.y1 - t.y0, t.x1 - t.x0)
-        self.ext = ctx.empty(self.eshape, np.float32)
+        # (zeros: with an OwnerTiling the box also holds spaxels that are neither this rank's nor
+        # needed by it; nothing kept depends on them, but they should not be NaN patterns)
+        self.ext = ctx.zeros(self.eshape, np.float32)
         self.emask = ctx.zeros(self.eshape, np.uint8)
         self.out = dict(correl=ctx.empty(self.eshape, np.float32),
                         correl_min=ctx.empty(self.eshape, np.float32),
@@ -506,11 +752,15 @@ class TiledGLR:
         return (self.ext, top, left)
 
     def _set_mask(self, mask):
-        if mask is not None and not self._mask_set:  # halo spaxels are discarded: mask 0 there
-            top, _, left, _ = self.halos
-            Nz, ny, nx = self.shape
-            _copy_box(self.ctx, self.emask, self.eshape, (0, top, left), mask, mask.shape,
-                      (0, 0, 0), (Nz, ny, nx))
+        """The mask of the extended tile, made once: this rank's part copied in, the halo
+        exchanged like the halo of the cube (COLLECTIVE: every rank passes a mask, or none
+        does).  The halo's results are discarded, but the 3x3x3 local maxima of the tile's edge
+        spaxels compare them with their neighbours beyond it, and ``correl[mask] = 0``
+        (steps.py:781) holds there too: with mask 0 in the halo a masked voxel next to an
+        internal cut kept its T_GLR and could out-rank a true local maximum on the edge row."""
+        if mask is not None and not self._mask_set:
+            exchange_halo(self.ctx, self.comm, self.tiling, self.rank, mask, self.emask,
+                          self._strips)
             self._mask_set = True
         return self.emask if mask is not None else None
 
@@ -522,6 +772,7 @@ class TiledGLR:
         on an untiled field).  ``area_boxes[a]`` = (ymin, ymax, xmin, xmax) of area ``a`` in TILE
         coordinates, inclusive; ``early_budget``: voxels of GLR started that way at most.  The
         next ``run(None, ...)`` finishes the step."""
+        self._set_mask(mask)   # (collective: here, on every rank, not inside the hook)
         if not self.plan.rows_supported():
             return None
         top, _, left, _ = self.halos
@@ -529,7 +780,7 @@ class TiledGLR:
         reach = self.plan.P // 2
 
         def hook(areas):
-            ok = interior_regions(e_ny, e_nx, self.halos, reach)
+            ok = self.tiling.local_regions(self.rank, reach)
             for a in areas:
                 if area_boxes[a] is None:
                     continue
@@ -586,7 +837,7 @@ class TiledGLR:
                 and (done is not None
                      or os.environ.get("ORIGIN_TILED_INTERIOR_FIRST", "1") != "0")):
             e_ny, e_nx = self.eshape[1:]
-            ok = interior_regions(e_ny, e_nx, self.halos, self.plan.P // 2)
+            ok = self.tiling.local_regions(self.rank, self.plan.P // 2)
             if os.environ.get("ORIGIN_TILED_INTERIOR_FIRST", "1") == "0":
                 ok[:] = False                 # (only what the hook started runs ahead)
             if done is not None:
@@ -633,7 +884,10 @@ class TiledGLR:
                       (0, top, left), (1, ny, nx))
         res = dict(correl=correl, profile=profile, correl_min=correl_min,
                    maxmap=self.maps["maxmap"], minmap=self.maps["minmap"],
-                   box=(top, left, ny, nx) if not crop else (0, 0, ny, nx))
+                   box=(top, left, ny, nx) if not crop else (0, 0, ny, nx),
+                   # OwnerTiling: which spaxels of the box are this rank's (None: all of them)
+                   owned=(None if self.tiling.owned_ext(self.rank) is None else
+                          self.tiling.owned_ext(self.rank)[top:top + ny, left:left + nx]))
         if local_max is not None and local_max is not False:
             need = self.plan.P // 2 + int(size) // 2
             if self.tiling.halo < need:

@@ -89,6 +89,13 @@ def greedy_pca(ctx, cube_std, areamap, nbAreas, thresholds, testO2, Noise_popula
     spx = area_lists(areamap, nbAreas) if spx is None else spx
     if into is not None:
         drv = driver or GreedyPCA(ctx)
+        if sum(len(s) for s in spx) < Ny * Nx:
+            # spaxels outside every area keep their cube_std values (:799): the box first, the
+            # areas over it
+            from .multigpu import _copy_box
+            ext, top, left = into
+            _copy_box(ctx, ext, ext.shape, (0, top, left), cube_std, cube_std.shape, (0, 0, 0),
+                      (Nz, Ny, Nx))
         hmap, nstop = drv.run(None, spx, testO2, [float(t) for t in thresholds],
                               Noise_population, itermax, test_map=o2_dev, src=cube_std,
                               want_map="full", into=into)

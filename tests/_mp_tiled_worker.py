@@ -22,7 +22,42 @@ sys.path.insert(0, ROOT)
 from origin_amd import multigpu, synth  # noqa: E402
 
 
+def areas_field():
+    """A field cut into IRREGULAR areas: the area map the reference's own CreateAreas functions
+    made for golden G10 ("many": 132 x 150 spaxels, five areas out of squares, sources, convex
+    hulls and growing, label 0 where no exposure covers the field; tests/golden/g10_areas.npz)."""
+    G = np.load(os.path.join(ROOT, "tests", "golden", "g10_areas.npz"))
+    amap = G["many_areamap"].astype(int)
+    Ny, Nx = amap.shape
+    f = synth.SyntheticField(64, Ny, Nx, seed=8, psf_size=9, nprof=3, blob_density=1 / 300,
+                             emitter_density=1 / 900, area_size=50)
+    raw, var, mask = f.arrays()
+    mask[:, amap == 0] = True          # unexposed spaxels: masked in every channel
+    mask[5:9, 60, 70] = True
+    # a masked spaxel right next to a cut between two areas (the 3x3x3 local maxima of the
+    # neighbouring rank's edge spaxels look at it)
+    ys, xs = np.nonzero((amap[:, :-1] != amap[:, 1:]) & (amap[:, :-1] > 0) & (amap[:, 1:] > 0))
+    k = len(ys) // 2
+    mask[:, ys[k], xs[k]] = True
+    mask[20:40, ys[k // 2], xs[k // 2] + 1] = True
+    raw[mask] = 0
+    var[mask] = np.inf
+    f.areamap, f.nbAreas = amap, int(amap.max())
+    return f, raw, var, mask
+
+
+def make_tiling(f, world, Ny, Nx):
+    # (+1: the 3x3x3 local maxima of the tile look one spaxel beyond it)
+    halo = f.PSF.shape[1] // 2 + 1
+    kind = os.environ.get("TILED_FIELD")
+    if kind == "areas":
+        return multigpu.OwnerTiling.from_areamap(f.areamap, world, halo)
+    return multigpu.Tiling(Ny, Nx, world, halo=halo, area_size=50 if kind == "big" else 20)
+
+
 def field():
+    if os.environ.get("TILED_FIELD") == "areas":
+        return areas_field()
     if os.environ.get("TILED_FIELD") == "big":
         # tiles wide enough for 64 x 64 regions that need no halo data (TiledGLR runs those on
         # the side stream while the strips travel)
@@ -46,6 +81,12 @@ def field():
     raw, var, mask = f.arrays()
     mask[10:14, 3, 7] = True
     mask[:, 25, 41] = True
+    # masked voxels in the one-spaxel ring just outside a tile (the two-rank tiling cuts the 40
+    # rows at 20, the four-rank one also the 60 columns at 40 / 20): correl[mask] = 0 must hold in
+    # the halo too, or the local maxima of the tile's edge row see the wrong neighbours
+    mask[:, 20, 10:30] = True
+    mask[30:60, 19, 45] = True
+    mask[:, 5:9, 40] = True
     raw[mask] = 0
     var[mask] = np.inf
     return f, raw, var, mask
@@ -73,34 +114,45 @@ def main():
                               backend="rccl" if mode == "rccl" else "host", group=group)
     f, raw, var, mask = field()
     Nz, Ny, Nx = raw.shape
-    # (+1: the 3x3x3 local maxima of the tile look one spaxel beyond it)
-    tiling = multigpu.Tiling(Ny, Nx, world, halo=f.PSF.shape[1] // 2 + 1,
-                             area_size=50 if os.environ.get("TILED_FIELD") == "big" else 20)
+    tiling = make_tiling(f, world, Ny, Nx)
     t = tiling.tile(rank)
     sl = (slice(None), slice(t.y0, t.y1), slice(t.x0, t.x1))
     traw, tvar, tmask = raw[sl], var[sl], mask[sl]
     amap = f.areamap[t.y0:t.y1, t.x0:t.x1]
-    labels = np.unique(amap)
-    lmap = np.searchsorted(labels, amap) + 1
+    owned = None
+    if isinstance(tiling, multigpu.OwnerTiling):
+        # the rank works on the bounding box of its areas; the spaxels of the box that belong to
+        # other ranks count as masked in the DCT stage (they stay out of the per-channel sums
+        # that are reduced over the ranks, and what is computed there is discarded) and carry
+        # label 0 (in no area of this rank)
+        owned = tiling.owned_tile(rank)
+        amap = np.where(owned, amap, 0)
+        dmask = tmask | ~owned[None]
+    else:
+        dmask = tmask
+    labels = np.unique(amap[amap > 0]) if owned is not None else np.unique(amap)
+    lmap = np.where(amap > 0, np.searchsorted(labels, amap) + 1, 0) if owned is not None \
+        else np.searchsorted(labels, amap) + 1
     res = {}
     if mode == "cpu":
         from oracle import cpu_ref
         r64, v64 = traw.astype(float), tvar.astype(float)
-        cont = cpu_ref.dct_residual(r64, 10, v64, False, tmask)
+        cont = cpu_ref.dct_residual(r64, 10, v64, False, dmask)
         data = r64 - cont
-        data[tmask] = np.nan
+        data[dmask] = np.nan
         both = comm.allreduce_sum(np.concatenate([np.nansum(data, axis=(1, 2)),
-                                                  np.sum(~tmask, axis=(1, 2)).astype(float)]))
+                                                  np.sum(~dmask, axis=(1, 2)).astype(float)]))
         mean = both[:Nz] / both[Nz:]
-        data = (data - mean[:, None, None]) / np.sqrt(v64)
-        data[tmask] = 0
+        with np.errstate(invalid="ignore"):
+            data = (data - mean[:, None, None]) / np.sqrt(v64)
+        data[dmask] = 0
         thr = cpu_ref.pca_threshold_areas(data, lmap, len(labels), 0.01)
         faint, mapO2, nstop = cpu_ref.Compute_GreedyPCA_area(len(labels), data, lmap, 50, thr[3],
                                                              100, thr[0])
         ext = multigpu.exchange_halo_host(comm, tiling, rank, faint)
         (_, _, _, _), (top, bot, left, right) = tiling.extended(rank)
-        emask = np.zeros(ext.shape, bool)
-        emask[:, top:top + tmask.shape[1], left:left + tmask.shape[2]] = tmask
+        # the TRUE mask over the extended tile: this rank's part, the halo from its owners
+        emask = multigpu.exchange_halo_host(comm, tiling, rank, tmask.astype(np.uint8)) > 0
         psf_, wts_ = (f.PSF.astype(float), None)
         if weighted:
             psf_, wfull = mosaic(f)
@@ -119,13 +171,14 @@ def main():
         ctx = Context(rank if mode == "rccl" else 0)
         d_raw, d_var = ctx.to_device(traw, np.float32), ctx.to_device(tvar, np.float32)
         d_mask = ctx.to_device(tmask.astype(np.uint8))
+        d_dmask = d_mask if owned is None else ctx.to_device(dmask.astype(np.uint8))
         if mode == "rccl":
             comm.attach(ctx)  # RCCL communicator on this context (collective)
             assert comm.backend == "rccl", (comm.backend, comm.note)
-            pre = pipeline.preprocess(ctx, d_raw, d_var, d_mask, 10, False,
+            pre = pipeline.preprocess(ctx, d_raw, d_var, d_dmask, 10, False,
                                       allreduce_dev=comm.allreduce_sum_device)
         else:
-            pre = pipeline.preprocess(ctx, d_raw, d_var, d_mask, 10, False,
+            pre = pipeline.preprocess(ctx, d_raw, d_var, d_dmask, 10, False,
                                       allreduce=comm.allreduce_sum)
         spx = pipeline.area_lists(lmap, len(labels))
         thr = pipeline.pca_threshold(pre["o2"].to_host(), lmap, len(labels), 0.01, spx=spx)
@@ -186,6 +239,8 @@ def main():
                    local_max=lm[0].to_host(), local_min=lm[1].to_host(),
                    n_early=n_early,   # rectangles run ahead of the halo exchange
                    n_hook=n_hook)     # regions the tail hook started
+    if owned is not None:
+        res["owned"] = owned
     np.savez(f"{out}.rank{rank}.npz", y0=t.y0, y1=t.y1, x0=t.x0, x1=t.x1, **res)
     comm.barrier()
     comm.close()

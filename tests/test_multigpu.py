@@ -25,13 +25,15 @@ def free_port():
     return p
 
 
-def run_ranks(mode, world, out, weighted=False, group="rdv"):
+def run_ranks(mode, world, out, weighted=False, group="rdv", field=None):
     port = free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0",
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2",
                    TILED_WEIGHTS="1" if weighted else "0", TILED_GROUP=group)
+        if field is not None:
+            env["TILED_FIELD"] = field
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests",
                                                                     "_mp_tiled_worker.py"),
                                        mode, out], env=env, stdout=subprocess.PIPE,
@@ -46,13 +48,21 @@ def run_ranks(mode, world, out, weighted=False, group="rdv"):
 
 
 def stitch(tiles, key, shape):
+    """The field from its tiles; tiles of an OwnerTiling are bounding boxes that carry an
+    ``owned`` map: only those spaxels are the tile's."""
     full = np.zeros(shape, dtype=tiles[0][key].dtype)
     for t in tiles:
         sl = (slice(int(t["y0"]), int(t["y1"])), slice(int(t["x0"]), int(t["x1"])))
+        own = t["owned"] if "owned" in t.files else None
         if len(shape) == 3:
-            full[(slice(None),) + sl] = t[key]
-        else:
+            if own is None:
+                full[(slice(None),) + sl] = t[key]
+            else:
+                full[(slice(None),) + sl][:, own] = t[key][:, own]
+        elif own is None:
             full[sl] = t[key]
+        else:
+            full[sl][own] = t[key][own]
     return full
 
 
@@ -130,7 +140,77 @@ def test_tiled_oracle_equals_untiled_oracle(tmp_path, world, group):
     lmax, lmin = cpu_ref.compute_local_max(ref["cube_correl"], ref["cube_correl_min"], mask, 3)
     for key, want in (("local_max", lmax), ("local_min", lmin)):
         got = stitch(tiles, key, shape)
-        assert np.mean((got != 0) != (want != 0)) <= 1e-5, key
+        # exactly the same voxels (the field has masked voxels in the ring just outside a tile:
+        # the halo carries the true mask, so correl[mask] = 0 holds there as well)
+        assert np.array_equal(got != 0, want != 0), key
+        assert np.max(np.abs(got - want)[(got != 0) & (want != 0)]) <= 1e-9, key
+
+
+def test_owner_tiling_hands_whole_areas_to_ranks():
+    """OwnerTiling on the reference-made irregular area map of golden G10: areas are never
+    split, label 0 goes with its nearest area, the column plan of every rank is the mirror of its
+    peers' and rebuilds exactly the spaxels the rank needs."""
+    from origin_amd.multigpu import OwnerTiling, column_plan
+    G = np.load(os.path.join(ROOT, "tests", "golden", "g10_areas.npz"))
+    amap = G["many_areamap"].astype(int)
+    Ny, Nx = amap.shape
+    for world in (1, 2, 3, 4, 5):
+        tl = OwnerTiling.from_areamap(amap, world, halo=5)
+        assert tl.owner.shape == amap.shape and set(np.unique(tl.owner)) == set(range(world))
+        for lab in range(1, amap.max() + 1):
+            assert len(np.unique(tl.owner[amap == lab])) == 1       # an area lives on ONE rank
+        bal = tl.balance()
+        assert sum(bal["owned"]) == Ny * Nx and sum(bal["areas_per_rank"]) == amap.max()
+        field = np.arange(Ny * Nx, dtype=np.float64).reshape(Ny, Nx)
+        plans = [column_plan(tl, r) for r in range(world)]
+        for r in range(world):
+            (ey0, ey1, ex0, ex1), _ = tl.extended(r)
+            t = tl.tile(r)
+            assert np.all(tl.owner[t.y0:t.y1, t.x0:t.x1][tl.owned_tile(r)] == r)
+            ext = np.where(tl.owned_ext(r), field[ey0:ey1, ex0:ex1], -1.0).reshape(-1)
+            for peer, ix in plans[r][1]:
+                match = [s_ for s_ in plans[peer][0] if s_[0] == r]
+                assert len(match) == 1 and len(match[0][1]) == len(ix)
+                (py0, py1, px0, px1), _ = tl.extended(peer)
+                sent = field[py0:py1, px0:px1].reshape(-1)[match[0][1]]   # the peer's columns
+                ext[ix] = sent
+            ext = ext.reshape(ey1 - ey0, ex1 - ex0)
+            need = tl.needed(r)[ey0:ey1, ex0:ex1] | tl.owned_ext(r)
+            assert np.array_equal(ext[need], field[ey0:ey1, ex0:ex1][need])
+            assert np.all(ext[~need] == -1.0)
+            # every spaxel within the halo of an owned one is there
+            ys, xs = np.nonzero(tl.owner == r)
+            for dy, dx in ((-5, -5), (5, 5), (-5, 5), (0, 5), (5, 0)):
+                yy, xx = np.clip(ys + dy, 0, Ny - 1), np.clip(xs + dx, 0, Nx - 1)
+                assert np.all(need[yy - ey0, xx - ex0])
+    with pytest.raises(ValueError):
+        OwnerTiling.from_areamap(amap, 6, halo=5)
+    rb = OwnerTiling.row_bands(40, 60, 3, 1)
+    assert [t.y1 - t.y0 for t in rb.tiles] == [14, 13, 13] and rb.owned_tile(1).all()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_tiled_oracle_on_irregular_areas_equals_untiled_oracle(tmp_path, world):
+    """The chain on an IRREGULAR area map (reference steps.py:492-569; golden G10's "many" map):
+    areas go to ranks as wholes, a rank works on the bounding box of its areas, the halo is a
+    list of spaxel columns -- stitched by ownership, the result is the untiled oracle's."""
+    from _mp_tiled_worker import areas_field
+    from oracle import cpu_ref
+    f, raw, var, mask = areas_field()
+    tiles = run_ranks("cpu", world, str(tmp_path / "cpua"), field="areas")
+    ref = cpu_ref.run_chain(raw.astype(float), var.astype(float), mask, f.PSF.astype(float), None,
+                            f.profiles, f.areamap, f.nbAreas)
+    shape = raw.shape
+    for key, rk in (("cube_std", "cube_std"), ("cube_faint", "cube_faint"),
+                    ("correl", "cube_correl"), ("correl_min", "cube_correl_min")):
+        got = stitch(tiles, key, shape)
+        assert np.max(np.abs(got - ref[rk])) <= 1e-9 * max(1.0, np.max(np.abs(ref[rk]))), key
+    assert np.array_equal(stitch(tiles, "mapO2", shape[1:]), ref["mapO2"])
+    assert np.max(np.abs(stitch(tiles, "maxmap", shape[1:]) - ref["maxmap"])) <= 1e-9
+    lmax, lmin = cpu_ref.compute_local_max(ref["cube_correl"], ref["cube_correl_min"], mask, 3)
+    for key, want in (("local_max", lmax), ("local_min", lmin)):
+        got = stitch(tiles, key, shape)
+        assert np.array_equal(got != 0, want != 0), key
         assert np.max(np.abs(got - want)[(got != 0) & (want != 0)]) <= 1e-9, key
 
 
@@ -190,6 +270,34 @@ def test_tiled_hip_equals_single_hip(tmp_path, world):
     # and against the oracle
     ref = cpu_ref.run_chain(raw.astype(float), var.astype(float), mask, f.PSF.astype(float), None,
                             f.profiles, f.areamap, f.nbAreas)
+    assert np.max(np.abs(stitch(tiles, "correl", shape) - ref["cube_correl"])) <= 2e-4
+    assert np.max(np.abs(stitch(tiles, "maxmap", shape[1:]) - ref["maxmap"])) <= 2e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_tiled_hip_on_irregular_areas(tmp_path, world):
+    """Irregular areas (golden G10's reference-made map) through the HIP path: areas to ranks as
+    wholes (OwnerTiling), bounding boxes, column-list halo (origin_gather_columns /
+    origin_scatter_columns), the true mask in the halo; against one rank and the oracle."""
+    from _mp_tiled_worker import areas_field
+    from oracle import cpu_ref
+    f, raw, var, mask = areas_field()
+    tiles = run_ranks("gpu", world, str(tmp_path / "gpua"), field="areas")
+    single = run_ranks("gpu", 1, str(tmp_path / "onea"), field="areas")
+    shape = raw.shape
+    for key, tol in (("cube_std", 1e-6), ("cube_faint", 1e-5), ("correl", 1e-4),
+                     ("correl_min", 1e-4)):
+        got, one = stitch(tiles, key, shape), stitch(single, key, shape)
+        assert np.max(np.abs(got - one)) <= tol, key
+    assert np.array_equal(stitch(tiles, "mapO2", shape[1:]), stitch(single, "mapO2", shape[1:]))
+    for key in ("local_max", "local_min"):   # (support can differ only where fp32 rounding ties)
+        got, one = stitch(tiles, key, shape), stitch(single, key, shape)
+        assert np.mean((got != 0) != (one != 0)) <= 1e-4, key
+    ref = cpu_ref.run_chain(raw.astype(float), var.astype(float), mask, f.PSF.astype(float), None,
+                            f.profiles, f.areamap, f.nbAreas)
+    assert np.array_equal(stitch(tiles, "mapO2", shape[1:]), ref["mapO2"])
+    assert np.max(np.abs(stitch(tiles, "cube_faint", shape) - ref["cube_faint"])) <= 1e-4
     assert np.max(np.abs(stitch(tiles, "correl", shape) - ref["cube_correl"])) <= 2e-4
     assert np.max(np.abs(stitch(tiles, "maxmap", shape[1:]) - ref["maxmap"])) <= 2e-4
 
