@@ -418,6 +418,40 @@ int origin_local_max(origin_ctx *ctx, const float *d_correl, const float *d_corr
                      const uint8_t *d_mask, int Nz, int Ny, int Nx, int size,
                      float *d_local_max, float *d_local_min);
 
+/* Sparse form of the same pass (size 3, Nx % 4 == 0): the two cubes are > 98 % zeros, and the
+ * consumers of cube_local_max / cube_local_min (Compute_threshold_purity lib_origin.py:1391-1479,
+ * Detection.run steps.py:935-974) only ever count or pick the non-zero voxels.  Instead of two
+ * dense float32 cubes (8 of the pass's 17 B per voxel) the pass appends (linear index z*Ny*Nx +
+ * y*Nx + x, value) of every non-zero output to per-wave segments: segment w of `seg_cap` entries
+ * starts at w * seg_cap in idx / val, counts[w] (maxima of correl) and counts[nseg + w] (maxima of
+ * -correl_min) say how many it holds.  A count above seg_cap means the segment overflowed (entries
+ * beyond it were dropped): use the dense form.  origin_local_max_sparse_plan gives nseg and seg_cap
+ * for a shape (nseg 0: no sparse form for it); order inside and across segments is the march order
+ * of the waves, not np.where's -- consumers that need an order sort what they keep.  The values are
+ * bit for bit those of origin_local_max. */
+int origin_local_max_sparse_plan(origin_ctx *ctx, int Nz, int Ny, int Nx, long *nseg, int *seg_cap);
+int origin_local_max_sparse(origin_ctx *ctx, const float *d_correl, const float *d_correl_min,
+                            const uint8_t *d_mask, int Nz, int Ny, int Nx, long nseg, int seg_cap,
+                            long long *d_idx_max, float *d_val_max, long long *d_idx_min,
+                            float *d_val_min, int *d_counts);
+/* consumers: the dense cube of n voxels (zeros + entries); counts above each of nthr thresholds
+ * (origin_count_above's contract; keep: uint8 per spaxel, 0 = excluded, or NULL); the entries
+ * above a threshold in no particular order (the first `cap`; *h_count = how many there are; aux:
+ * a uint8 cube gathered at the hits, or NULL); per-spaxel maximum over z, 0 where a column has no
+ * positive entry (the dense cube's columns always hold zeros). */
+int origin_sparse_to_dense(origin_ctx *ctx, const long long *d_idx, const float *d_val,
+                           const int *d_counts, long nseg, int seg_cap, float *d_dense, long n);
+int origin_sparse_count_above(origin_ctx *ctx, const long long *d_idx, const float *d_val,
+                              const int *d_counts, long nseg, int seg_cap, const uint8_t *d_keep,
+                              long S, int nthr, const double *h_thr, long *h_counts);
+int origin_sparse_where_above(origin_ctx *ctx, const long long *d_idx, const float *d_val,
+                              const int *d_counts, long nseg, int seg_cap, double threshold,
+                              const uint8_t *d_aux, long cap, long long *d_out_idx,
+                              float *d_out_val, uint8_t *d_out_aux, long *h_count);
+int origin_sparse_zmax_map(origin_ctx *ctx, const long long *d_idx, const float *d_val,
+                           const int *d_counts, long nseg, int seg_cap, const uint8_t *d_keep,
+                           long S, float *d_map);
+
 #ifdef __cplusplus
 }
 #endif

@@ -95,6 +95,13 @@ SIGNATURES = {
     "origin_glr_run_finish": [vp, vp, vp, vp, vp],
     "origin_pca_set_tail_hook": [vp, vp, vp, i32],
     "origin_local_max": [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp],
+    "origin_local_max_sparse_plan": [vp, i32, i32, i32, PP(i64), PP(i32)],
+    "origin_local_max_sparse": [vp, vp, vp, vp, i32, i32, i32, i64, i32, vp, vp, vp, vp, vp],
+    "origin_sparse_to_dense": [vp, vp, vp, vp, i64, i32, vp, i64],
+    "origin_sparse_count_above": [vp, vp, vp, vp, i64, i32, vp, i64, i32, vp, vp],
+    "origin_sparse_where_above": [vp, vp, vp, vp, i64, i32, C.c_double, vp, i64, vp, vp, vp,
+                                  PP(i64)],
+    "origin_sparse_zmax_map": [vp, vp, vp, vp, i64, i32, vp, i64, vp],
 }
 _RESTYPE = {"origin_last_error": C.c_char_p}
 

@@ -2,7 +2,9 @@
 // filter, keep voxels equal to their window maximum and not masked, zero elsewhere; the
 // same on -correl_min.  scipy's default border mode 'reflect' duplicates edge samples,
 // which for a maximum is the same as clamping the window to the cube.
+#include <algorithm>
 #include <cstdlib>
+#include <vector>
 #include "common.h"
 
 namespace {
@@ -124,13 +126,29 @@ __device__ __forceinline__ float wave_from_next(float v) {  // lane i gets lane 
                                                     0xF, 0xF, false));  // wave_shl:1
 }
 
-template <int NC, int R>
+// SPARSE (round 4): the two output cubes are > 98 % zeros (a voxel in ~70 of a smoothed cube is a
+// 3x3x3 maximum), and writing them dense is half of the pass's traffic (17 B per voxel: 9 in, 8
+// out).  The sparse form writes (linear index, value) pairs of the non-zero outputs instead: every
+// wave owns a segment of `seg_cap` entries per cube in idx0 / val0 (maxima of a0) and idx1 / val1
+// (maxima of -a1) and appends to it -- a wave-uniform counter, ballot + mbcnt for the lanes' slots,
+// no atomics, no second pass; the number of entries of wave w ends up in counts[w] (cube 0) and
+// counts[nwaves + w] (cube 1), entries beyond the capacity are counted but not stored (the host
+// sees counts > seg_cap and falls back to the dense form).  9 B per voxel read, ~0.4 B written.
+struct LmSparse {
+  long long *idx0, *idx1;
+  float *val0, *val1;
+  int *counts;
+  int seg_cap;
+};
+
+template <int NC, int R, bool SPARSE = false>
 __global__ __launch_bounds__(256) void local_max3v_kernel(const float *__restrict__ a0,
                                                           const float *__restrict__ a1,
                                                           const uint8_t *__restrict__ mask, int Nz,
                                                           int Ny, int Nx, int zper, float sign0,
                                                           float *__restrict__ out0,
-                                                          float *__restrict__ out1) {
+                                                          float *__restrict__ out1,
+                                                          LmSparse sp = LmSparse()) {
   // Waves overlap by two lanes: wave w holds the flattened (row group, float4 column) indices
   // 62 w - 1 .. 62 w + 62; lanes 1..62 produce outputs, lanes 0 and 63 only hand their samples to
   // their neighbours -- no lane ever loads a halo sample (a conditional 4-byte load per row and
@@ -186,9 +204,18 @@ __global__ __launch_bounds__(256) void local_max3v_kernel(const float *__restric
     plane(a1, -1.0f, z0 - 1, pa[1], dummy);
     plane(a1, -1.0f, z0, pb[1], cb[1]);
   }
+  // sparse form: this wave's segments and how many entries they hold so far (wave-uniform)
+  const long wave_id = ((long)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const long seg = SPARSE ? wave_id * sp.seg_cap : 0;
+  int cnt[NC];
+#pragma unroll
+  for (int q = 0; q < NC; ++q) cnt[q] = 0;
   for (int z = z0; z < z1; ++z) {
     plane(a0, sign0, z + 1, pc[0], cc[0]);
     if constexpr (NC == 2) plane(a1, -1.0f, z + 1, pc[1], cc[1]);
+    unsigned km[NC];   // SPARSE: bit 4 r + e = output (r, e) of this lane is a non-zero maximum
+#pragma unroll
+    for (int q = 0; q < NC; ++q) km[q] = 0u;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int y = yb + r;
@@ -202,11 +229,15 @@ __global__ __launch_bounds__(256) void local_max3v_kernel(const float *__restric
           for (int e = 0; e < 4; ++e) {
             const float m = fmaxf(fmaxf(pa[q][r][e], pb[q][r][e]), pc[q][r][e]);
             const bool unmasked = ((mk >> (8 * e)) & 0xffu) == 0u;
-            o[q][e] = (cb[q][r][e] == m && unmasked) ? m : 0.0f;  // local_max *= local_mask (lib :1247)
+            const bool keep = cb[q][r][e] == m && unmasked;     // local_max *= local_mask (lib :1247)
+            o[q][e] = keep ? m : 0.0f;
+            if constexpr (SPARSE) km[q] |= (keep && m != 0.0f) ? (1u << (4 * r + e)) : 0u;
           }
-        *reinterpret_cast<float4 *>(out0 + idx) = make_float4(o[0][0], o[0][1], o[0][2], o[0][3]);
-        if constexpr (NC == 2)
-          *reinterpret_cast<float4 *>(out1 + idx) = make_float4(o[1][0], o[1][1], o[1][2], o[1][3]);
+        if constexpr (!SPARSE) {
+          *reinterpret_cast<float4 *>(out0 + idx) = make_float4(o[0][0], o[0][1], o[0][2], o[0][3]);
+          if constexpr (NC == 2)
+            *reinterpret_cast<float4 *>(out1 + idx) = make_float4(o[1][0], o[1][1], o[1][2], o[1][3]);
+        }
       }
 #pragma unroll
       for (int q = 0; q < NC; ++q)
@@ -214,6 +245,125 @@ __global__ __launch_bounds__(256) void local_max3v_kernel(const float *__restric
         for (int e = 0; e < 4; ++e)
           pa[q][r][e] = pb[q][r][e], pb[q][r][e] = pc[q][r][e], cb[q][r][e] = cc[q][r][e];
     }
+    if constexpr (SPARSE) {
+      // append the lanes' maxima of this channel to the wave's segments: one round per entry of
+      // the busiest lane (usually one or two); the value is read back from the cube (the line is
+      // in cache: this lane loaded it a channel ago)
+      const long zbase = (long)z * S + (long)yb * Nx + 4 * x4;
+#pragma unroll
+      for (int q = 0; q < NC; ++q) {
+        unsigned m = km[q];
+        const float *src = q == 0 ? a0 : a1;
+        const float sg = q == 0 ? sign0 : -1.0f;
+        long long *ix = q == 0 ? sp.idx0 : sp.idx1;
+        float *vl = q == 0 ? sp.val0 : sp.val1;
+        for (;;) {
+          const unsigned long long bal = __ballot(m != 0u);
+          if (bal == 0ull) break;
+          if (m != 0u) {
+            const int b = __builtin_ctz(m);
+            m &= m - 1u;
+            const long at = zbase + (long)(b >> 2) * Nx + (b & 3);
+            const int slot = cnt[q] + (int)__builtin_amdgcn_mbcnt_hi(
+                                          (unsigned)(bal >> 32),
+                                          __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+            if (slot < sp.seg_cap) {
+              ix[seg + slot] = at;
+              vl[seg + slot] = sg * src[at];
+            }
+          }
+          cnt[q] += __popcll(bal);
+        }
+      }
+    }
+  }
+  if constexpr (SPARSE) {
+    if (lane == 0) {
+      const long nwaves = (long)gridDim.x * gridDim.y * 4;
+#pragma unroll
+      for (int q = 0; q < NC; ++q) sp.counts[q * nwaves + wave_id] = cnt[q];
+    }
+  }
+}
+
+// ---- consumers of the sparse form ------------------------------------------------------------
+// one block per segment; entries beyond the capacity were never stored
+__global__ __launch_bounds__(256) void sparse_to_dense_kernel(const long long *__restrict__ idx,
+                                                              const float *__restrict__ val,
+                                                              const int *__restrict__ counts,
+                                                              int seg_cap, float *__restrict__ dense) {
+  const long seg = (long)blockIdx.x * seg_cap;
+  const int n = min(counts[blockIdx.x], seg_cap);
+  for (int i = threadIdx.x; i < n; i += 256) dense[idx[seg + i]] = val[seg + i];
+}
+
+// hist[b] += 1 for every kept entry whose value exceeds exactly the b + 1 smallest thresholds
+__global__ __launch_bounds__(256) void sparse_count_above_kernel(
+    const long long *__restrict__ idx, const float *__restrict__ val, const int *__restrict__ counts,
+    long nseg, int seg_cap, const uint8_t *__restrict__ keep, long S, int nthr,
+    const double *__restrict__ thr, unsigned long long *__restrict__ hist) {
+  __shared__ double sthr[1024];
+  __shared__ unsigned shist[1024];
+  for (int i = threadIdx.x; i < nthr; i += 256) sthr[i] = thr[i], shist[i] = 0u;
+  __syncthreads();
+  const double t0 = sthr[0];
+  for (long sgi = blockIdx.x; sgi < nseg; sgi += gridDim.x) {
+    const long seg = sgi * seg_cap;
+    const int n = min(counts[sgi], seg_cap);
+    for (int i = threadIdx.x; i < n; i += 256) {
+      const double v = (double)val[seg + i];
+      if (!(v > t0)) continue;
+      if (keep && !keep[idx[seg + i] % S]) continue;
+      int lo = 0, hi = nthr;                   // number of thresholds < v
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (sthr[mid] < v) lo = mid + 1;
+        else hi = mid;
+      }
+      atomicAdd(&shist[lo - 1], 1u);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nthr; i += 256)
+    if (shist[i]) atomicAdd(&hist[i], (unsigned long long)shist[i]);
+}
+
+// entries above the threshold, appended in any order (the host sorts the few that come back)
+__global__ __launch_bounds__(256) void sparse_where_above_kernel(
+    const long long *__restrict__ idx, const float *__restrict__ val, const int *__restrict__ counts,
+    int seg_cap, double thr, const uint8_t *__restrict__ aux, long cap,
+    long long *__restrict__ out_idx, float *__restrict__ out_val, uint8_t *__restrict__ out_aux,
+    unsigned long long *__restrict__ total) {
+  const long seg = (long)blockIdx.x * seg_cap;
+  const int n = min(counts[blockIdx.x], seg_cap);
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float v = val[seg + i];
+    if (!((double)v > thr)) continue;
+    const unsigned long long at = atomicAdd(total, 1ull);
+    if ((long)at < cap) {
+      const long long ii = idx[seg + i];
+      out_idx[at] = ii;
+      out_val[at] = v;
+      if (aux) out_aux[at] = aux[ii];
+    }
+  }
+}
+
+// map[s] = max(map[s], v) for the POSITIVE entries (the map starts at 0: every column of a
+// local-maximum cube holds zeros); positive floats order like their bit patterns
+__global__ __launch_bounds__(256) void sparse_zmax_kernel(const long long *__restrict__ idx,
+                                                          const float *__restrict__ val,
+                                                          const int *__restrict__ counts,
+                                                          int seg_cap, const uint8_t *__restrict__ keep,
+                                                          long S, int *__restrict__ map_bits) {
+  const long seg = (long)blockIdx.x * seg_cap;
+  const int n = min(counts[blockIdx.x], seg_cap);
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float v = val[seg + i];
+    if (!(v > 0.0f)) continue;
+    const long s_ = idx[seg + i] % S;
+    if (keep && !keep[s_]) continue;
+    atomicMax(&map_bits[s_], __float_as_int(v));
   }
 }
 
@@ -256,7 +406,7 @@ extern "C" int origin_local_max(origin_ctx *ctx, const float *d_correl,
         nzc = nzc < 1 ? 1 : (nzc > cdiv(Nz, 32) ? cdiv(Nz, 32) : nzc);
         const int zp = cdiv(Nz, nzc);
         hipLaunchKernelGGL(kernel, dim3((unsigned)bx, cdiv(Nz, zp)), dim3(256), 0, ctx->stream, a, b,
-                           d_mask, Nz, Ny, Nx, zp, sgn, oa, ob);
+                           d_mask, Nz, Ny, Nx, zp, sgn, oa, ob, LmSparse());
       };
       if (both && form == 0)
         go(local_max3v_kernel<2, 2>, 2, d_correl, d_correl_min, 1.0f, d_local_max, d_local_min);
@@ -296,3 +446,160 @@ extern "C" int origin_local_max(origin_ctx *ctx, const float *d_correl,
   ORIGIN_LAUNCH_CHECK();
   return ORIGIN_OK;
 }
+
+// ---- sparse form: C ABI ---------------------------------------------------------------------
+namespace {
+
+struct LmGeom {
+  long bx;
+  int zp, nzc;
+};
+
+// the launch geometry of local_max3v_kernel<2, 4> (shared by the dense and the sparse form)
+LmGeom lm_geometry(const origin_ctx *ctx, int Nz, int Ny, int Nx) {
+  const int R = 4;
+  const long threads = (long)cdiv(Ny, R) * (Nx / 4);
+  LmGeom g;
+  g.bx = (threads + 4 * 62 - 1) / (4 * 62);  // 62 producing lanes per wave
+  int nzc = (int)(((long)ctx->num_cu * 16 + g.bx - 1) / g.bx);  // ~16 blocks per CU
+  nzc = nzc < 1 ? 1 : (nzc > cdiv(Nz, 32) ? cdiv(Nz, 32) : nzc);
+  g.zp = cdiv(Nz, nzc);
+  g.nzc = cdiv(Nz, g.zp);
+  return g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int origin_local_max_sparse_plan(origin_ctx *ctx, int Nz, int Ny, int Nx, long *nseg, int *seg_cap) {
+  ORIGIN_USE(ctx);
+  ORIGIN_CHECK_ARG(Nz > 0 && Ny > 0 && Nx > 0 && nseg && seg_cap, "bad arguments");
+  *nseg = 0, *seg_cap = 0;
+  if ((Nx & 3) != 0 || Nz > 65535 * 32) return ORIGIN_OK;  // no sparse form for this shape
+  const LmGeom g = lm_geometry(ctx, Nz, Ny, Nx);
+  *nseg = g.bx * g.nzc * 4;
+  // a wave sees zp channels of 62 lanes x 16 outputs; white noise has one 3x3x3 maximum in 27
+  // voxels, a smoothed cube one in ~70: room for one in 8
+  const long per_wave = (long)g.zp * 62 * 16;
+  long cap = (per_wave / 8 + 63) / 64 * 64;
+  *seg_cap = (int)(cap < 256 ? 256 : cap);
+  return ORIGIN_OK;
+}
+
+int origin_local_max_sparse(origin_ctx *ctx, const float *d_correl, const float *d_correl_min,
+                            const uint8_t *d_mask, int Nz, int Ny, int Nx, long nseg, int seg_cap,
+                            long long *d_idx_max, float *d_val_max, long long *d_idx_min,
+                            float *d_val_min, int *d_counts) {
+  ORIGIN_USE(ctx);
+  ORIGIN_CHECK_ARG(d_correl && d_correl_min && d_idx_max && d_val_max && d_idx_min && d_val_min &&
+                       d_counts, "null pointer");
+  ORIGIN_CHECK_ARG(Nz > 0 && Ny > 0 && (Nx & 3) == 0 && Nx > 0, "the sparse form needs Nx % 4 == 0");
+  ORIGIN_CHECK_ARG(((uintptr_t)d_correl & 15) == 0 && ((uintptr_t)d_correl_min & 15) == 0 &&
+                       ((uintptr_t)d_mask & 3) == 0, "cubes must be 16-byte aligned");
+  const LmGeom g = lm_geometry(ctx, Nz, Ny, Nx);
+  ORIGIN_CHECK_ARG(nseg == g.bx * g.nzc * 4 && seg_cap > 0,
+                   "segments do not match origin_local_max_sparse_plan for this shape");
+  LmSparse sp;
+  sp.idx0 = d_idx_max, sp.val0 = d_val_max, sp.idx1 = d_idx_min, sp.val1 = d_val_min;
+  sp.counts = d_counts, sp.seg_cap = seg_cap;
+  ProfScope ps(ctx, K_LOCAL_MAX);
+  hipLaunchKernelGGL((local_max3v_kernel<2, 4, true>), dim3((unsigned)g.bx, g.nzc), dim3(256), 0,
+                     ctx->stream, d_correl, d_correl_min, d_mask, Nz, Ny, Nx, g.zp, 1.0f,
+                     (float *)nullptr, (float *)nullptr, sp);
+  ORIGIN_LAUNCH_CHECK();
+  return ORIGIN_OK;
+}
+
+int origin_sparse_to_dense(origin_ctx *ctx, const long long *d_idx, const float *d_val,
+                           const int *d_counts, long nseg, int seg_cap, float *d_dense, long n) {
+  ORIGIN_USE(ctx);
+  ORIGIN_CHECK_ARG(d_idx && d_val && d_counts && d_dense && nseg > 0 && seg_cap > 0 && n > 0,
+                   "bad arguments");
+  ORIGIN_HIP(hipMemsetAsync(d_dense, 0, (size_t)n * sizeof(float), ctx->stream));
+  ProfScope ps(ctx, K_SMALL);
+  hipLaunchKernelGGL(sparse_to_dense_kernel, dim3((unsigned)nseg), dim3(256), 0, ctx->stream, d_idx,
+                     d_val, d_counts, seg_cap, d_dense);
+  ORIGIN_LAUNCH_CHECK();
+  return ORIGIN_OK;
+}
+
+int origin_sparse_count_above(origin_ctx *ctx, const long long *d_idx, const float *d_val,
+                              const int *d_counts, long nseg, int seg_cap, const uint8_t *d_keep,
+                              long S, int nthr, const double *h_thr, long *h_counts) {
+  ORIGIN_USE(ctx);
+  ORIGIN_CHECK_ARG(d_idx && d_val && d_counts && h_thr && h_counts && nseg > 0 && S > 0,
+                   "bad arguments");
+  ORIGIN_CHECK_ARG(nthr >= 1 && nthr <= 1024, "1..1024 thresholds");
+  for (int i = 0; i < nthr; ++i) ORIGIN_CHECK_ARG(h_thr[i] == h_thr[i], "NaN threshold");
+  std::vector<int> order(nthr);
+  for (int i = 0; i < nthr; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return h_thr[a] < h_thr[b]; });
+  std::vector<double> sorted(nthr);
+  for (int i = 0; i < nthr; ++i) sorted[i] = h_thr[order[i]];
+  void *scr = nullptr;
+  const size_t tb = (size_t)nthr * sizeof(double), hb = (size_t)nthr * sizeof(unsigned long long);
+  int rc = origin_scratch(ctx, tb + hb, &scr);
+  if (rc) return rc;
+  double *d_thr = (double *)scr;
+  unsigned long long *d_hist = (unsigned long long *)((char *)scr + tb);
+  ORIGIN_HIP(hipMemcpyAsync(d_thr, sorted.data(), tb, hipMemcpyHostToDevice, ctx->stream));
+  ORIGIN_HIP(hipMemsetAsync(d_hist, 0, hb, ctx->stream));
+  {
+    ProfScope ps(ctx, K_SMALL);
+    const long blocks = nseg < (long)ctx->num_cu * 16 ? nseg : (long)ctx->num_cu * 16;
+    hipLaunchKernelGGL(sparse_count_above_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+                       d_idx, d_val, d_counts, nseg, seg_cap, d_keep, S, nthr, d_thr, d_hist);
+  }
+  ORIGIN_LAUNCH_CHECK();
+  std::vector<unsigned long long> hist(nthr);
+  ORIGIN_HIP(hipMemcpyAsync(hist.data(), d_hist, hb, hipMemcpyDeviceToHost, ctx->stream));
+  ORIGIN_HIP(hipStreamSynchronize(ctx->stream));
+  unsigned long long run = 0;
+  for (int j = nthr - 1; j >= 0; --j) {
+    run += hist[j];
+    h_counts[order[j]] = (long)run;
+  }
+  return ORIGIN_OK;
+}
+
+int origin_sparse_where_above(origin_ctx *ctx, const long long *d_idx, const float *d_val,
+                              const int *d_counts, long nseg, int seg_cap, double threshold,
+                              const uint8_t *d_aux, long cap, long long *d_out_idx,
+                              float *d_out_val, uint8_t *d_out_aux, long *h_count) {
+  ORIGIN_USE(ctx);
+  ORIGIN_CHECK_ARG(d_idx && d_val && d_counts && d_out_idx && d_out_val && h_count && nseg > 0 &&
+                       cap > 0, "bad arguments");
+  ORIGIN_CHECK_ARG(!d_aux || d_out_aux, "aux cube without an output for it");
+  void *scr = nullptr;
+  int rc = origin_scratch(ctx, sizeof(unsigned long long), &scr);
+  if (rc) return rc;
+  ORIGIN_HIP(hipMemsetAsync(scr, 0, sizeof(unsigned long long), ctx->stream));
+  {
+    ProfScope ps(ctx, K_SMALL);
+    hipLaunchKernelGGL(sparse_where_above_kernel, dim3((unsigned)nseg), dim3(256), 0, ctx->stream,
+                       d_idx, d_val, d_counts, seg_cap, threshold, d_aux, cap, d_out_idx, d_out_val,
+                       d_out_aux, (unsigned long long *)scr);
+  }
+  ORIGIN_LAUNCH_CHECK();
+  unsigned long long total = 0;
+  ORIGIN_HIP(hipMemcpyAsync(&total, scr, sizeof(total), hipMemcpyDeviceToHost, ctx->stream));
+  ORIGIN_HIP(hipStreamSynchronize(ctx->stream));
+  *h_count = (long)total;
+  return ORIGIN_OK;
+}
+
+int origin_sparse_zmax_map(origin_ctx *ctx, const long long *d_idx, const float *d_val,
+                           const int *d_counts, long nseg, int seg_cap, const uint8_t *d_keep,
+                           long S, float *d_map) {
+  ORIGIN_USE(ctx);
+  ORIGIN_CHECK_ARG(d_idx && d_val && d_counts && d_map && nseg > 0 && S > 0, "bad arguments");
+  ORIGIN_HIP(hipMemsetAsync(d_map, 0, (size_t)S * sizeof(float), ctx->stream));
+  ProfScope ps(ctx, K_SMALL);
+  hipLaunchKernelGGL(sparse_zmax_kernel, dim3((unsigned)nseg), dim3(256), 0, ctx->stream, d_idx,
+                     d_val, d_counts, seg_cap, d_keep, S, (int *)d_map);
+  ORIGIN_LAUNCH_CHECK();
+  return ORIGIN_OK;
+}
+
+}  // extern "C"

@@ -20,8 +20,16 @@ CAT0_COLUMNS = ("x0", "y0", "z0", "comp", "STD", "T_GLR", "profile")
 def det_correl_min(ctx, cube_local_min, thresh):
     """``Detection.det_correl_min`` (steps.py:935-939): positions above ``thresh`` in
     cube_local_min -> (zm, ym, xm)."""
-    w = kernels.where_above(ctx, cube_local_min, thresh)
+    w = _where_above(ctx, cube_local_min, thresh)
     return w["z"], w["y"], w["x"]
+
+
+def _where_above(ctx, cube, threshold, aux=None):
+    """``kernels.where_above`` for a DeviceArray; cubes that live in pieces on several devices
+    (session.TiledCube) bring their own."""
+    if hasattr(cube, "where_above"):
+        return cube.where_above(threshold, aux=aux)
+    return kernels.where_above(ctx, cube, threshold, aux=aux)
 
 
 def threshold_detections(ctx, cube_local_max, cube_profile, cube_std_local_max,
@@ -33,8 +41,8 @@ def threshold_detections(ctx, cube_local_max, cube_profile, cube_std_local_max,
     ``cat_std_kept`` the std rows farther than ``maxdist_lines`` from every correl detection
     (:983-994; in ascending row order) -- the two tables the reference stacks again at :1010.
     """
-    c = kernels.where_above(ctx, cube_local_max, threshold_correl, aux=cube_profile)
-    s = kernels.where_above(ctx, cube_std_local_max, threshold_std)
+    c = _where_above(ctx, cube_local_max, threshold_correl, aux=cube_profile)
+    s = _where_above(ctx, cube_std_local_max, threshold_std)
     n, m = c["z"].size, s["z"].size
     cat = dict(x0=c["x"], y0=c["y"], z0=c["z"], comp=np.zeros(n, int), STD=np.full(n, np.nan),
                T_GLR=c["value"], profile=c["aux"])
@@ -55,7 +63,7 @@ def from_session(orig, threshold=None, threshold_std=None, maxdist_lines=2.5):
     thr = orig.param['threshold'] if threshold is None else threshold
     thr_std = orig.param['threshold_std'] if threshold_std is None else threshold_std
     prof = get(orig, ctx, 'cube_profile')
-    if prof.dtype != np.uint8:
+    if prof.dtype != np.uint8 and not hasattr(prof, "where_above"):
         prof = ctx.to_device(prof.to_host().astype(np.uint8))
     return threshold_detections(ctx, get(orig, ctx, 'cube_local_max'), prof,
                                 get(orig, ctx, 'cube_std_local_max'), thr, thr_std,

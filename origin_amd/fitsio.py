@@ -180,6 +180,8 @@ def _device_source(ctx, data):
     """(DeviceArray, host dtype the reference would hold) for anything a DataObj may hold."""
     dev = getattr(data, "dev", None)
     if dev is not None:  # steps.LazyCube
+        if hasattr(dev, "gathered"):   # in pieces on several devices (session.TiledCube)
+            return dev.gathered(ctx), np.dtype(getattr(data, "_dtype", dev.dtype))
         return dev, np.dtype(getattr(data, "_dtype", dev.dtype))
     if isinstance(data, DeviceArray):
         return data, data.dtype

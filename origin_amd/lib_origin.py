@@ -159,27 +159,45 @@ def Compute_threshold_purity(purity, cube_local_max, cube_local_min, segmap=None
     ctx = _ctx()
     logger = logging.getLogger(__name__)
 
+    class OnDevice:
+        """The two reductions on one DeviceArray; cubes that live in pieces on several devices
+        (session.TiledCube) bring their own ``zmax_map`` / ``count_above``."""
+
+        def __init__(self, a):
+            self.a, self.shape = a, a.shape
+
+        def _keep(self, keep):
+            return None if keep is None else ctx.to_device(
+                np.ascontiguousarray(keep, dtype=np.uint8).reshape(-1))
+
+        def zmax_map(self, keep=None):
+            return kernels.zmax_map(ctx, self.a, self._keep(keep))
+
+        def count_above(self, thresholds, keep=None):
+            return kernels.count_above(ctx, self.a, thresholds, self._keep(keep))
+
     def dev(c):
-        return c if isinstance(c, DeviceArray) else ctx.to_device(np.asarray(c), np.float32)
+        if hasattr(c, "count_above"):
+            return c
+        return OnDevice(c if isinstance(c, DeviceArray) else ctx.to_device(np.asarray(c), np.float32))
 
     lmax, lmin = dev(cube_local_max), dev(cube_local_min)
     L1 = int(np.prod(lmin.shape[1:]))                                          # :1425
     keep = None
     if segmap is not None:                                                     # :1428-1435
-        segmask = np.asarray(segmap) == 0
-        keep = ctx.to_device(np.ascontiguousarray(segmask, dtype=np.uint8).reshape(-1))
-        L0 = int(np.count_nonzero(segmask))
+        keep = np.asarray(segmap) == 0
+        L0 = int(np.count_nonzero(keep))
         logger.info('using only background pixels (%.1f%%)', L0 / L1 * 100)
     else:
         L0 = L1
     if threshlist is None:                                                     # :1437-1442
-        map_max = kernels.zmax_map(ctx, lmax)
-        threshmax = min(kernels.zmax_map(ctx, lmin, keep).max(), map_max.max())
+        map_max = lmax.zmax_map()
+        threshmax = min(lmin.zmax_map(keep).max(), map_max.max())
         threshmin = np.median(map_max) * 1.1
         threshlist = np.linspace(threshmin, threshmax, 50)
     threshlist = np.asarray(threshlist, dtype=np.float64)
-    n1 = kernels.count_above(ctx, lmax, threshlist)                            # :1444-1450
-    n0 = kernels.count_above(ctx, lmin, threshlist, keep) * (L1 / L0)          # :1452
+    n1 = lmax.count_above(threshlist)                                          # :1444-1450
+    n0 = lmin.count_above(threshlist, keep) * (L1 / L0)                        # :1452
     with np.errstate(divide='ignore', invalid='ignore'):
         est_purity = 1 - n0 / n1                                               # :1454
     order = np.argsort(threshlist, kind='stable')                              # res.sort('Tval_r')

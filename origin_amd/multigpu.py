@@ -711,9 +711,11 @@ class TiledGLR:
     """GLR of one tile of a tiled field: halo exchange + plan on the extended tile + crop."""
 
     def __init__(self, ctx, comm, tiling, rank, Nz, PSF, profiles, pcut=1e-8, pmeansub=True,
-                 weights=None):
+                 weights=None, ext=None):
         """``weights``: None or the mosaic's weight maps (one (Ny, Nx) array per field of the WHOLE
-        field, origin.py:600-609): every rank crops them to its halo-extended tile, no exchange."""
+        field, origin.py:600-609): every rank crops them to its halo-extended tile, no exchange.
+        ``ext``: an extended tile made earlier (a greedy PCA that ran before the GLR's parameters
+        were known wrote cube_faint into it) instead of a fresh one."""
         self.ctx, self.comm, self.tiling, self.rank, self.Nz = ctx, comm, tiling, rank, Nz
         # a kept spaxel must see real neighbour data over the whole PSF footprint, and a strip
         # must come from ONE neighbour: halo >= P//2 and every tile at least a halo wide
@@ -733,7 +735,9 @@ class TiledGLR:
         self.shape = (Nz, t.y1 - t.y0, t.x1 - t.x0)
         # (zeros: with an OwnerTiling the box also holds spaxels that are neither this rank's nor
         # needed by it; nothing kept depends on them, but they should not be NaN patterns)
-        self.ext = ctx.zeros(self.eshape, np.float32)
+        if ext is not None and (ext.shape != self.eshape or ext.dtype != np.float32):
+            raise ValueError(f"ext must be a float32 array of shape {self.eshape}")
+        self.ext = ctx.zeros(self.eshape, np.float32) if ext is None else ext
         self.emask = ctx.zeros(self.eshape, np.uint8)
         self.out = dict(correl=ctx.empty(self.eshape, np.float32),
                         correl_min=ctx.empty(self.eshape, np.float32),
@@ -750,6 +754,13 @@ class TiledGLR:
         that writes there is followed by ``run(None, ...)`` -- no copy of the tile in between."""
         top, _, left, _ = self.halos
         return (self.ext, top, left)
+
+    def set_ext_mask(self, emask):
+        """Hand over the TRUE mask of the whole extended tile (uint8, extended shape) -- a caller
+        that holds the whole field's mask on the host cuts it there; no exchange then."""
+        if emask.shape != self.eshape or emask.dtype != np.uint8:
+            raise ValueError(f"the extended mask must be uint8 of shape {self.eshape}")
+        self.emask, self._mask_set = emask, True
 
     def _set_mask(self, mask):
         """The mask of the extended tile, made once: this rank's part copied in, the halo

@@ -293,6 +293,28 @@ def _cache(orig):
     return c
 
 
+# Devices of the sessions that do not say themselves (``register(devices=[...])`` sets it for
+# the reference's ORIGIN objects, which know nothing of GPUs); None = one context on device 0.
+_DEFAULT_DEVICES = None
+
+
+def _session_of(orig):
+    """The ``session.TiledSession`` of a session that runs on several devices (``orig.hip_devices``
+    -- ``SimpleOrig(..., devices=[...])`` -- or ``register(devices=[...])``), made on first use;
+    None for the usual one-context session.  One process, one context and one thread per entry;
+    the same ordinal twice means two contexts on that card (strips through the host)."""
+    sess = orig.__dict__.get('_hip_session')
+    if sess is not None:
+        return sess
+    devices = orig.__dict__.get('hip_devices', None) or _DEFAULT_DEVICES
+    if devices is None or len(devices) < 2:
+        return None
+    from .session import DeviceGroup, TiledSession
+    sess = TiledSession(DeviceGroup(devices, orig.__dict__.get('hip_backend')))
+    orig.__dict__['_hip_session'] = sess
+    return sess
+
+
 def _inputs_on_device(orig, ctx):
     """cube_raw / var / mask uploaded once per session (origin.py:262-274)."""
     c = _cache(orig)
@@ -332,32 +354,43 @@ class _PreprocessingRun(_HipStepMixin):
 
     def run(self, orig, dct_order=10, dct_approx=False, pfasegcont=0.01, pfasegres=0.01,
             local_max_size=3, bins='fd'):
-        ctx = _ctx_of(orig)
-        raw, var, mask = _inputs_on_device(orig, ctx)
+        sess = _session_of(orig)
         self._loginfo('DCT computation')
-        out = pipeline.preprocess(ctx, raw, var, mask, dct_order, dct_approx,
-                                  allreduce=getattr(orig, 'allreduce', None))
+        if sess is not None:   # several devices: row bands, one all-reduce, a one-spaxel halo
+            out = sess.preprocess(orig.cube_raw, orig.var, orig.mask, dct_order, dct_approx,
+                                  local_max_size)
+            Nz = out['cube_std'].shape[0]
+            lmax, lmin = out['cube_std_local_max'], out['cube_std_local_min']
+            ima_std, ima_dct, o2, cont_o2 = (out['ima_std'], out['ima_dct'].astype(np.float32),
+                                             out['o2'], out['cont_o2'])
+        else:
+            ctx = _ctx_of(orig)
+            raw, var, mask = _inputs_on_device(orig, ctx)
+            Nz = raw.shape[0]
+            out = pipeline.preprocess(ctx, raw, var, mask, dct_order, dct_approx,
+                                      allreduce=getattr(orig, 'allreduce', None))
+            ima_std = out['ima_std'].to_host().astype(np.float64)
+            lmax, lmin = kernels.local_max(ctx, out['cube_std'], out['cube_std'], mask,
+                                           local_max_size)
+            ima_dct, o2 = out['ima_dct'].to_host(), out['o2_host']
+            # sum_z cont_dct^2 is a per-spaxel reduction of the device cube
+            cont_o2 = kernels.o2test(ctx, out['cont_dct']).to_host()
         self._loginfo('Std signal saved in self.cube_std and self.ima_std')
         self._put_cube(orig, 'cube_std', out['cube_std'])
-        ima_std = out['ima_std'].to_host().astype(np.float64)
         self.store_image('ima_std', ima_std)
 
         self._loginfo('Compute local maximum of std cube values')
-        lmax, lmin = kernels.local_max(ctx, out['cube_std'], out['cube_std'], mask,
-                                       local_max_size)
         self._put_cube(orig, 'cube_std_local_max', lmax)
         self._put_cube(orig, 'cube_std_local_min', lmin)
 
         self._loginfo('DCT continuum saved in self.cont_dct and self.ima_dct')
         self._put_cube(orig, 'cont_dct', out['cont_dct'], np.float32)
-        self.store_image('ima_dct', out['ima_dct'].to_host())
-        o2 = out['o2_host']
+        self.store_image('ima_dct', ima_dct)
         _cache(orig)['o2_std'] = o2
 
         mean_fwhm = int(np.ceil(np.mean(orig.FWHM_PSF)))
         self._loginfo('Segmentation based on the continuum')
-        # sum_z cont_dct^2 is a per-spaxel reduction of the device cube
-        map1 = np.log10(kernels.o2test(ctx, out['cont_dct']).to_host() * raw.shape[0])
+        map1 = np.log10(cont_o2 * Nz)
         thresh, map_cont = compute_segmap_gauss(map1, pfasegcont, mean_fwhm, bins=bins)
         self.store_image('segmap_cont', map_cont)
         self._loginfo('Segmentation based on the residual')
@@ -402,9 +435,9 @@ class _ComputePCAThresholdRun(_HipStepMixin):
     require = ('preprocessing', 'areas')
 
     def run(self, orig, pfa_test=0.01):
-        ctx = _ctx_of(orig)
         o2 = _cache(orig).get('o2_std')
         if o2 is None:  # session reloaded: recompute the O2 map from cube_std
+            ctx = _ctx_of(orig)
             o2 = kernels.o2test(ctx, self._get_cube(orig, ctx, 'cube_std')).to_host()
         areamap = getattr(orig.areamap, '_data', orig.areamap)
         res = pipeline.pca_threshold(o2, areamap, orig.nbAreas, pfa_test)
@@ -421,15 +454,24 @@ class _ComputeGreedyPCARun(_HipStepMixin):
     require = ('preprocessing', 'areas', 'compute_PCA_threshold')
 
     def run(self, orig, Noise_population=50, itermax=100, threshold_list=None):
-        ctx = _ctx_of(orig)
+        ctx = _ctx_of(orig) if _session_of(orig) is None else None
         thr = orig.thresO2 if threshold_list is None else threshold_list
         orig.param['threshold_list'] = thr
         self._loginfo('   - List of threshold = %s', ' '.join("%.2f" % x for x in thr))
         self._loginfo('Compute greedy PCA on each zone')
         areamap = getattr(orig.areamap, '_data', orig.areamap)
-        faint, mapO2, nstop, drv = pipeline.greedy_pca(
-            ctx, self._get_cube(orig, ctx, 'cube_std'), areamap, orig.nbAreas, thr, orig.testO2,
-            Noise_population, itermax)
+        sess = _session_of(orig)
+        if sess is not None:   # several devices: whole areas per rank (session.TiledSession)
+            std = _cache(orig).get('cube_std')
+            if std is None:
+                std = orig.cube_std
+            faint, mapO2, nstop = sess.greedy_pca(
+                std, areamap, orig.nbAreas, thr, orig.testO2, _glr_halo(orig), Noise_population,
+                itermax)
+        else:
+            faint, mapO2, nstop, drv = pipeline.greedy_pca(
+                ctx, self._get_cube(orig, ctx, 'cube_std'), areamap, orig.nbAreas, thr,
+                orig.testO2, Noise_population, itermax)
         if nstop > 0:
             self._logwarning('The iterations have been reached the limit of %d in %d cases',
                              itermax, nstop)
@@ -443,17 +485,29 @@ class _ComputeTGLRRun(_HipStepMixin):
     require = ('compute_greedy_PCA',)
 
     def run(self, orig, size=3, ncpu=1, pcut=1e-8, pmeansub=True):
-        ctx = _ctx_of(orig)
-        _, _, mask = _inputs_on_device(orig, ctx)
-        faint = self._get_cube(orig, ctx, 'cube_faint')
+        sess = _session_of(orig)
         self._loginfo('Correlation')
-        plan = kernels.GLRPlan(ctx, faint.shape, orig.PSF, orig.wfields, orig.profiles, pcut,
-                               pmeansub)
-        try:
-            out = pipeline.tglr(ctx, plan, faint, mask, size)
-            ctx.sync()
-        finally:
-            plan.close()
+        if sess is not None:   # several devices: halo exchange + GLR per box of areas
+            faint = _cache(orig).get('cube_faint')
+            if faint is None:
+                faint = orig.cube_faint
+            areamap = getattr(orig.areamap, '_data', orig.areamap)
+            if getattr(sess, 'host_mask', None) is None:
+                sess.host_mask = _host_mask(orig, faint.shape)
+            out = sess.tglr(faint, areamap, orig.PSF, orig.wfields, orig.profiles, size, pcut,
+                            pmeansub)
+            out['maxmap'], out['minmap'] = _HostImage(out['maxmap']), _HostImage(out['minmap'])
+        else:
+            ctx = _ctx_of(orig)
+            _, _, mask = _inputs_on_device(orig, ctx)
+            faint = self._get_cube(orig, ctx, 'cube_faint')
+            plan = kernels.GLRPlan(ctx, faint.shape, orig.PSF, orig.wfields, orig.profiles, pcut,
+                                   pmeansub)
+            try:
+                out = pipeline.tglr(ctx, plan, faint, mask, size)
+                ctx.sync()
+            finally:
+                plan.close()
         self._put_cube(orig, 'cube_correl', out['correl'])
         self._put_cube(orig, 'cube_correl_min', out['correl_min'])
         self._put_cube(orig, 'cube_profile', out['profile'], np.uint8)
@@ -502,6 +556,30 @@ class _ComputePurityThresholdRun(_HipStepMixin):
 def _data(img):
     """ndarray of an image attribute (mpdaf Image under the reference, ndarray here)."""
     return np.asarray(getattr(img, '_data', img))
+
+
+class _HostImage:
+    """A map that is already on the host, where the run bodies expect ``.to_host()``."""
+
+    def __init__(self, arr):
+        self._a = np.asarray(arr)
+
+    def to_host(self):
+        return self._a
+
+
+def _host_mask(orig, shape):
+    m = orig.mask
+    if m is None or m is np.ma.nomask:
+        return np.zeros(shape, np.uint8)
+    return np.asarray(getattr(m, '_data', m))
+
+
+def _glr_halo(orig, size=3):
+    """Spaxels the GLR of step 5 and its local maxima read beyond a rank's own: half the PSF's
+    side (PSF_size, origin.py:161) plus half the maximum filter's (steps.py:756 ``size=3``)."""
+    psf = orig.PSF[0] if isinstance(orig.PSF, (list, tuple)) else orig.PSF
+    return int(np.asarray(psf).shape[-1]) // 2 + int(size) // 2
 
 
 # ----------------------------------------------------------------------------- stand-alone
@@ -560,14 +638,20 @@ class SimpleOrig:
     ``stepNN_name`` callables like origin.py:193-208 does."""
 
     def __init__(self, cube_raw, var, mask, PSF, profiles, FWHM_PSF=3.3, wfields=None,
-                 param=None, ctx=None):
+                 param=None, ctx=None, devices=None, backend=None):
+        """``devices``: None (one context, ``ctx`` or device 0) or a list of device ordinals --
+        the hot steps then run tiled over them in this one process (origin_amd/session.py); the
+        same ordinal twice = two contexts on one card.  ``backend``: "rccl" / "host" for the
+        cubes that travel between them (default: RCCL when the ordinals differ)."""
+        self.hip_devices = list(devices) if devices is not None else None
+        self.hip_backend = backend
         self.cube_raw, self.var, self.mask = cube_raw, var, mask
         self.PSF, self.wfields, self.profiles = PSF, wfields, profiles
         self.FWHM_PSF = FWHM_PSF
         self.param = param or {}
         self.wave = self.wcs = None
         self.testO2 = self.histO2 = self.binO2 = None
-        self.hip_ctx = ctx or default_context(0)
+        self.hip_ctx = ctx or default_context(0 if not devices else int(devices[0]))
         self.steps = OrderedDict()
         self._dataobjs = {}
         for i, cls in enumerate(STEPS, start=1):
@@ -589,10 +673,12 @@ class SimpleOrig:
 
 
 # ----------------------------------------------------------------------------- register
-def register():
+def register(devices=None):
     """Swap GPU versions of the six steps built here into ``muse_origin.steps.STEPS``.  Call
     before constructing ``ORIGIN`` (origin.py:193 reads the list then).  Returns the list of
-    replaced class names.
+    replaced class names.  ``devices``: list of device ordinals the sessions made afterwards
+    spread their hot steps over (one process, one context per entry: origin_amd/session.py);
+    None = one context on device 0.
 
     Each replacement is ``class <Name>(<run mixin>, <reference class>)`` made with the
     reference's own metaclass.  That metaclass rebuilds ``_dataobjs`` from the attributes of
@@ -601,6 +687,8 @@ def register():
     ``ORIGIN.__init__`` (origin.py:206-207), ``Step.dump`` and ``Step.load`` all walk it."""
     import muse_origin.steps as ref  # noqa: raises ImportError when the reference is absent
 
+    global _DEFAULT_DEVICES
+    _DEFAULT_DEVICES = list(devices) if devices is not None else None
     replaced = []
     for mixin, refname in ((_PreprocessingRun, 'Preprocessing'),
                            (_CreateAreasRun, 'CreateAreas'),
