@@ -168,6 +168,10 @@ def main():
                     help="leave compute_local_max (the last dense pass of ComputeTGLR.run, reference "
                          "steps.py:796) out of the step")
     ap.set_defaults(local_max=True)
+    ap.add_argument("--dense-local-max", action="store_true",
+                    help="write cube_local_max / cube_local_min as two dense float32 cubes (rounds "
+                         "1-3: 17 B/voxel); default: (index, value) lists of their non-zero voxels "
+                         "(origin_local_max_sparse: 9 B/voxel read, one rank only)")
     ap.add_argument("--area-size", type=int, default=100,
                     help="side of the square PCA areas (development: 128 makes area rows "
                          "cache-line aligned)")
@@ -284,8 +288,14 @@ def main():
 
     # (outputs of --local-max, allocated once: a 5 GB hipMalloc / hipFree per step is slower than
     # the kernel)
-    lmax_buf = ctx.empty((Nz, ny, nx), np.float32) if args.local_max and world == 1 else None
-    lmin_buf = ctx.empty((Nz, ny, nx), np.float32) if args.local_max and world == 1 else None
+    sparse_lm = args.local_max and world == 1 and not args.dense_local_max and nx % 4 == 0
+    lm_bufs = None
+    if sparse_lm:
+        from origin_amd import sparse
+        lm_bufs = sparse.SparseBuffers(ctx, (Nz, ny, nx))
+    dense_lm = args.local_max and world == 1 and not sparse_lm
+    lmax_buf = ctx.empty((Nz, ny, nx), np.float32) if dense_lm else None
+    lmin_buf = ctx.empty((Nz, ny, nx), np.float32) if dense_lm else None
 
     glr_key = "glr_and_local_max" if args.local_max else "glr"
 
@@ -329,7 +339,7 @@ def main():
                 ctx, plan, cube_std, local_map, nb_local, thr["thresO2"], thr["testO2"], mask,
                 correl, profile, correl_min, cube_faint, 50, 100, spx=spx, driver=pca_driver,
                 o2_dev=pre["o2"], max_active=args.tail_max_active, area_rows=area_rows,
-                local_max=(lmax_buf, lmin_buf) if do_lm else None,
+                local_max=(lm_bufs if sparse_lm else (lmax_buf, lmin_buf)) if do_lm else None,
                 early_budget=args.tail_early_budget or None)
             info["glr_bands"] = {"early": out["bands"][0], "late": out["bands"][1]}
             t3 = time.perf_counter()
@@ -376,7 +386,10 @@ def main():
         else:
             out = plan.run(cube_faint, mask=mask, correl=correl, profile=profile,
                            correl_min=correl_min, want_maps=True)
-            if do_lm:   # cube_local_max / cube_local_min (steps.py:796)
+            if do_lm and sparse_lm:   # cube_local_max / cube_local_min (steps.py:796)
+                out["local_max"], out["local_min"] = sparse.local_max_sparse(
+                    ctx, correl, correl_min, mask, lm_bufs)
+            elif do_lm:
                 kernels.local_max(ctx, correl, correl_min, mask, 3, out_max=lmax_buf,
                                   out_min=lmin_buf)
         ctx.sync()
@@ -493,7 +506,9 @@ def main():
         "dct_standardize": ("hbm", 17.0 * local_vox),   # + cube_std 4 + cont_dct 4
         "pca_deflate_dot": ("hbm", 4.0),                # per voxel of the launch's areas
         "pca_flush": ("hbm", 8.0 * local_vox),
-        "local_max": ("hbm", 17.0 * local_vox),        # correl 4 + correl_min 4 + mask 1 in, 2 x 4 out
+        # correl 4 + correl_min 4 + mask 1 in; two dense cubes out (2 x 4) or, sparse, their
+        # non-zero voxels as lists (~0.4 B/voxel, not counted)
+        "local_max": ("hbm", (9.0 if sparse_lm else 17.0) * local_vox),
         # flops per launch for the compute-bound GLR stages (fp32 FMA = 2 flop)
         "glr_spatial": ("mfma", 2.0 * 25 * 25 * local_vox),
         "glr_spectral": ("mfma", 2.0 * ntaps * local_vox),
@@ -591,7 +606,8 @@ def main():
         tot = comm.allreduce_sum(np.array([(it_mean or 0.0) * len(spx), float(len(spx))]))
         it_mean = float(tot[0] / max(tot[1], 1.0))
     if rank == 0 and it_mean is not None:
-        bpv = 17.0 + 14.0 + 4.0 * (it_mean + 2.0) + (17.0 if args.local_max else 0.0)
+        lm_bpv = 0.0 if not args.local_max else (9.0 if sparse_lm else 17.0)
+        bpv = 17.0 + 14.0 + 4.0 * (it_mean + 2.0) + lm_bpv
         gbs = bpv * Nz * N * N / (ms_per_step * 1e-3) / 1e9
         path_hbm = dict(bytes_per_voxel=round(bpv, 2), achieved=round(gbs, 1),
                         peak=HBM_PEAK_GBS * world, unit="GB/s",
@@ -600,7 +616,7 @@ def main():
                         # 6.29 TB/s a float4 copy reaches (MI355X_MICROARCH.md)
                         frac_of_measured_copy=round(gbs / (6290.0 * world), 4),
                         note="algorithmic bytes of DCT+standardise (17 B/voxel), greedy PCA "
-                             "(4 (n_iter + 2)), GLR (14)" + (" and the 3x3x3 local maxima (17)"
+                             "(4 (n_iter + 2)), GLR (14)" + (f" and the 3x3x3 local maxima ({lm_bpv:g})"
                                                             if args.local_max else "") +
                              " over the step time; the GLR stages are MFMA-bound (see roofline)")
 
@@ -649,7 +665,15 @@ def main():
         else:
             gtol = dict(tol=1e-4, tol_argmax=1e-4)
             gtxt = "GLR |dT|<=1e-4, argmax mismatch<=1e-4"
-        if args.local_max:   # bit-exact check of the local maxima on the same windows
+        sparse_info = None
+        if sparse_lm:   # the lists of the last step, made dense for the windows of the check
+            sm, sn = out["local_max"], out["local_min"]
+            sparse_info = dict(segments=lm_bufs.nseg, segment_capacity=lm_bufs.seg_cap,
+                               fullest_segment=int(max(sm.counts().max(), sn.counts().max())),
+                               local_maxima=sm.nnz, local_minima=sn.nnz,
+                               list_bytes=12 * (sm.nnz + sn.nnz))
+            out = dict(out, local_max=sm.dense(), local_min=sn.dense())
+        elif args.local_max:   # bit-exact check of the local maxima on the same windows
             out = dict(out, local_max=lmax_buf, local_min=lmin_buf)
         glr_res = [wc.check_glr_window(cube_faint, out, mask, psf64, field.profiles, w,
                                        nthreads=ncpu, **gtol) for w in wins]
@@ -677,6 +701,9 @@ def main():
                                 "1e-5*max(1,|x|)",
                      oracle="oracle.cpu_ref (float64) on haloed windows / whole areas of the "
                             "device arrays of the last step",
+                     local_max_form=("sparse lists (origin_local_max_sparse), checked through "
+                                     "origin_sparse_to_dense" if sparse_lm else "dense cubes"),
+                     sparse=sparse_info,
                      seconds=round(time.perf_counter() - t, 1))
 
     # ---- PCIe-inclusive pass: host arrays in, host arrays out, through the Step seam ---------
@@ -736,7 +763,9 @@ def main():
             "metric": "voxels/s through DCT+PCA+GLR (ORIGIN hot path)",
             "step": "Preprocessing (DCT, standardise) -> PCA thresholds -> greedy PCA -> TGLR "
                     "(correl, correl_min, profile, maxmap, minmap" +
-                    (", cube_local_max, cube_local_min)" if args.local_max else ")"),
+                    (", cube_local_max, cube_local_min" + (" as lists of their non-zero voxels)"
+                                                           if sparse_lm else ")")
+                     if args.local_max else ")"),
             "value": round(value, 1),
             "unit": "voxels/s",
             "n_gpus": 1 if share_gpu else world,

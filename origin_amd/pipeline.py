@@ -172,7 +172,9 @@ def greedy_pca_then_glr(ctx, plan, cube_std, areamap, nbAreas, thresholds, testO
     but a reserve the PCA's small kernels keep), the remaining bands behind the PCA on the main
     stream.  Same results as ``greedy_pca`` followed by ``plan.run`` (the bands run the same
     kernels on the same waves and regions).  ``local_max = (out_max, out_min)``: the 3x3x3 local
-    maxima of correl / correl_min behind the last band (steps.py:796).  ``early_budget``: voxels
+    maxima of correl / correl_min behind the last band (steps.py:796), dense; a
+    ``sparse.SparseBuffers`` instead of the pair: the same in sparse form (``out["local_max"]`` /
+    ``["local_min"]`` are ``SparseCube`` s then).  ``early_budget``: voxels
     of GLR given to the side stream at most (None: every band that is ready).  The PCA's tail
     is a few milliseconds of mostly idle device; GLR work beyond what fits beside it only keeps
     the PCA's small kernels on the reserved CUs for longer (3681x900x900: 139.6 ms per step with
@@ -212,10 +214,16 @@ def greedy_pca_then_glr(ctx, plan, cube_std, areamap, nbAreas, thresholds, testO
     if err is not None:
         raise err
     def finish_local_max(out):
-        if local_max is not None:
+        if local_max is None:
+            return out
+        if isinstance(local_max, tuple):
             kernels.local_max(ctx, correl, correl_min, mask, 3, out_max=local_max[0],
                               out_min=local_max[1])
             out["local_max"], out["local_min"] = local_max
+        else:    # a sparse.SparseBuffers: (index, value) lists instead of two dense cubes
+            from . import sparse
+            out["local_max"], out["local_min"] = sparse.local_max_sparse(ctx, correl, correl_min,
+                                                                         mask, local_max)
         return out
 
     if state["early"] is None:     # the hook did not fire (every area finished together)
@@ -238,6 +246,9 @@ def tglr(ctx, plan, cube_faint, mask, size=3, want_local=True):
     maxima, all on the device."""
     out = plan.run(cube_faint, mask=mask, want_maps=True)
     if want_local:
-        lmax, lmin = kernels.local_max(ctx, out["correl"], out["correl_min"], mask, size)
+        # (sparse where the pass has a sparse form: the cubes are > 98 % zeros and their consumers
+        # -- steps 6 and 7 -- count and pick; a DataObj turns dense when somebody reads it)
+        from . import sparse
+        lmax, lmin = sparse.local_max(ctx, out["correl"], out["correl_min"], mask, size)
         out["local_max"], out["local_min"] = lmax, lmin
     return out

@@ -71,6 +71,8 @@ def _wrap(ctx, value, dtype=np.float32):
         return value.device(ctx, dtype)
     if isinstance(value, DeviceArray):
         return value
+    if hasattr(value, "dense"):        # sparse.SparseCube
+        return value.dense()
     data = getattr(value, "_data", value)
     return ctx.to_device(np.asarray(data), dtype)
 
@@ -370,8 +372,9 @@ class _PreprocessingRun(_HipStepMixin):
             out = pipeline.preprocess(ctx, raw, var, mask, dct_order, dct_approx,
                                       allreduce=getattr(orig, 'allreduce', None))
             ima_std = out['ima_std'].to_host().astype(np.float64)
-            lmax, lmin = kernels.local_max(ctx, out['cube_std'], out['cube_std'], mask,
-                                           local_max_size)
+            from . import sparse
+            lmax, lmin = sparse.local_max(ctx, out['cube_std'], out['cube_std'], mask,
+                                          local_max_size)
             ima_dct, o2 = out['ima_dct'].to_host(), out['o2_host']
             # sum_z cont_dct^2 is a per-spaxel reduction of the device cube
             cont_o2 = kernels.o2test(ctx, out['cont_dct']).to_host()
