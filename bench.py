@@ -172,6 +172,10 @@ def main():
                     help="write cube_local_max / cube_local_min as two dense float32 cubes (rounds "
                          "1-3: 17 B/voxel); default: (index, value) lists of their non-zero voxels "
                          "(origin_local_max_sparse: 9 B/voxel read, one rank only)")
+    ap.add_argument("--masked-border", type=int, default=0,
+                    help="SURVEY 8(d)'s input variant: that many spaxels along every field edge masked "
+                         "in every channel (raw 0, var inf; origin.py:262-274); the check then also "
+                         "covers a DCT window on the border and the corner area (O2 == 0 spaxels)")
     ap.add_argument("--area-size", type=int, default=100,
                     help="side of the square PCA areas (development: 128 makes area rows "
                          "cache-line aligned)")
@@ -191,7 +195,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     Nz, N = args.nz, args.size
-    field_args = (Nz, N, N, None, 25, args.nprof, 0, 1.0 / 400, 1.0 / 900, args.area_size)
+    field_args = (Nz, N, N, None, 25, args.nprof, args.masked_border, 1.0 / 400, 1.0 / 900,
+                  args.area_size)
     # worker pool for the synthetic cube: forked BEFORE this process touches the GPU
     nworkers = max(1, min(12, (os.cpu_count() or 8) // max(1, min(world, 8)) - 1))
     pool = mp.get_context("fork").Pool(nworkers)
@@ -684,6 +689,8 @@ def main():
                                      else [])
         if not full:   # light: the median area (the longest can take minutes on the CPU)
             areas = [int(order_a[len(order_a) // 2])]
+        if args.masked_border and 0 not in areas:
+            areas.append(0)    # the corner area: holds fully masked spaxels (O2 == 0, lib :908-917)
         if args.check == "glr":
             areas = []
         pca_res = [wc.check_pca_area(cube_std, cube_faint, last["mapO2"], spx[a],
@@ -691,6 +698,12 @@ def main():
         dct_res = []
         if args.check == "full":
             w = ("dct", ny // 2 - 8, ny // 2 + 8, nx // 3, nx // 3 + 24)
+            r_ = wc.check_dct_window(raw, var, mask, cube_std, cont_dct, w)
+            r_.pop("_zmean")
+            dct_res.append(r_)
+        if args.masked_border and args.check in ("full", "light"):
+            # a window across the masked border (fully masked spaxels next to exposed ones)
+            w = ("dct_border", 0, 16, nx // 2, nx // 2 + 24)
             r_ = wc.check_dct_window(raw, var, mask, cube_std, cont_dct, w)
             r_.pop("_zmean")
             dct_res.append(r_)
@@ -785,6 +798,7 @@ def main():
                                                  "accumulate (fp32-class: 22 significant bits)",
                                         "bf16": "single bf16 MFMA per product, fp32 accumulate",
                                         "f32": "fp32 FMA"}.get(glr_precision, glr_precision),
+                       "masked_border": args.masked_border,
                        "glr_spectral_arithmetic": glr_precision, "tiles": world, "comm": (comm.backend + (" " + comm.note if comm.note else ""))
                        if comm is not None else None, "pca": info,
                        "gen_seconds": round(t_gen, 1)},

@@ -127,6 +127,72 @@ def test_config2_glr_3681x300x300_oracle_windows(ctx):
     plan.close()
 
 
+def test_masked_border_3681x300x300(ctx):
+    """SURVEY 8(d)'s masked-border variant at size: 5 spaxels along every edge masked in every
+    channel (raw 0, var inf -- origin.py:262-274).  DCT window across the border (masked spaxels
+    exactly 0, the plain-DCT fallback of lib_origin.py:226 never reached for them); the corner area
+    holds O2 == 0 spaxels (the index quirk of lib_origin.py:908-917) and its mapO2 is identical;
+    GLR corner / edge windows with correl[mask] = 0 (steps.py:781); local maxima bit exact, in the
+    sparse form the chain keeps."""
+    from origin_amd import sparse
+    Nz, N = 3681, 300
+    f = synth.SyntheticField(Nz, N, N, masked_border=5)
+    raw, var, mask = f.arrays()
+    assert mask[:, :5].all() and mask[:, :, -5:].all() and not mask[:, 5:-5, 5:-5].any()
+    hip = _hip_chain(ctx, f, raw, var, mask)
+    assert hip["nstop"] == 0
+    o2 = hip["pre"]["o2_host"]
+    assert np.all(o2[:5] == 0) and np.all(o2[:, -5:] == 0) and np.all(o2[5:-5, 5:-5] > 0)
+    for w in (("dct_border", 0, 16, 140, 164), ("dct_corner", 284, 300, 280, 300)):
+        res = window_check.check_dct_window(hip["raw"], hip["var"], hip["mask"],
+                                            hip["pre"]["cube_std"], hip["pre"]["cont_dct"], w)
+        res.pop("_zmean")
+        assert res["ok"], res
+    # the corner area (masked spaxels among its columns) and an interior one
+    for a in (0, 4):
+        res = window_check.check_pca_area(hip["pre"]["cube_std"], hip["faint"], hip["mapO2"],
+                                          hip["spx"][a], hip["thr"]["thresO2"][a], a)
+        assert res["ok"] and res["iterations"] >= 2, res
+    psf = f.PSF.astype(np.float64)
+    plan = kernels.GLRPlan(ctx, (Nz, N, N), psf, None, f.profiles, 1e-8, True)
+    out = pipeline.tglr(ctx, plan, hip["faint"], hip["mask"])
+    ctx.sync()
+    assert isinstance(out["local_max"], sparse.SparseCube)
+    dense = dict(out, local_max=out["local_max"].dense(), local_min=out["local_min"].dense())
+    ncpu = min(32, os.cpu_count() or 1)
+    for w in window_check.glr_windows(N, N, which=("corner", "edge", "far_corner")):
+        res = window_check.check_glr_window(hip["faint"], dense, hip["mask"], psf, f.profiles, w,
+                                            nthreads=ncpu)
+        assert res["ok"] and res["local_max_mismatch"] == 0, res
+    m = mask[0]
+    assert np.all(out["maxmap"].to_host()[m] == 0)           # correl[mask] = 0 in every channel
+    assert np.all(dense["local_max"].window(0, 5, 0, N) == 0)
+    plan.close()
+
+
+def test_masked_border_two_ranks_on_one_gpu():
+    """The same variant tiled over two ranks that share the GPU (`bench.py --gpus 2
+    --masked-border 5`, host-staged strips): runs end to end, and the single-rank run of the same
+    field passes its oracle check (DCT border window, corner area, GLR windows)."""
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--size", "200", "--masked-border", "5",
+            "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--e2e-size", "0"]
+    env = dict(os.environ, ORIGIN_BENCH_SHARE_GPU="1")
+    r = subprocess.run(base + ["--gpus", "2", "--check", "off"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    two = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    r = subprocess.run(base + ["--check", "full"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    one = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert one["check"]["ok"], one["check"]
+    assert any(d_["window"] == "dct_border" for d_ in one["check"]["dct"])
+    assert 0 in [p_["area"] for p_ in one["check"]["pca"]]
+    assert two["config"]["masked_border"] == 5 and two["config"]["tiles"] == 2
+    assert sum(two["per_rank"]["areas"]) == 4
+    assert sum(two["per_rank"]["pca_iterations"]) > 0
+
+
 def test_config3_headline_600_bench_check():
     """bench.py on the headline workload with --check full: three GLR windows, two PCA areas
     and a DCT window of the very arrays the timed steps produced."""
