@@ -286,6 +286,155 @@ __global__ __launch_bounds__(256) void local_max3v_kernel(const float *__restric
   }
 }
 
+// ---- the sparse pass, second form (round 4) ------------------------------------------------
+// The kernel above, compiled with SPARSE, takes 4.05 ms at 3681 x 600 x 600 against 4.6 ms for the
+// dense cubes: not the bytes (9 B per voxel: 2.9 TB/s) but ~770 instructions per wave and channel
+// -- sign multiplies, canonicalising maxima, 115 register moves that rotate the three planes,
+// per-output compare / select / bit-merge chains -- on two waves per SIMD.  This form does the same
+// arithmetic in ~100 VALU instructions per wave and channel:
+//   * one cube per wave (grid z = cube): half the registers, four or more waves per SIMD; the
+//     minima of correl_min are found as minima (v_min3), not as maxima of a negated copy;
+//   * the three planes rotate by NAME (the channel loop is unrolled by three), no moves;
+//   * every maximum is one v_max3 / v_min3 (inline asm: no canonicalisation of its operands);
+//   * "is this voxel its window's maximum" is a v_cmp into a scalar register pair per output; the
+//     wave tests each pair (SALU) and only for the few that are non-zero -- 5 of 16 per channel --
+//     looks at the lanes: value non-zero, mask byte (read there, not per row), slot by
+//     ballot + mbcnt, two stores.
+template <int SIGN>
+__device__ __forceinline__ float lm_ext3(float a, float b, float c) {
+  float d;
+  if constexpr (SIGN > 0) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  else asm("v_min3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
+template <int R>
+struct LmPlane {
+  float p[R][4];  // 3 x 3 extrema of the lane's R x 4 outputs in this plane
+  float c[R][4];  // the plane's own samples there
+};
+
+template <int SIGN, int R>
+__device__ __forceinline__ void lm_sparse_march(const float *__restrict__ a,
+                                                const uint8_t *__restrict__ mask, int Nz, int Ny,
+                                                int Nx, int zper, long long *__restrict__ idx_out,
+                                                float *__restrict__ val_out,
+                                                int *__restrict__ counts, int seg_cap) {
+  const int nx4 = Nx >> 2, ngrp = (Ny + R - 1) / R;
+  const long total = (long)ngrp * nx4;
+  const int lane = threadIdx.x & 63;
+  const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long t_raw = 62 * wv - 1 + lane;
+  const bool live = lane >= 1 && lane <= 62 && t_raw < total;
+  const long t = min(max(t_raw, 0L), total - 1);
+  const int grp = (int)(t / nx4);
+  const int x4 = (int)(t - (long)grp * nx4);
+  const int yb = grp * R;
+  const int z0 = blockIdx.y * zper, z1 = min(Nz, z0 + zper);
+  const long S = (long)Ny * Nx;
+  const unsigned long long first_m = __ballot(x4 == 0), last_m = __ballot(x4 == nx4 - 1);
+  const bool first = x4 == 0, last = x4 == nx4 - 1;
+  (void)first_m, (void)last_m;
+  unsigned roff[R + 2];  // byte offsets of rows yb - 1 .. yb + R (clamped) at this lane's float4
+#pragma unroll
+  for (int r = 0; r < R + 2; ++r)
+    roff[r] = 4u * (unsigned)((long)min(max(yb - 1 + r, 0), Ny - 1) * Nx + 4 * x4);
+  // rows of the lane's group that exist, and the lane produces at all
+  unsigned long long okrow[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) okrow[r] = __ballot(live && yb + r < Ny);
+
+  auto plane = [&](int z, LmPlane<R> &o) {
+    const char *pz = reinterpret_cast<const char *>(a + (long)min(max(z, 0), Nz - 1) * S);
+    float4 v[R + 2];
+#pragma unroll
+    for (int r = 0; r < R + 2; ++r) {
+      // (the empty asm keeps the 32-bit offset's zero-extension next to the load: "SGPR base +
+      // 32-bit lane offset" is one addressing mode; hoisted, each row costs a 64-bit VGPR pair)
+      unsigned o = roff[r];
+      asm volatile("" : "+v"(o));
+      v[r] = *reinterpret_cast<const float4 *>(pz + o);
+    }
+    float xm[R + 2][4];
+#pragma unroll
+    for (int r = 0; r < R + 2; ++r) {
+      float l = wave_from_prev(v[r].w), rr = wave_from_next(v[r].x);
+      l = first ? v[r].x : l;   // at a row's ends the window is clamped to the row
+      rr = last ? v[r].w : rr;
+      xm[r][0] = lm_ext3<SIGN>(l, v[r].x, v[r].y);
+      xm[r][1] = lm_ext3<SIGN>(v[r].x, v[r].y, v[r].z);
+      xm[r][2] = lm_ext3<SIGN>(v[r].y, v[r].z, v[r].w);
+      xm[r][3] = lm_ext3<SIGN>(v[r].z, v[r].w, rr);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o.p[r][e] = lm_ext3<SIGN>(xm[r][e], xm[r + 1][e], xm[r + 2][e]);
+      o.c[r][0] = v[r + 1].x, o.c[r][1] = v[r + 1].y, o.c[r][2] = v[r + 1].z, o.c[r][3] = v[r + 1].w;
+    }
+  };
+
+  const long wave_id = ((long)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const long seg = wave_id * seg_cap;
+  int cnt = 0;  // entries of this wave's segment so far (wave-uniform)
+  // channel z: extrema of planes z - 1 (pa), z (pb), z + 1 (pc, made here); centre = plane z
+  auto step = [&](int z, const LmPlane<R> &pa, const LmPlane<R> &pb, LmPlane<R> &pc) {
+    plane(z + 1, pc);
+    const long zbase = (long)z * S + (long)yb * Nx + 4 * x4;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float m = lm_ext3<SIGN>(pa.p[r][e], pb.p[r][e], pc.p[r][e]);
+        const unsigned long long eq = __builtin_amdgcn_fcmpf(pb.c[r][e], m, 1) & okrow[r];  // OEQ
+        if (eq != 0ull) {  // (wave-uniform; ~1 output in 3 has a candidate in some lane)
+          const long at = zbase + (long)r * Nx + e;
+          bool hit = ((eq >> lane) & 1ull) != 0ull && m != 0.0f;
+          if (hit && mask) hit = mask[at] == 0;         // local_max *= local_mask   (lib :1247)
+          const unsigned long long bal = __ballot(hit);
+          if (hit) {
+            const int slot = cnt + (int)__builtin_amdgcn_mbcnt_hi(
+                                       (unsigned)(bal >> 32),
+                                       __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+            if (slot < seg_cap) {
+              idx_out[seg + slot] = at;
+              val_out[seg + slot] = SIGN > 0 ? m : -m;
+            }
+          }
+          cnt += __popcll(bal);
+        }
+      }
+  };
+  LmPlane<R> A, B, C;
+  plane(z0 - 1, A);
+  plane(z0, B);
+  int z = z0;
+  for (; z + 3 <= z1; z += 3) {
+    step(z, A, B, C);
+    step(z + 1, B, C, A);
+    step(z + 2, C, A, B);
+  }
+  if (z < z1) {
+    step(z, A, B, C);
+    if (z + 1 < z1) step(z + 1, B, C, A);
+  }
+  if (lane == 0) counts[wave_id] = cnt;
+}
+
+constexpr int LMS_R = 4;  // rows per lane of the sparse pass
+
+__global__ __launch_bounds__(256, 4) void local_max3s_kernel(const float *__restrict__ a0,
+                                                          const float *__restrict__ a1,
+                                                          const uint8_t *__restrict__ mask, int Nz,
+                                                          int Ny, int Nx, int zper, LmSparse sp) {
+  const long nwaves = (long)gridDim.x * gridDim.y * 4;
+  if (blockIdx.z == 0)
+    lm_sparse_march<1, LMS_R>(a0, mask, Nz, Ny, Nx, zper, sp.idx0, sp.val0, sp.counts, sp.seg_cap);
+  else
+    lm_sparse_march<-1, LMS_R>(a1, mask, Nz, Ny, Nx, zper, sp.idx1, sp.val1, sp.counts + nwaves,
+                               sp.seg_cap);
+}
+
 // ---- consumers of the sparse form ------------------------------------------------------------
 // one block per segment; entries beyond the capacity were never stored
 __global__ __launch_bounds__(256) void sparse_to_dense_kernel(const long long *__restrict__ idx,
@@ -455,9 +604,9 @@ struct LmGeom {
   int zp, nzc;
 };
 
-// the launch geometry of local_max3v_kernel<2, 4> (shared by the dense and the sparse form)
+// the launch geometry of the sparse pass (local_max3s_kernel)
 LmGeom lm_geometry(const origin_ctx *ctx, int Nz, int Ny, int Nx) {
-  const int R = 4;
+  const int R = LMS_R;
   const long threads = (long)cdiv(Ny, R) * (Nx / 4);
   LmGeom g;
   g.bx = (threads + 4 * 62 - 1) / (4 * 62);  // 62 producing lanes per wave
@@ -481,7 +630,7 @@ int origin_local_max_sparse_plan(origin_ctx *ctx, int Nz, int Ny, int Nx, long *
   *nseg = g.bx * g.nzc * 4;
   // a wave sees zp channels of 62 lanes x 16 outputs; white noise has one 3x3x3 maximum in 27
   // voxels, a smoothed cube one in ~70: room for one in 8
-  const long per_wave = (long)g.zp * 62 * 16;
+  const long per_wave = (long)g.zp * 62 * 4 * LMS_R;
   long cap = (per_wave / 8 + 63) / 64 * 64;
   *seg_cap = (int)(cap < 256 ? 256 : cap);
   return ORIGIN_OK;
@@ -504,9 +653,13 @@ int origin_local_max_sparse(origin_ctx *ctx, const float *d_correl, const float 
   sp.idx0 = d_idx_max, sp.val0 = d_val_max, sp.idx1 = d_idx_min, sp.val1 = d_val_min;
   sp.counts = d_counts, sp.seg_cap = seg_cap;
   ProfScope ps(ctx, K_LOCAL_MAX);
-  hipLaunchKernelGGL((local_max3v_kernel<2, 4, true>), dim3((unsigned)g.bx, g.nzc), dim3(256), 0,
-                     ctx->stream, d_correl, d_correl_min, d_mask, Nz, Ny, Nx, g.zp, 1.0f,
-                     (float *)nullptr, (float *)nullptr, sp);
+  if (getenv("ORIGIN_LOCALMAX_SPARSE_V1") && LMS_R == 4)   // the first form (same segments)
+    hipLaunchKernelGGL((local_max3v_kernel<2, 4, true>), dim3((unsigned)g.bx, g.nzc), dim3(256), 0,
+                       ctx->stream, d_correl, d_correl_min, d_mask, Nz, Ny, Nx, g.zp, 1.0f,
+                       (float *)nullptr, (float *)nullptr, sp);
+  else
+    hipLaunchKernelGGL(local_max3s_kernel, dim3((unsigned)g.bx, g.nzc, 2), dim3(256), 0,
+                       ctx->stream, d_correl, d_correl_min, d_mask, Nz, Ny, Nx, g.zp, sp);
   ORIGIN_LAUNCH_CHECK();
   return ORIGIN_OK;
 }
