@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "../../include/origin_hip.h"
@@ -175,3 +176,21 @@ static inline int origin_use(origin_ctx *ctx) {
   } while (0)
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// hipFuncSetAttribute (the dynamic-LDS ceiling of a kernel) holds per DEVICE, and a process may
+// drive several devices from several threads (origin_amd/session.py: one context and one thread
+// per GPU): the statements run once per device, under a lock -- a second thread on the same device
+// must not launch before the attribute is there.  They may leave through ORIGIN_HIP.
+struct OriginPerDeviceOnce {
+  std::mutex mu;
+  unsigned long long done = 0;
+};
+#define ORIGIN_ONCE_PER_DEVICE(ctx, state, ...)                          \
+  do {                                                                   \
+    std::lock_guard<std::mutex> lk_((state).mu);                         \
+    const unsigned long long bit_ = 1ull << ((ctx)->device & 63);        \
+    if (!((state).done & bit_)) {                                        \
+      __VA_ARGS__;                                                       \
+      (state).done |= bit_;                                              \
+    }                                                                    \
+  } while (0)

@@ -388,12 +388,11 @@ template <int P, int TERMS, bool VEC, bool WEIGHTED>
 static int s2_launch(origin_ctx *ctx, const float *A, const float *W, const float *taps, int Nz,
                      int Ny, int Nx, int accf, float *out, int ry0, int nry, int rx0, int nrx) {
   const size_t lds = 2 * s2_group_bytes<P, TERMS>();
-  static bool attr_done = false;
-  if (!attr_done) {
-    ORIGIN_HIP(hipFuncSetAttribute((const void *)spatial2_kernel<P, TERMS, VEC, WEIGHTED>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
+  static OriginPerDeviceOnce attr_once;
+  ORIGIN_ONCE_PER_DEVICE(ctx, attr_once,
+                         ORIGIN_HIP(hipFuncSetAttribute(
+                             (const void *)spatial2_kernel<P, TERMS, VEC, WEIGHTED>,
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)));
   // one block per CU at a time (LDS): choose the number of z chunks so that the blocks fill
   // whole rounds of the chip (an even number of channels per chunk keeps both groups busy)
   if (nry <= 0) ry0 = 0, nry = cdiv(Ny, S2_R);

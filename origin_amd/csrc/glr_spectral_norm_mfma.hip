@@ -317,15 +317,15 @@ static int nm_passes(origin_ctx *ctx, const float *fsf, const float *norm, const
   }
   const int npass = K > NM_MAX_K ? 2 : 1;
   const int K0 = npass == 2 ? (K / 2 + 1) / 2 * 2 : K;  // an even count first: whole pairs
-  static bool attr_done = false;
-  if (!attr_done) {
-    const int dyn = NM_MAX_K * 2 * MF_PROF_BYTES;
-    ORIGIN_HIP(hipFuncSetAttribute((const void *)spectral_norm_mfma_kernel<false>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
-    ORIGIN_HIP(hipFuncSetAttribute((const void *)spectral_norm_mfma_kernel<true>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
-    attr_done = true;
-  }
+  static OriginPerDeviceOnce attr_once;
+  const int dyn = NM_MAX_K * 2 * MF_PROF_BYTES;
+  ORIGIN_ONCE_PER_DEVICE(ctx, attr_once,
+                         ORIGIN_HIP(hipFuncSetAttribute(
+                             (const void *)spectral_norm_mfma_kernel<false>,
+                             hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
+                         ORIGIN_HIP(hipFuncSetAttribute(
+                             (const void *)spectral_norm_mfma_kernel<true>,
+                             hipFuncAttributeMaxDynamicSharedMemorySize, dyn)));
   for (int pass = 0; pass < npass; ++pass) {
     const int s0 = pass == 0 ? 0 : K0, Kl = pass == 0 ? K0 : K - K0;
     const bool last = pass == npass - 1;

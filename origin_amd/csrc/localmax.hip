@@ -319,22 +319,22 @@ __device__ __forceinline__ void lm_sparse_march(const float *__restrict__ a,
                                                 const uint8_t *__restrict__ mask, int Nz, int Ny,
                                                 int Nx, int zper, long long *__restrict__ idx_out,
                                                 float *__restrict__ val_out,
-                                                int *__restrict__ counts, int seg_cap) {
+                                                int *__restrict__ counts, int seg_cap, long bxi,
+                                                int bzi, long nbx) {
+  // (bxi, bzi: this block's position among the nbx spaxel blocks and the z chunks)
   const int nx4 = Nx >> 2, ngrp = (Ny + R - 1) / R;
   const long total = (long)ngrp * nx4;
   const int lane = threadIdx.x & 63;
-  const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long wv = bxi * 4 + (threadIdx.x >> 6);
   const long t_raw = 62 * wv - 1 + lane;
   const bool live = lane >= 1 && lane <= 62 && t_raw < total;
   const long t = min(max(t_raw, 0L), total - 1);
   const int grp = (int)(t / nx4);
   const int x4 = (int)(t - (long)grp * nx4);
   const int yb = grp * R;
-  const int z0 = blockIdx.y * zper, z1 = min(Nz, z0 + zper);
+  const int z0 = bzi * zper, z1 = min(Nz, z0 + zper);
   const long S = (long)Ny * Nx;
-  const unsigned long long first_m = __ballot(x4 == 0), last_m = __ballot(x4 == nx4 - 1);
   const bool first = x4 == 0, last = x4 == nx4 - 1;
-  (void)first_m, (void)last_m;
   unsigned roff[R + 2];  // byte offsets of rows yb - 1 .. yb + R (clamped) at this lane's float4
 #pragma unroll
   for (int r = 0; r < R + 2; ++r)
@@ -374,7 +374,7 @@ __device__ __forceinline__ void lm_sparse_march(const float *__restrict__ a,
     }
   };
 
-  const long wave_id = ((long)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const long wave_id = ((long)bzi * nbx + bxi) * 4 + (threadIdx.x >> 6);
   const long seg = wave_id * seg_cap;
   int cnt = 0;  // entries of this wave's segment so far (wave-uniform)
   // channel z: extrema of planes z - 1 (pa), z (pb), z + 1 (pc, made here); centre = plane z
@@ -423,16 +423,32 @@ __device__ __forceinline__ void lm_sparse_march(const float *__restrict__ a,
 
 constexpr int LMS_R = 4;  // rows per lane of the sparse pass
 
+// 1-D grid of nbx * nzc * 2 blocks.  Workgroups go to the 8 XCDs round robin by their id, and a
+// lane's rows yb - 1 and yb + R are the own rows of lanes nx4 = Nx / 4 flattened positions away --
+// two or three waves on, mostly in the NEXT block.  With the natural numbering that block runs on
+// another XCD, behind another L2, and the shared rows come from HBM twice (the dense form's PMC
+// passes: 1.4 x the read bytes).  So the ids are decoded such that an XCD gets a contiguous range
+// of the (cube, z chunk, spaxel block) order: neighbours in that order run on the same XCD at about
+// the same time and find each other's rows in its L2.
 __global__ __launch_bounds__(256, 4) void local_max3s_kernel(const float *__restrict__ a0,
                                                           const float *__restrict__ a1,
                                                           const uint8_t *__restrict__ mask, int Nz,
-                                                          int Ny, int Nx, int zper, LmSparse sp) {
-  const long nwaves = (long)gridDim.x * gridDim.y * 4;
-  if (blockIdx.z == 0)
-    lm_sparse_march<1, LMS_R>(a0, mask, Nz, Ny, Nx, zper, sp.idx0, sp.val0, sp.counts, sp.seg_cap);
+                                                          int Ny, int Nx, int zper, long nbx, int nzc,
+                                                          LmSparse sp) {
+  const long nb = (long)gridDim.x;
+  const long xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+  const long base = nb >> 3, rem = nb & 7;
+  const long logical = xcd * base + (xcd < rem ? xcd : rem) + within;  // (a bijection of [0, nb))
+  const long bxi = logical % nbx;
+  const long t = logical / nbx;
+  const int bzi = (int)(t % nzc), cube = (int)(t / nzc);
+  const long nwaves = nbx * nzc * 4;
+  if (cube == 0)
+    lm_sparse_march<1, LMS_R>(a0, mask, Nz, Ny, Nx, zper, sp.idx0, sp.val0, sp.counts, sp.seg_cap,
+                              bxi, bzi, nbx);
   else
     lm_sparse_march<-1, LMS_R>(a1, mask, Nz, Ny, Nx, zper, sp.idx1, sp.val1, sp.counts + nwaves,
-                               sp.seg_cap);
+                               sp.seg_cap, bxi, bzi, nbx);
 }
 
 // ---- consumers of the sparse form ------------------------------------------------------------
@@ -658,8 +674,9 @@ int origin_local_max_sparse(origin_ctx *ctx, const float *d_correl, const float 
                        ctx->stream, d_correl, d_correl_min, d_mask, Nz, Ny, Nx, g.zp, 1.0f,
                        (float *)nullptr, (float *)nullptr, sp);
   else
-    hipLaunchKernelGGL(local_max3s_kernel, dim3((unsigned)g.bx, g.nzc, 2), dim3(256), 0,
-                       ctx->stream, d_correl, d_correl_min, d_mask, Nz, Ny, Nx, g.zp, sp);
+    hipLaunchKernelGGL(local_max3s_kernel, dim3((unsigned)(g.bx * g.nzc * 2)), dim3(256), 0,
+                       ctx->stream, d_correl, d_correl_min, d_mask, Nz, Ny, Nx, g.zp, g.bx, g.nzc,
+                       sp);
   ORIGIN_LAUNCH_CHECK();
   return ORIGIN_OK;
 }

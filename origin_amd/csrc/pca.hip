@@ -2573,6 +2573,105 @@ __global__ __launch_bounds__(256, 4) void flush_kernel(const float *X, float *F,
   }
 }
 
+// The same pass with the block -> memory mapping of the cube instead of the areas' (round 4): a
+// block is 256 consecutive spaxels of the flattened (Ny, Nx) plane x 32 channels, every lane looks
+// up its area (area_of), whether that area is written now and with how many vectors (aT[a] >= 0),
+// and its list position (pos_of).  An area row of 100 float32 cuts the 128-byte lines at both
+// ends: with one block set per area (flush_kernel) cut lines are fetched twice and written as two
+// partial lines unless the neighbour's block happens to run while the line is still in L2 --
+// 15.3 GB moved for 10.6 algorithmic at 3681 x 600 x 600 (profiles/r03_pmc_fetch_write.json).  Here
+// every line of X is read once and every line of F written once, whole.
+// The rows of U of every area present in the block sit in LDS, one table per RUN of equal areas
+// along the block's 256 spaxels (a row of the field crosses an area border every ~100 spaxels:
+// three or four runs), laid out [vector][channel] with the block's largest vector count as the
+// common depth, zero beyond an area's own count; lanes of different areas read different tables
+// (two or three distinct addresses per LDS instruction).  Blocks with more runs, or deeper tables,
+// than fit FLUSH_ROWS_LDS take several rounds.  Same sums in the same order as flush_kernel:
+// identical bits.
+constexpr int FLUSH_ROWS_LDS = 48 * 1024;
+__global__ __launch_bounds__(256, 3) void flush_rows_kernel(
+    const float *X, float *F, int Nz, long S, const int *__restrict__ area_of,
+    const int *__restrict__ pos_of, const int *__restrict__ aT, const double *__restrict__ U,
+    const double *__restrict__ C, long ntot, int out_nx, long out_py, long out_pz) {
+  extern __shared__ __align__(16) double fr_us[];  // [slot][q][FLUSH_ZB]
+  __shared__ int fr_wave_heads[4], fr_slot_area[256], fr_tmax;
+  const long s = (long)blockIdx.x * 256 + threadIdx.x;
+  const int z0 = blockIdx.y * FLUSH_ZB;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int a = -1, T = -1;
+  if (s < S) {
+    a = area_of[s];
+    if (a >= 0) T = aT[a];
+    if (T < 0) a = -1;
+  }
+  if (!__syncthreads_or(a >= 0)) return;  // nothing of this block is written now
+  // runs of equal areas: a lane opens one when its area differs from its left neighbour's
+  int left = __shfl_up(a, 1);
+  if (lane == 0) left = -2;  // (a wave's first lane always opens a run: no look across waves)
+  const bool head = a >= 0 && a != left;
+  const unsigned long long hb = __ballot(head);
+  if (lane == 0) fr_wave_heads[wv] = __popcll(hb);
+  if (threadIdx.x == 0) fr_tmax = 0;
+  __syncthreads();
+  int slot = __popcll(hb & ((2ull << lane) - 1ull)) - 1;  // run index inside the wave
+  for (int w = 0; w < wv; ++w) slot += fr_wave_heads[w];
+  const int nslots = fr_wave_heads[0] + fr_wave_heads[1] + fr_wave_heads[2] + fr_wave_heads[3];
+  if (head) fr_slot_area[slot] = a;
+  if (a >= 0) atomicMax(&fr_tmax, T);
+  __syncthreads();
+  const int Tp = (fr_tmax + 7) & ~7;          // common table depth (multiple of 8)
+  const long pos = a >= 0 ? pos_of[s] : 0;
+  const long fcol = out_nx > 0 ? (s / out_nx) * out_py + (s % out_nx) : s;
+  const long fS = out_nx > 0 ? out_pz : S;
+  double acc[FLUSH_ZB];
+#pragma unroll
+  for (int r = 0; r < FLUSH_ZB; ++r) acc[r] = 0.0;
+  if (Tp > 0) {
+    const int per_round = max(1, FLUSH_ROWS_LDS / (Tp * FLUSH_ZB * (int)sizeof(double)));
+    for (int base = 0; base < nslots; base += per_round) {
+      const int nhere = min(per_round, nslots - base);
+      // tables of the runs base .. base + nhere - 1: Us[slot][q][r] = U[area][z0 + r][q]
+      for (int i = threadIdx.x; i < nhere * Tp * FLUSH_ZB; i += 256) {
+        const int sl = i / (Tp * FLUSH_ZB), rem = i - sl * (Tp * FLUSH_ZB);
+        const int r = rem / Tp, q = rem - r * Tp;  // (q fastest: consecutive addresses of U)
+        const int ar = fr_slot_area[base + sl];
+        const double *Ua = U + (long)ar * Nz * PCA_CAP;
+        fr_us[(sl * Tp + q) * FLUSH_ZB + r] =
+            (z0 + r < Nz && q < aT[ar]) ? Ua[(long)(z0 + r) * PCA_CAP + q] : 0.0;
+      }
+      __syncthreads();
+      if (a >= 0 && slot >= base && slot < base + nhere) {
+        const double *us = fr_us + (long)(slot - base) * Tp * FLUSH_ZB;
+        for (int q0 = 0; q0 < T; q0 += 8) {
+          double c[8];  // independent loads; entries beyond T multiply zero rows of the table
+#pragma unroll
+          for (int e = 0; e < 8; ++e) c[e] = q0 + e < T ? C[(long)(q0 + e) * ntot + pos] : 0.0;
+#pragma unroll
+          for (int r = 0; r < FLUSH_ZB; r += 2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const double2 u2 = *reinterpret_cast<const double2 *>(us + (q0 + e) * FLUSH_ZB + r);
+              acc[r] = fma(u2.x, c[e], acc[r]);
+              acc[r + 1] = fma(u2.y, c[e], acc[r + 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (a < 0) return;
+  float xv[FLUSH_ZB];
+#pragma unroll
+  for (int r = 0; r < FLUSH_ZB; ++r) xv[r] = X[(long)min(z0 + r, Nz - 1) * S + s];
+#pragma unroll
+  for (int r = 0; r < FLUSH_ZB; ++r) {
+    const int z = z0 + r;
+    if (z < Nz) F[(long)z * fS + fcol] = (float)((double)xv[r] - acc[r]);
+  }
+}
+
 // ------------------------------------------------------------------------------------
 // host helpers
 // ------------------------------------------------------------------------------------
@@ -2632,28 +2731,27 @@ int eig_launch(origin_ctx *ctx, int nmat, long ldmax, const double *d_G, const l
                const long *d_ld, const long *d_n, double *d_q, const long *d_q_off, double *d_v,
                const long *d_v_off, double *d_info, const double *d_slab = nullptr,
                long slab_stride = 0, int ksplit = 0, double *d_dbg = nullptr) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    // dynamic + static LDS must stay within the 160 KB of a CU: ask for exactly what is used
-    const int dyn_max = (int)std::max(PW_BYTES, (size_t)(LANCZOS_M + 2) * LANCZOS_QLDS_LD * sizeof(double));
-    ORIGIN_HIP(hipFuncSetAttribute((const void *)lanczos_kernel<true>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, dyn_max));
-    ORIGIN_HIP(hipFuncSetAttribute((const void *)lanczos_kernel<false>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, dyn_max));
-    attr_done = true;
-  }
+  static OriginPerDeviceOnce attr_once;
+  // dynamic + static LDS must stay within the 160 KB of a CU: ask for exactly what is used
+  const int dyn_max = (int)std::max(PW_BYTES, (size_t)(LANCZOS_M + 2) * LANCZOS_QLDS_LD * sizeof(double));
+  ORIGIN_ONCE_PER_DEVICE(ctx, attr_once,
+                         ORIGIN_HIP(hipFuncSetAttribute((const void *)lanczos_kernel<true>,
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        dyn_max));
+                         ORIGIN_HIP(hipFuncSetAttribute((const void *)lanczos_kernel<false>,
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        dyn_max)));
   // Above PW_N columns: plain Lanczos with the matrix resident on the CU (lanczos_plain_kernel;
   // ORIGIN_PCA_EIG=cgs2 keeps the round-2 kernel for A/B runs).  A launch whose largest matrix
   // exceeds LP_NMAX columns goes to the round-2 kernel as a whole.
   static const bool cgs2 = getenv("ORIGIN_PCA_EIG") && !strcmp(getenv("ORIGIN_PCA_EIG"), "cgs2");
   if (!d_slab && ldmax > PW_N && ldmax <= LP_NMAX && !cgs2) {
-    static bool attr_plain = false;
+    static OriginPerDeviceOnce attr_plain;
     const size_t lds = std::max(std::max(PW_BYTES, sizeof(SmallWork)), LP_BYTES);
-    if (!attr_plain) {
-      ORIGIN_HIP(hipFuncSetAttribute((const void *)lanczos_plain_kernel,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_plain = true;
-    }
+    ORIGIN_ONCE_PER_DEVICE(ctx, attr_plain,
+                           ORIGIN_HIP(hipFuncSetAttribute((const void *)lanczos_plain_kernel,
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                          (int)lds)));
     hipLaunchKernelGGL(lanczos_plain_kernel, dim3(nmat), dim3(LP_NT), lds, ctx->stream, d_G, d_g_off,
                        d_ld, d_n, d_q, d_q_off, d_v, d_v_off, 8, 1e-14, d_info, d_dbg);
     ORIGIN_LAUNCH_CHECK();
@@ -2863,7 +2961,8 @@ int origin_pca_run_into(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, l
   const bool row_dot = getenv("ORIGIN_PCA_AREA_DOT") == nullptr;
   if ((rc = W.b[19].reserve(ctx, (size_t)2 * S * sizeof(int)))) return rc;
   int *d_area_of = (int *)W.b[19].p, *d_pos_of = d_area_of + S;
-  if (row_dot) {
+  const bool row_flush = getenv("ORIGIN_PCA_AREA_FLUSH") == nullptr;
+  if (row_dot || row_flush) {
     int nsm = 0;
     for (int a = 0; a < na; ++a) nsm = std::max(nsm, (int)(h_spx_off[a + 1] - h_spx_off[a]));
     ORIGIN_HIP(hipMemsetAsync(d_area_of, 0xFF, (size_t)S * sizeof(int), st));
@@ -2939,6 +3038,14 @@ int origin_pca_run_into(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, l
         nsmax = std::max(nsmax, ns);
         ++k;
       }
+      // behind the descriptors: aT[a] = vectors of area a, -1 = not written now (flush_rows_kernel)
+      const size_t fd_desc = fd.size();
+      fd.resize(fd_desc + ((size_t)na + 1) / 2, 0);
+      {
+        int *at = reinterpret_cast<int *>(fd.data() + fd_desc);
+        for (int a = 0; a < na; ++a) at[a] = -1;
+        for (int k2 = 0; k2 < nf; ++k2) at[fd[k2]] = (int)fd[(size_t)3 * nf + k2];
+      }
       int r;
       if ((r = b_fd.reserve(ctx, fd.size() * sizeof(long)))) return r;
       ORIGIN_HIP(hipMemcpyAsync(b_fd.p, fd.data(), fd.size() * sizeof(long), hipMemcpyHostToDevice,
@@ -2949,10 +3056,26 @@ int origin_pca_run_into(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, l
       // cube's memory order with one pass per area present in a wave, 3.39 ms; two / four spaxels
       // per lane so that one LDS read of U serves several products, 3.0 / 3.8 ms; this form 2.83.)
       const int nxb = cdiv(nsmax, 256), nzb = cdiv(Nz, FLUSH_ZB);
-      const long ngroups = ((long)nxb * nzb + 7) / 8;  // groups of 8 (spaxel chunk, channel block)
-      hipLaunchKernelGGL(flush_kernel, dim3((unsigned)(ngroups * nf * 8)), dim3(256), 0, st, src, dst,
-                         Nz, S, d_spx, (const long *)b_fd.p, nf, d_U, d_C, ntot, nxb, nzb,
-                         to_strided ? out_nx : 0, out_py, out_pz);
+      long nsum_f = 0;
+      for (int k2 = 0; k2 < nf; ++k2) nsum_f += fd[(size_t)2 * nf + k2];
+      if (row_flush && 2 * nsum_f >= S && Nz / FLUSH_ZB < 65535) {
+        // the areas written now cover at least half of the field: walk the cube in memory order
+        // (flush_rows_kernel); aT[a] = vectors of area a, -1 = not written now
+        const int *d_aT = (const int *)((const long *)b_fd.p + fd_desc);
+        static OriginPerDeviceOnce attr_rows;
+        ORIGIN_ONCE_PER_DEVICE(ctx, attr_rows,
+                               ORIGIN_HIP(hipFuncSetAttribute(
+                                   (const void *)flush_rows_kernel,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, FLUSH_ROWS_LDS)));
+        hipLaunchKernelGGL(flush_rows_kernel, dim3((unsigned)cdiv(S, 256), nzb), dim3(256),
+                           FLUSH_ROWS_LDS, st, src, dst, Nz, S, d_area_of, d_pos_of, d_aT, d_U, d_C,
+                           ntot, to_strided ? out_nx : 0, out_py, out_pz);
+      } else {
+        const long ngroups = ((long)nxb * nzb + 7) / 8;  // groups of 8 (spaxel chunk, channel block)
+        hipLaunchKernelGGL(flush_kernel, dim3((unsigned)(ngroups * nf * 8)), dim3(256), 0, st, src,
+                           dst, Nz, S, d_spx, (const long *)b_fd.p, nf, d_U, d_C, ntot, nxb, nzb,
+                           to_strided ? out_nx : 0, out_py, out_pz);
+      }
       ORIGIN_LAUNCH_CHECK();
     }
     if (only_done) {  // the areas that still iterate keep their vectors and go on reading src
