@@ -100,6 +100,11 @@ def spawn_ranks(n):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
                                       env=env, stdout=subprocess.PIPE if r == 0 else
                                       subprocess.DEVNULL))
+    # rank 0's line can outgrow the pipe's buffer (64 KiB): read it while waiting, not afterwards
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
     failed = None
     live = set(range(n))
     while live and failed is None:
@@ -113,8 +118,6 @@ def spawn_ranks(n):
                 break
         else:
             time.sleep(0.05)
-        if procs[0].stdout is not None and 0 not in live and failed is None and live:
-            pass   # rank 0 is done; its pipe is read below
     if failed is not None:
         for r in live:          # exactly the children started above
             procs[r].terminate()
@@ -126,7 +129,8 @@ def spawn_ranks(n):
         sys.stderr.write(f"bench.py: rank {failed[0]} exited with code {failed[1]}; "
                          "the other ranks were stopped\n")
         raise SystemExit(1)
-    out = procs[0].stdout.read().decode()
+    reader.join(timeout=30)
+    out = b"".join(chunks).decode()
     lines = [ln for ln in out.splitlines() if ln.startswith("{")]
     if len(lines) != 1:
         sys.stderr.write("bench.py: rank 0 did not print exactly one JSON line\n" + out[-2000:])
@@ -369,17 +373,30 @@ def main():
             hook = glr.make_tail_hook(area_boxes, mask, args.tail_early_budget or None)
         if hook is not None:
             ctx.set_pca_tail_hook(hook, args.tail_max_active)
+        pca_err = None
         try:
             F, mapO2, nstop, drv = pipeline.greedy_pca(
                 ctx, cube_std, local_map, nb_local, thr["thresO2"], thr["testO2"], 50, 100, spx=spx,
                 inplace=False, driver=pca_driver, o2_dev=pre["o2"],
                 out=cube_faint if world == 1 else None,
                 into=glr.faint_target() if world > 1 else None)
+        except Exception as exc:   # noqa: BLE001 -- agreed on with the other ranks below
+            pca_err = exc
         finally:
             if hook is not None:
                 ctx.set_pca_tail_hook(None)
-        if hook is not None and ctx.pop_tail_hook_error() is not None:
-            raise RuntimeError("the tail hook of the tiled GLR failed")
+        if pca_err is None and hook is not None:
+            pca_err = ctx.pop_tail_hook_error()
+        if comm is not None:
+            # every rank learns whether all PCAs and hooks went through BEFORE the collective halo
+            # exchange: a rank that failed would leave the others waiting in it
+            ok = comm.group.allreduce(np.array([0.0 if pca_err is not None else 1.0]), "min")[0]
+            if ok != 1.0:
+                glr._early_done = None   # (regions the hook started belong to a step that is over)
+                raise pca_err if pca_err is not None else RuntimeError(
+                    "the greedy PCA or its tail hook failed on another rank")
+        elif pca_err is not None:
+            raise pca_err
         t3 = time.perf_counter()
         if world > 1:
             # (no crop: correl / correl_min / profile and the local maxima stay in the tile's

@@ -34,6 +34,19 @@ def _addresses(world):
     return [(socket.AF_UNIX, f"\0origin-rdv-{port}-{key}-r{r}") for r in range(world)]
 
 
+def _job_tag():
+    """16 bytes every rank of one job derives alike (key and port): the first thing a rank says
+    when it connects, so that a stray connection cannot take a rank's place."""
+    import hashlib
+    key = os.environ.get("ORIGIN_RDV_KEY") or os.environ.get("TORCHELASTIC_RUN_ID") or \
+        str(os.getppid())
+    return hashlib.sha256(f"origin-rdv:{key}:{os.environ.get('MASTER_PORT', '0')}".encode()).digest()[:16]
+
+
+def _hello(rank):
+    return struct.pack("<16si", _job_tag(), rank)
+
+
 def _recv_exact(sock, n, into=None):
     buf = into if into is not None else bytearray(n)
     view = memoryview(buf).cast("B")
@@ -60,7 +73,12 @@ class HostGroup:
         ls = socket.socket(fam, socket.SOCK_STREAM)
         if fam == socket.AF_INET:
             ls.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-        ls.bind(me)
+        try:
+            ls.bind(me)
+        except OSError as exc:
+            raise OSError(f"rank {rank}: rendezvous address {me!r} is taken -- another job with the "
+                          "same MASTER_PORT and key runs on this node (set ORIGIN_RDV_KEY or "
+                          f"another MASTER_PORT): {exc}") from exc
         ls.listen(world)
         ls.settimeout(TIMEOUT)
         self._listener = ls
@@ -77,12 +95,22 @@ class HostGroup:
                     if time.time() > deadline:
                         raise TimeoutError(f"rank {rank}: rank {r} never came up at {addr!r}")
                     time.sleep(0.02)
-            s.sendall(struct.pack("<i", rank))
+            s.sendall(_hello(rank))
             self._setup(s, fam_r)
             self.peers[r] = s
-        for _ in range(rank + 1, world):            # accept every higher rank
+        while len(self.peers) < world - 1:          # accept every higher rank
             s, _a = ls.accept()
-            (r,) = struct.unpack("<i", bytes(_recv_exact(s, 4)))
+            s.settimeout(TIMEOUT)
+            try:
+                tag, r = struct.unpack("<16si", bytes(_recv_exact(s, 20)))
+            except (ConnectionError, OSError, struct.error):
+                s.close()
+                continue
+            # a connection that is not one of this job's higher ranks (wrong key, a rank out of
+            # range or one that is already here) is dropped, not given a rank's place
+            if tag != _job_tag() or not (rank < r < world) or r in self.peers:
+                s.close()
+                continue
             self._setup(s, fam)
             self.peers[r] = s
 

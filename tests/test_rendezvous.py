@@ -80,3 +80,50 @@ def test_package_does_not_import_torch():
             if f.endswith((".py", ".hip", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(import|from)\s+torch", txt, re.M), f
+
+
+def test_stray_connection_does_not_take_a_rank():
+    """A connection that does not open with this job's tag (or names a rank out of range, or one
+    that is already connected) is dropped by the listener; the real rank still gets in."""
+    import socket
+    import struct
+    import threading
+    import time
+    from origin_amd import rendezvous as rdv
+    os.environ["ORIGIN_RDV_KEY"] = f"stray{os.getpid()}"
+    os.environ["MASTER_PORT"] = "29611"
+    groups = {}
+
+    def rank(r):
+        groups[r] = rdv.HostGroup(r, 2)
+    t0 = threading.Thread(target=rank, args=(0,))
+    t0.start()
+    fam, addr = rdv._addresses(2)[0]
+    deadline = time.time() + 20
+    for payload in (struct.pack("<16si", b"x" * 16, 1),          # wrong tag
+                    struct.pack("<16si", rdv._job_tag(), 7),      # rank out of range
+                    b"\x01\x00"):                                 # short and gone
+        while True:
+            s = socket.socket(fam, socket.SOCK_STREAM)
+            try:
+                s.connect(addr)
+                break
+            except OSError:
+                s.close()
+                assert time.time() < deadline
+                time.sleep(0.02)
+        s.sendall(payload)
+        s.close()
+    t1 = threading.Thread(target=rank, args=(1,))
+    t1.start()
+    t0.join(30), t1.join(30)
+    assert set(groups) == {0, 1} and set(groups[0].peers) == {1}
+
+    def red(r, out):
+        out[r] = groups[r].allreduce(np.array([float(r + 1)]))[0]
+    out = {}
+    ts = [threading.Thread(target=red, args=(r, out)) for r in (0, 1)]
+    [t.start() for t in ts], [t.join(30) for t in ts]
+    assert out == {0: 3.0, 1: 3.0}
+    for g in groups.values():
+        g.close()
