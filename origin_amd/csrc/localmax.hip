@@ -314,7 +314,7 @@ struct LmPlane {
   float c[R][4];  // the plane's own samples there
 };
 
-template <int SIGN, int R>
+template <int SIGN, int R, bool HAS_MASK>
 __device__ __forceinline__ void lm_sparse_march(const float *__restrict__ a,
                                                 const uint8_t *__restrict__ mask, int Nz, int Ny,
                                                 int Nx, int zper, long long *__restrict__ idx_out,
@@ -340,9 +340,10 @@ __device__ __forceinline__ void lm_sparse_march(const float *__restrict__ a,
   for (int r = 0; r < R + 2; ++r)
     roff[r] = 4u * (unsigned)((long)min(max(yb - 1 + r, 0), Ny - 1) * Nx + 4 * x4);
   // rows of the lane's group that exist, and the lane produces at all
-  unsigned long long okrow[R];
+  unsigned long long okrow[R];   // lanes whose output row r exists (scalar register pairs)
 #pragma unroll
   for (int r = 0; r < R; ++r) okrow[r] = __ballot(live && yb + r < Ny);
+  const unsigned lane_lo = lane < 32 ? 1u << lane : 0u, lane_hi = lane < 32 ? 0u : 1u << (lane - 32);
 
   auto plane = [&](int z, LmPlane<R> &o) {
     const char *pz = reinterpret_cast<const char *>(a + (long)min(max(z, 0), Nz - 1) * S);
@@ -358,7 +359,9 @@ __device__ __forceinline__ void lm_sparse_march(const float *__restrict__ a,
     float xm[R + 2][4];
 #pragma unroll
     for (int r = 0; r < R + 2; ++r) {
-      float l = wave_from_prev(v[r].w), rr = wave_from_next(v[r].x);
+      // (mov_dpp without an `old` operand: lanes 0 / 63 get zeros, and they produce no output)
+      float l = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v[r].w), 0x138, 0xF, 0xF, true));
+      float rr = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v[r].x), 0x130, 0xF, 0xF, true));
       l = first ? v[r].x : l;   // at a row's ends the window is clamped to the row
       rr = last ? v[r].w : rr;
       xm[r][0] = lm_ext3<SIGN>(l, v[r].x, v[r].y);
@@ -375,7 +378,9 @@ __device__ __forceinline__ void lm_sparse_march(const float *__restrict__ a,
   };
 
   const long wave_id = ((long)bzi * nbx + bxi) * 4 + (threadIdx.x >> 6);
-  const long seg = wave_id * seg_cap;
+  // this wave's segment: uniform base pointers, 32-bit lane offsets
+  char *seg_idx = reinterpret_cast<char *>(idx_out + wave_id * seg_cap);
+  char *seg_val = reinterpret_cast<char *>(val_out + wave_id * seg_cap);
   int cnt = 0;  // entries of this wave's segment so far (wave-uniform)
   // channel z: extrema of planes z - 1 (pa), z (pb), z + 1 (pc, made here); centre = plane z
   auto step = [&](int z, const LmPlane<R> &pa, const LmPlane<R> &pb, LmPlane<R> &pc) {
@@ -386,19 +391,25 @@ __device__ __forceinline__ void lm_sparse_march(const float *__restrict__ a,
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float m = lm_ext3<SIGN>(pa.p[r][e], pb.p[r][e], pc.p[r][e]);
+        // one v_cmp into a scalar register pair, the rest of the test on the scalar unit (a bool
+        // that goes through __ballot() costs two more VALU instructions per output: the compiler
+        // widens it to 0 / 1 per lane and compares again)
         const unsigned long long eq = __builtin_amdgcn_fcmpf(pb.c[r][e], m, 1) & okrow[r];  // OEQ
-        if (eq != 0ull) {  // (wave-uniform; ~1 output in 3 has a candidate in some lane)
+        if (eq != 0ull) {  // (uniform; ~1 output in 3 has a candidate in some lane)
           const long at = zbase + (long)r * Nx + e;
-          bool hit = ((eq >> lane) & 1ull) != 0ull && m != 0.0f;
-          if (hit && mask) hit = mask[at] == 0;         // local_max *= local_mask   (lib :1247)
-          const unsigned long long bal = __ballot(hit);
+          const bool cand = (((unsigned)eq & lane_lo) | ((unsigned)(eq >> 32) & lane_hi)) != 0u;
+          bool hit = cand && m != 0.0f;
+          if constexpr (HAS_MASK) {
+            if (hit) hit = mask[at] == 0;               // local_max *= local_mask   (lib :1247)
+          }
+          const unsigned long long bal = __builtin_amdgcn_ballot_w64(hit);
           if (hit) {
-            const int slot = cnt + (int)__builtin_amdgcn_mbcnt_hi(
-                                       (unsigned)(bal >> 32),
-                                       __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-            if (slot < seg_cap) {
-              idx_out[seg + slot] = at;
-              val_out[seg + slot] = SIGN > 0 ? m : -m;
+            const unsigned slot = (unsigned)cnt + __builtin_amdgcn_mbcnt_hi(
+                                                      (unsigned)(bal >> 32),
+                                                      __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+            if (slot < (unsigned)seg_cap) {
+              *reinterpret_cast<long long *>(seg_idx + 8u * slot) = at;
+              *reinterpret_cast<float *>(seg_val + 4u * slot) = SIGN > 0 ? m : -m;
             }
           }
           cnt += __popcll(bal);
@@ -430,25 +441,27 @@ constexpr int LMS_R = 4;  // rows per lane of the sparse pass
 // passes: 1.4 x the read bytes).  So the ids are decoded such that an XCD gets a contiguous range
 // of the (cube, z chunk, spaxel block) order: neighbours in that order run on the same XCD at about
 // the same time and find each other's rows in its L2.
+template <bool HAS_MASK>
 __global__ __launch_bounds__(256, 4) void local_max3s_kernel(const float *__restrict__ a0,
                                                           const float *__restrict__ a1,
                                                           const uint8_t *__restrict__ mask, int Nz,
                                                           int Ny, int Nx, int zper, long nbx, int nzc,
-                                                          LmSparse sp) {
+                                                          int xcd_order, LmSparse sp) {
   const long nb = (long)gridDim.x;
   const long xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
   const long base = nb >> 3, rem = nb & 7;
-  const long logical = xcd * base + (xcd < rem ? xcd : rem) + within;  // (a bijection of [0, nb))
+  long logical = xcd * base + (xcd < rem ? xcd : rem) + within;  // (a bijection of [0, nb))
+  if (!xcd_order) logical = blockIdx.x;
   const long bxi = logical % nbx;
   const long t = logical / nbx;
   const int bzi = (int)(t % nzc), cube = (int)(t / nzc);
   const long nwaves = nbx * nzc * 4;
   if (cube == 0)
-    lm_sparse_march<1, LMS_R>(a0, mask, Nz, Ny, Nx, zper, sp.idx0, sp.val0, sp.counts, sp.seg_cap,
-                              bxi, bzi, nbx);
+    lm_sparse_march<1, LMS_R, HAS_MASK>(a0, mask, Nz, Ny, Nx, zper, sp.idx0, sp.val0, sp.counts,
+                                        sp.seg_cap, bxi, bzi, nbx);
   else
-    lm_sparse_march<-1, LMS_R>(a1, mask, Nz, Ny, Nx, zper, sp.idx1, sp.val1, sp.counts + nwaves,
-                               sp.seg_cap, bxi, bzi, nbx);
+    lm_sparse_march<-1, LMS_R, HAS_MASK>(a1, mask, Nz, Ny, Nx, zper, sp.idx1, sp.val1,
+                                         sp.counts + nwaves, sp.seg_cap, bxi, bzi, nbx);
 }
 
 // ---- consumers of the sparse form ------------------------------------------------------------
@@ -674,9 +687,16 @@ int origin_local_max_sparse(origin_ctx *ctx, const float *d_correl, const float 
                        ctx->stream, d_correl, d_correl_min, d_mask, Nz, Ny, Nx, g.zp, 1.0f,
                        (float *)nullptr, (float *)nullptr, sp);
   else
-    hipLaunchKernelGGL(local_max3s_kernel, dim3((unsigned)(g.bx * g.nzc * 2)), dim3(256), 0,
-                       ctx->stream, d_correl, d_correl_min, d_mask, Nz, Ny, Nx, g.zp, g.bx, g.nzc,
-                       sp);
+  {
+    static const int xcd_order = getenv("ORIGIN_LOCALMAX_XCD") ? atoi(getenv("ORIGIN_LOCALMAX_XCD")) : 1;
+    const dim3 grid((unsigned)(g.bx * g.nzc * 2));
+    if (d_mask)
+      hipLaunchKernelGGL(local_max3s_kernel<true>, grid, dim3(256), 0, ctx->stream, d_correl,
+                         d_correl_min, d_mask, Nz, Ny, Nx, g.zp, g.bx, g.nzc, xcd_order, sp);
+    else
+      hipLaunchKernelGGL(local_max3s_kernel<false>, grid, dim3(256), 0, ctx->stream, d_correl,
+                         d_correl_min, d_mask, Nz, Ny, Nx, g.zp, g.bx, g.nzc, xcd_order, sp);
+  }
   ORIGIN_LAUNCH_CHECK();
   return ORIGIN_OK;
 }

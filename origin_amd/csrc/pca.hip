@@ -2619,7 +2619,10 @@ __global__ __launch_bounds__(256, 3) void flush_rows_kernel(
   if (head) fr_slot_area[slot] = a;
   if (a >= 0) atomicMax(&fr_tmax, T);
   __syncthreads();
-  const int Tp = (fr_tmax + 7) & ~7;          // common table depth (multiple of 8)
+  // common table depth: a power of two >= 8 (index arithmetic of the fill by shifts)
+  int lt = 3;
+  while ((1 << lt) < fr_tmax) ++lt;
+  const int Tp = fr_tmax > 0 ? 1 << lt : 0;
   const long pos = a >= 0 ? pos_of[s] : 0;
   const long fcol = out_nx > 0 ? (s / out_nx) * out_py + (s % out_nx) : s;
   const long fS = out_nx > 0 ? out_pz : S;
@@ -2630,29 +2633,32 @@ __global__ __launch_bounds__(256, 3) void flush_rows_kernel(
     const int per_round = max(1, FLUSH_ROWS_LDS / (Tp * FLUSH_ZB * (int)sizeof(double)));
     for (int base = 0; base < nslots; base += per_round) {
       const int nhere = min(per_round, nslots - base);
-      // tables of the runs base .. base + nhere - 1: Us[slot][q][r] = U[area][z0 + r][q]
-      for (int i = threadIdx.x; i < nhere * Tp * FLUSH_ZB; i += 256) {
-        const int sl = i / (Tp * FLUSH_ZB), rem = i - sl * (Tp * FLUSH_ZB);
-        const int r = rem / Tp, q = rem - r * Tp;  // (q fastest: consecutive addresses of U)
+      // tables of the runs base .. base + nhere - 1: Us[slot][r][q] = U[area][z0 + r][q], q fastest
+      // on both sides (rows of U are PCA_CAP doubles: 8-double pieces, coalesced; no LDS conflicts)
+      for (int i = threadIdx.x; i < (nhere * FLUSH_ZB) << lt; i += 256) {
+        const int q = i & (Tp - 1), r = (i >> lt) & (FLUSH_ZB - 1), sl = i >> (lt + 5);
         const int ar = fr_slot_area[base + sl];
-        const double *Ua = U + (long)ar * Nz * PCA_CAP;
-        fr_us[(sl * Tp + q) * FLUSH_ZB + r] =
-            (z0 + r < Nz && q < aT[ar]) ? Ua[(long)(z0 + r) * PCA_CAP + q] : 0.0;
+        fr_us[i] = (z0 + r < Nz && q < aT[ar])
+                       ? U[((long)ar * Nz + z0 + r) * PCA_CAP + q] : 0.0;
       }
       __syncthreads();
       if (a >= 0 && slot >= base && slot < base + nhere) {
-        const double *us = fr_us + (long)(slot - base) * Tp * FLUSH_ZB;
+        const double *us = fr_us + ((long)(slot - base) * FLUSH_ZB << lt);
         for (int q0 = 0; q0 < T; q0 += 8) {
-          double c[8];  // independent loads; entries beyond T multiply zero rows of the table
+          double c[8];  // independent loads; entries beyond T multiply zero entries of the table
 #pragma unroll
           for (int e = 0; e < 8; ++e) c[e] = q0 + e < T ? C[(long)(q0 + e) * ntot + pos] : 0.0;
+          const double *uq = us + q0;
 #pragma unroll
           for (int r = 0; r < FLUSH_ZB; r += 2) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const double2 u2 = *reinterpret_cast<const double2 *>(us + (q0 + e) * FLUSH_ZB + r);
-              acc[r] = fma(u2.x, c[e], acc[r]);
-              acc[r + 1] = fma(u2.y, c[e], acc[r + 1]);
+            for (int e = 0; e < 8; e += 2) {
+              const double2 ua = *reinterpret_cast<const double2 *>(uq + ((long)r << lt) + e);
+              const double2 ub = *reinterpret_cast<const double2 *>(uq + ((long)(r + 1) << lt) + e);
+              acc[r] = fma(ua.x, c[e], acc[r]);
+              acc[r] = fma(ua.y, c[e + 1], acc[r]);
+              acc[r + 1] = fma(ub.x, c[e], acc[r + 1]);
+              acc[r + 1] = fma(ub.y, c[e + 1], acc[r + 1]);
             }
             __builtin_amdgcn_sched_barrier(0);
           }
