@@ -688,7 +688,10 @@ int origin_local_max_sparse(origin_ctx *ctx, const float *d_correl, const float 
                        (float *)nullptr, (float *)nullptr, sp);
   else
   {
-    static const int xcd_order = getenv("ORIGIN_LOCALMAX_XCD") ? atoi(getenv("ORIGIN_LOCALMAX_XCD")) : 1;
+    // (XCD-contiguous block order: measured 3.39 ms against 3.26 with the natural order at
+    // 3681 x 600 x 600 -- the rows two neighbouring blocks share are not what the pass waits for;
+    // off unless ORIGIN_LOCALMAX_XCD=1)
+    static const int xcd_order = getenv("ORIGIN_LOCALMAX_XCD") ? atoi(getenv("ORIGIN_LOCALMAX_XCD")) : 0;
     const dim3 grid((unsigned)(g.bx * g.nzc * 2));
     if (d_mask)
       hipLaunchKernelGGL(local_max3s_kernel<true>, grid, dim3(256), 0, ctx->stream, d_correl,

@@ -2967,7 +2967,11 @@ int origin_pca_run_into(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, l
   const bool row_dot = getenv("ORIGIN_PCA_AREA_DOT") == nullptr;
   if ((rc = W.b[19].reserve(ctx, (size_t)2 * S * sizeof(int)))) return rc;
   int *d_area_of = (int *)W.b[19].p, *d_pos_of = d_area_of + S;
-  const bool row_flush = getenv("ORIGIN_PCA_AREA_FLUSH") == nullptr;
+  // (flush_rows_kernel, round 4: 4.15 ms against 2.96 for the area-order flush_kernel at
+  // 3681 x 600 x 600 -- per block of 256 spaxels x 32 channels the run detection, the tables of
+  // three or four areas and four block barriers cost more than the cut lines they save; kept
+  // behind ORIGIN_PCA_ROW_FLUSH=1)
+  const bool row_flush = getenv("ORIGIN_PCA_ROW_FLUSH") != nullptr;
   if (row_dot || row_flush) {
     int nsm = 0;
     for (int a = 0; a < na; ++a) nsm = std::max(nsm, (int)(h_spx_off[a + 1] - h_spx_off[a]));
