@@ -117,12 +117,31 @@ struct SmState {
 
 // Epilogue item o of a profile pair: output o of the lane is accumulator register o (profile a)
 // and o + 8 (profile b).
-template <int O, bool FOLD>
+// EPI_FIRST (FOLD, round 4): the epilogue of a half tile's FIRST pair writes the state instead of
+// updating it -- the same five instructions with -inf / +inf (scalar operands) in the state's
+// place, so that the state needs no initialisation (24 v_mov per half tile).
+constexpr int EPI_UPDATE = 0, EPI_FIRST = 1, EPI_NONE = 2;
+template <int O, bool FOLD, int MODE = EPI_UPDATE>
 __device__ __forceinline__ void sm_epi_item(const f32x16 &acc, const f32x4v (&fa)[2],
                                             const f32x4v (&fb)[2], SmState &st, unsigned maskv,
                                             int ca, int cb) {
   constexpr int g = O >> 2, q = O & 3;
   float T0, T1, K0, K1;
+  if constexpr (MODE == EPI_NONE) return;
+  if constexpr (FOLD && MODE == EPI_FIRST) {
+    // (a VOP3 instruction reads ONE scalar register: the and-ors take ca / cb, the extrema the
+    // infinities; NaN accumulators are ignored by v_max3 / v_min3 as in the update form)
+    const int ninf = 0xff800000, pinf = 0x7f800000;
+    asm volatile(
+        "v_and_or_b32 %0, %5, %7, %8\n\t"
+        "v_and_or_b32 %1, %6, %7, %9\n\t"
+        "v_max3_f32 %2, %10, %0, %1\n\t"
+        "v_max3_f32 %3, %10, %5, %6\n\t"
+        "v_min3_f32 %4, %11, %5, %6"
+        : "=&v"(K0), "=&v"(K1), "=&v"(st.key[O]), "=&v"(st.best[O]), "=&v"(st.worst[O])
+        : "v"(acc[O]), "v"(acc[O + 8]), "v"(maskv), "s"(ca), "s"(cb), "s"(ninf), "s"(pinf));
+    return;
+  }
   if constexpr (FOLD) {  // the taps carry a_k: the accumulators are compared as they are
     asm volatile(
         "v_and_or_b32 %0, %5, %7, %8\n\t"
@@ -165,7 +184,7 @@ constexpr int sm_epi_start(int j, int NM) {
 // FOLD (the registers of the 1/sqrt(den) values are free): the fragments of block 1 arrive in
 // fh / fl -- requested by the stage before, behind its own last request -- and leave as the next
 // stage's (ak_next), so that no stage opens with a wait for LDS.
-template <int TERMS, int OFF, bool FOLD>
+template <int TERMS, int OFF, bool FOLD, int MODE = EPI_UPDATE>
 __device__ __forceinline__ void sm_stage(const char *ak, const char *ak_next, u32x4v &fh,
                                          u32x4v &fl, bool wide, const u32x4v (&bh)[6],
                                          const u32x4v (&bl)[6], f32x16 &acc, const f32x16 &pacc,
@@ -194,7 +213,7 @@ __device__ __forceinline__ void sm_stage(const char *ak, const char *ak_next, u3
     auto gap = [&](auto jc) {
       constexpr int j = decltype(jc)::value;
       sm_for<sm_epi_start(j, NM), sm_epi_start(j + 1, NM)>([&](auto kc) {
-        sm_epi_item<decltype(kc)::value, FOLD>(pacc, pfa, pfb, st, maskv, pca, pcb);
+        sm_epi_item<decltype(kc)::value, FOLD, MODE>(pacc, pfa, pfb, st, maskv, pca, pcb);
       });
     };
     sm_mma<TERMS, g == 0>(acc, ah, bh[OFF + ks]);
@@ -435,9 +454,14 @@ __device__ __forceinline__ void sm_tiles(
       else load_new_blocks(z0, xb);
       int se = 127;
       if constexpr (TERMS == 3) {
+        // (one v_max3 with |.| modifiers per two values: fmaxf(m, fabsf(x)) is a canonicalising
+        // maximum per value)
         float m4 = 0.0f, m5 = 0.0f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) m4 = fmaxf(m4, fabsf(xb[0][j])), m5 = fmaxf(m5, fabsf(xb[1][j]));
+        for (int j = 0; j < 8; j += 2) {
+          asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m4) : "v"(xb[0][j]), "v"(xb[0][j + 1]));
+          asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m5) : "v"(xb[1][j]), "v"(xb[1][j + 1]));
+        }
         bmx[0] = bmx[2], bmx[1] = bmx[3], bmx[2] = bmx[4], bmx[3] = bmx[5];
         bmx[4] = wave_max(m4), bmx[5] = wave_max(m5);
         int mm = max(max(max(bmx[0], bmx[1]), max(bmx[2], bmx[3])), max(bmx[4], bmx[5]));
@@ -549,9 +573,11 @@ __device__ __forceinline__ void sm_tiles(
         for (int g = 0; g < 2; ++g) sg[g] = *reinterpret_cast<const f32x4v *>(sdl + zh + 8 * g);
       }
       SmState st;
+      if constexpr (!FOLD) {   // (FOLD: the first pair's epilogue writes the state, EPI_FIRST)
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        st.best[i] = -INFINITY, st.worst[i] = INFINITY, st.key[i] = -INFINITY;
+        for (int i = 0; i < 8; ++i)
+          st.best[i] = -INFINITY, st.worst[i] = INFINITY, st.key[i] = -INFINITY;
+      }
 
       // profile pairs, software pipelined; two accumulators in ping-pong: a stage writes one
       // while the epilogue of the pair before reads the other.  The first stage runs the same
@@ -562,17 +588,9 @@ __device__ __forceinline__ void sm_tiles(
       int ca = 0, cb = 0;
 #pragma unroll
       for (int g = 0; g < 2; ++g) fa[g] = fb[g] = (f32x4v){NAN, NAN, NAN, NAN};
-      if constexpr (FOLD) {  // the neutral "previous pair": NaN accumulators (ignored by max3 / min3)
-        // (the NaN comes out of an asm statement: as a constant the sixteen copies are hoisted out
-        // of the tile loop and spilled)
-        float nanv;
-        asm volatile("v_mov_b32 %0, 0x7fc00000" : "=v"(nanv));
-#pragma unroll
-        for (int i = 0; i < 16; ++i) accY[i] = nanv;
-        asm volatile("s_nop 1" : "+v"(accY));
-      } else {
-        asm volatile("s_nop 1" : "=v"(accY));  // (accY: any bits; B fragment writes -> first MFMA)
-      }
+      // (accY: any bits -- FOLD: the first stage has no epilogue, EPI_NONE; exact form: its neutral
+      // "previous pair" comes from the NaN 1/sqrt(den) values.  B fragment writes -> first MFMA)
+      asm volatile("s_nop 1" : "=v"(accY));
       // the lane's own profile of the pair: slot 2p (rows 0-15) or 2p+1 (rows 16-31; an odd K's
       // last profile sits in LDS twice): one pointer, a constant step per pair
       const char *akp = a_lane + (second ? MF_PROF_BYTES : 0);
@@ -581,7 +599,8 @@ __device__ __forceinline__ void sm_tiles(
         fh = *reinterpret_cast<const u32x4v *>(akp + 32), fl = fh;
         if constexpr (TERMS == 3) fl = *reinterpret_cast<const u32x4v *>(akp + 32 + 8 * MF_COPY_BYTES);
       }
-      auto run = [&](int p, f32x16 &wacc, const f32x16 &racc) {
+      auto run = [&](int p, f32x16 &wacc, const f32x16 &racc, auto mode_c) {
+        constexpr int MODE = decltype(mode_c)::value;
         const int sa = 2 * p, sb = min(2 * p + 1, K - 1);  // (odd K: the last profile twice)
         int ia, ib;
         if constexpr (IDENT) {
@@ -591,8 +610,8 @@ __device__ __forceinline__ void sm_tiles(
         }
         const char *ak = akp;
         akp += 2 * MF_PROF_BYTES;
-        sm_stage<TERMS, HALF, FOLD>(ak, akp, fh, fl, ((ia | ib) >> 8) != 0, bh, bl, wacc, racc, fa,
-                                    fb, st, maskv, ca, cb);
+        sm_stage<TERMS, HALF, FOLD, MODE>(ak, akp, fh, fl, ((ia | ib) >> 8) != 0, bh, bl, wacc,
+                                          racc, fa, fb, st, maskv, ca, cb);
         // 1/sqrt(den) of this pair for the lane's 8 channels: requested now (the epilogue that
         // read the previous values is done), used from the third MFMA gap of the next stage
         const int ka = ia & 0xff, kb = ib & 0xff;
@@ -613,13 +632,23 @@ __device__ __forceinline__ void sm_tiles(
         }
         ca = 31 - ka, cb = 31 - kb;
       };
+      using UpdC = std::integral_constant<int, EPI_UPDATE>;
       int p = 0;
+      if constexpr (FOLD) {
+        // (the launch gives FOLD plans at least two pairs.)  Stage 0 has no pair before it: no
+        // epilogue in its gaps, no neutral accumulator to set up; stage 1 carries the epilogue that
+        // WRITES the state: per half tile 16 + 24 register moves and eight wasted epilogue items
+        // (40 VALU instructions) less than with one stage body for all pairs
+        run(0, accX, accY, std::integral_constant<int, EPI_NONE>{});
+        run(1, accY, accX, std::integral_constant<int, EPI_FIRST>{});
+        p = 2;
+      }
       for (; p + 1 < NP; p += 2) {
-        run(p, accX, accY);
-        run(p + 1, accY, accX);
+        run(p, accX, accY, UpdC{});
+        run(p + 1, accY, accX, UpdC{});
       }
       if constexpr (PODD) {
-        run(p, accX, accY);
+        run(p, accX, accY, UpdC{});
         sm_drain<FOLD>(accX, fa, fb, st, maskv, ca, cb);
       } else {
         sm_drain<FOLD>(accY, fa, fb, st, maskv, ca, cb);
@@ -888,7 +917,7 @@ int origin_spectral_mfma_launch(origin_ctx *ctx, int terms, const float *fsf, co
   }
   // (LDS: the tap copies and the staging rows -- K <= 24 with twelve waves)
   const size_t lds_fold = (size_t)Kp * MF_PROF_BYTES + (size_t)MF_WAVES * MF_STAGE_BYTES;
-  if (!mf_fold_fits(K)) zf0 = zf1 = 0;
+  if (!mf_fold_fits(K) || NP < 2) zf0 = zf1 = 0;  // (the FOLD pair loop peels its first two stages)
   const int fold = zf1 > zf0;
   const void *fn = pick(fold);
   if (!fn) {

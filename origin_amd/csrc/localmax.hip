@@ -314,7 +314,7 @@ struct LmPlane {
   float c[R][4];  // the plane's own samples there
 };
 
-template <int SIGN, int R, bool HAS_MASK>
+template <int SIGN, int R, bool HAS_MASK, bool PREFETCH>
 __device__ __forceinline__ void lm_sparse_march(const float *__restrict__ a,
                                                 const uint8_t *__restrict__ mask, int Nz, int Ny,
                                                 int Nx, int zper, long long *__restrict__ idx_out,
@@ -345,9 +345,9 @@ __device__ __forceinline__ void lm_sparse_march(const float *__restrict__ a,
   for (int r = 0; r < R; ++r) okrow[r] = __ballot(live && yb + r < Ny);
   const unsigned lane_lo = lane < 32 ? 1u << lane : 0u, lane_hi = lane < 32 ? 0u : 1u << (lane - 32);
 
-  auto plane = [&](int z, LmPlane<R> &o) {
+  // the R + 2 rows of plane z around the lane's outputs
+  auto fetch = [&](int z, float4 (&v)[R + 2]) {
     const char *pz = reinterpret_cast<const char *>(a + (long)min(max(z, 0), Nz - 1) * S);
-    float4 v[R + 2];
 #pragma unroll
     for (int r = 0; r < R + 2; ++r) {
       // (the empty asm keeps the 32-bit offset's zero-extension next to the load: "SGPR base +
@@ -355,6 +355,17 @@ __device__ __forceinline__ void lm_sparse_march(const float *__restrict__ a,
       unsigned o = roff[r];
       asm volatile("" : "+v"(o));
       v[r] = *reinterpret_cast<const float4 *>(pz + o);
+    }
+  };
+  float4 vnext[R + 2];   // PREFETCH: the rows of the plane after next, requested a channel ahead
+  auto plane = [&](int z, LmPlane<R> &o) {
+    float4 v[R + 2];
+    if constexpr (PREFETCH) {
+#pragma unroll
+      for (int r = 0; r < R + 2; ++r) v[r] = vnext[r];
+      fetch(z + 1, vnext);
+    } else {
+      fetch(z, v);
     }
     float xm[R + 2][4];
 #pragma unroll
@@ -417,6 +428,7 @@ __device__ __forceinline__ void lm_sparse_march(const float *__restrict__ a,
       }
   };
   LmPlane<R> A, B, C;
+  if constexpr (PREFETCH) fetch(z0 - 1, vnext);
   plane(z0 - 1, A);
   plane(z0, B);
   int z = z0;
@@ -441,8 +453,8 @@ constexpr int LMS_R = 4;  // rows per lane of the sparse pass
 // passes: 1.4 x the read bytes).  So the ids are decoded such that an XCD gets a contiguous range
 // of the (cube, z chunk, spaxel block) order: neighbours in that order run on the same XCD at about
 // the same time and find each other's rows in its L2.
-template <bool HAS_MASK>
-__global__ __launch_bounds__(256, 4) void local_max3s_kernel(const float *__restrict__ a0,
+template <bool HAS_MASK, bool PREFETCH>
+__global__ __launch_bounds__(256, PREFETCH ? 3 : 4) void local_max3s_kernel(const float *__restrict__ a0,
                                                           const float *__restrict__ a1,
                                                           const uint8_t *__restrict__ mask, int Nz,
                                                           int Ny, int Nx, int zper, long nbx, int nzc,
@@ -457,10 +469,10 @@ __global__ __launch_bounds__(256, 4) void local_max3s_kernel(const float *__rest
   const int bzi = (int)(t % nzc), cube = (int)(t / nzc);
   const long nwaves = nbx * nzc * 4;
   if (cube == 0)
-    lm_sparse_march<1, LMS_R, HAS_MASK>(a0, mask, Nz, Ny, Nx, zper, sp.idx0, sp.val0, sp.counts,
+    lm_sparse_march<1, LMS_R, HAS_MASK, PREFETCH>(a0, mask, Nz, Ny, Nx, zper, sp.idx0, sp.val0, sp.counts,
                                         sp.seg_cap, bxi, bzi, nbx);
   else
-    lm_sparse_march<-1, LMS_R, HAS_MASK>(a1, mask, Nz, Ny, Nx, zper, sp.idx1, sp.val1,
+    lm_sparse_march<-1, LMS_R, HAS_MASK, PREFETCH>(a1, mask, Nz, Ny, Nx, zper, sp.idx1, sp.val1,
                                          sp.counts + nwaves, sp.seg_cap, bxi, bzi, nbx);
 }
 
@@ -692,13 +704,18 @@ int origin_local_max_sparse(origin_ctx *ctx, const float *d_correl, const float 
     // 3681 x 600 x 600 -- the rows two neighbouring blocks share are not what the pass waits for;
     // off unless ORIGIN_LOCALMAX_XCD=1)
     static const int xcd_order = getenv("ORIGIN_LOCALMAX_XCD") ? atoi(getenv("ORIGIN_LOCALMAX_XCD")) : 0;
+    // ORIGIN_LOCALMAX_PREFETCH=1: the rows of the plane after next are requested a channel ahead
+    // (24 more registers: three waves per SIMD instead of four, twice the loads in flight per wave)
+    static const int prefetch = getenv("ORIGIN_LOCALMAX_PREFETCH") ? atoi(getenv("ORIGIN_LOCALMAX_PREFETCH")) : 0;
     const dim3 grid((unsigned)(g.bx * g.nzc * 2));
-    if (d_mask)
-      hipLaunchKernelGGL(local_max3s_kernel<true>, grid, dim3(256), 0, ctx->stream, d_correl,
-                         d_correl_min, d_mask, Nz, Ny, Nx, g.zp, g.bx, g.nzc, xcd_order, sp);
-    else
-      hipLaunchKernelGGL(local_max3s_kernel<false>, grid, dim3(256), 0, ctx->stream, d_correl,
-                         d_correl_min, d_mask, Nz, Ny, Nx, g.zp, g.bx, g.nzc, xcd_order, sp);
+#define LM_GO(M, P)                                                                              \
+  hipLaunchKernelGGL((local_max3s_kernel<M, P>), grid, dim3(256), 0, ctx->stream, d_correl,      \
+                     d_correl_min, d_mask, Nz, Ny, Nx, g.zp, g.bx, g.nzc, xcd_order, sp)
+    if (d_mask && prefetch) LM_GO(true, true);
+    else if (d_mask) LM_GO(true, false);
+    else if (prefetch) LM_GO(false, true);
+    else LM_GO(false, false);
+#undef LM_GO
   }
   ORIGIN_LAUNCH_CHECK();
   return ORIGIN_OK;
