@@ -115,6 +115,46 @@ def test_registered_chain_equals_standalone_chain(ref):
     assert a.param['compute_TGLR']['params'] == dict(size=3, ncpu=1, pcut=1e-8, pmeansub=True)
 
 
+@pytest.mark.gpu
+def test_registered_chain_on_two_contexts(ref):
+    """``register(devices=[0, 0])``: the reference-shaped session (its own ``Step.__call__`` and
+    ``store_cube``) drives the hot steps tiled over two contexts of the card -- the one changed
+    line of INTEGRATION section 2 -- and ends with the cubes of the one-device chain (to the
+    rounding of the all-reduced mean and of another tile geometry in the GLR)."""
+    f, raw, var, mask = synth.small_case(Nz=160, Ny=48, Nx=52, seed=3, psf_size=9, nprof=3,
+                                         area_size=24)
+    psf = f.PSF.astype(float)
+    try:
+        hip_steps.register(devices=[0, 0])
+        a = _refstub.Session(ref, raw, var, mask, psf, f.profiles)
+        for step in ("step01_preprocessing",):
+            getattr(a, step)()
+        a.step02_areas.set_areamap(f.areamap)
+        a.step03_compute_PCA_threshold()
+        a.step04_compute_greedy_PCA()
+        a.step05_compute_TGLR()
+        a.step06_compute_purity_threshold()
+        assert a.__dict__["_hip_session"].world == 2
+    finally:
+        hip_steps.register()          # (sessions made from here on: one context again)
+    b = hip_steps.SimpleOrig(raw, var, mask, psf, f.profiles)
+    b.step01_preprocessing()
+    b.step02_areas.set_areamap(f.areamap)
+    b.step03_compute_PCA_threshold()
+    b.step04_compute_greedy_PCA()
+    b.step05_compute_TGLR()
+    b.step06_compute_purity_threshold()
+    assert all(s.status is ref.Status.RUN for s in list(a.steps.values())[:6])
+    assert a.cube_faint._data.dtype == np.float64 and a.cube_profile._data.dtype == np.uint8
+    np.testing.assert_array_equal(np.asarray(a.mapO2._data), np.asarray(b.mapO2))
+    for label, tol in (('cube_std', 1e-6), ('cube_faint', 1e-6), ('cube_correl', 1e-4),
+                       ('cube_correl_min', 1e-4)):
+        assert np.max(np.abs(getattr(a, label)._data - getattr(b, label)._data)) <= tol, label
+    assert np.max(np.abs(np.asarray(a.maxmap._data) - np.asarray(b.maxmap))) <= 1e-4
+    assert np.isclose(a.param['threshold'], b.param['threshold'], rtol=1e-5, equal_nan=True)
+    a.__dict__["_hip_session"].close()
+
+
 def test_register_against_the_real_reference_module():
     """oracle/check_register.py: register() on the reference's REAL muse_origin/steps.py
     (metaclass, Step.__call__, STEPS, the way ORIGIN.__init__ instantiates the steps) -- build
