@@ -306,6 +306,11 @@ def main():
     lmax_buf = ctx.empty((Nz, ny, nx), np.float32) if dense_lm else None
     lmin_buf = ctx.empty((Nz, ny, nx), np.float32) if dense_lm else None
 
+    # tiled: the local maxima of the extended tile, as lists where that tile has a sparse form
+    tiled_sparse = False
+    if world > 1 and args.local_max and not args.dense_local_max:
+        from origin_amd import sparse
+        tiled_sparse = sparse.plan(ctx, glr.eshape)[0] > 0
     glr_key = "glr_and_local_max" if args.local_max else "glr"
 
     area_rows = [(int(s_.min()) // nx, int(s_.max()) // nx) if len(s_) else None for s_ in spx]
@@ -401,7 +406,8 @@ def main():
         if world > 1:
             # (no crop: correl / correl_min / profile and the local maxima stay in the tile's
             # halo-extended arrays, out["box"] is the tile inside them)
-            out = glr.run(None, mask, None, None, None, local_max=True if do_lm else None)
+            lm_form = None if not do_lm else ("sparse" if tiled_sparse else True)
+            out = glr.run(None, mask, None, None, None, local_max=lm_form)
             info["glr_rects"] = {"ahead_of_exchange": len(glr.last_rects[0]),
                                  "behind_exchange": len(glr.last_rects[1]),
                                  "regions_in_pca_tail": glr.last_rects[2]}
@@ -649,7 +655,7 @@ def main():
         tot = comm.allreduce_sum(np.array([(it_mean or 0.0) * len(spx), float(len(spx))]))
         it_mean = float(tot[0] / max(tot[1], 1.0))
     if rank == 0 and it_mean is not None:
-        lm_bpv = 0.0 if not args.local_max else (9.0 if sparse_lm else 17.0)
+        lm_bpv = 0.0 if not args.local_max else (9.0 if (sparse_lm or tiled_sparse) else 17.0)
         bpv = 17.0 + 14.0 + 4.0 * (it_mean + 2.0) + lm_bpv
         gbs = bpv * Nz * N * N / (ms_per_step * 1e-3) / 1e9
         path_hbm = dict(bytes_per_voxel=round(bpv, 2), achieved=round(gbs, 1),

@@ -826,7 +826,9 @@ class TiledGLR:
         the two local-maxima cubes on the device is 34 B/voxel of extra traffic per step, more
         than a third of what the whole path moves.
 
-        ``local_max``: None, or a pair of tile-shaped DeviceArrays that receive
+        ``local_max``: None, ``True`` (dense, in the extended arrays, with correl=None),
+        ``"sparse"`` (the same as lists of the non-zero voxels of the extended cubes:
+        ``sparse.SparseCube`` s), or a pair of tile-shaped DeviceArrays that receive
         ``compute_local_max(correl, correl_min, mask, size)`` (reference steps.py:796).  The
         maximum filter looks size // 2 spaxels beyond the tile, so the tiling's halo must be at
         least P // 2 + size // 2: those neighbours are then exact values of the extended GLR."""
@@ -904,6 +906,21 @@ class TiledGLR:
             if self.tiling.halo < need:
                 raise ValueError(f"local maxima of size {size} on tiles need a halo of {need} "
                                  f"spaxels, the tiling has {self.tiling.halo}")
+            if local_max == "sparse":
+                # (index, value) lists of the extended cubes' non-zero voxels instead of two dense
+                # cubes (origin_amd/sparse.py): indices are those of the EXTENDED tile, entries
+                # outside res["box"] / not owned belong to the neighbours
+                from . import sparse
+                if crop:
+                    raise ValueError("local_max='sparse' goes with correl=None (no crop at all)")
+                if int(size) != 3 or sparse.plan(ctx, self.eshape)[0] == 0:
+                    raise ValueError("no sparse local-maximum form for this tile (size 3, Nx % 4)")
+                if getattr(self, "_lm_sparse", None) is None:
+                    self._lm_sparse = sparse.SparseBuffers(ctx, self.eshape)
+                res["local_max"], res["local_min"] = sparse.local_max_sparse(
+                    ctx, o["correl"], o["correl_min"], self.emask if mask is not None else None,
+                    self._lm_sparse)
+                return res
             if self._lm is None:
                 self._lm = (ctx.empty(self.eshape, np.float32), ctx.empty(self.eshape, np.float32))
             kernels.local_max(ctx, o["correl"], o["correl_min"],

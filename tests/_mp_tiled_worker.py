@@ -228,6 +228,15 @@ def main():
                 got = o2[name].window(by, by + bny, bx, bx + bnx)
                 assert np.array_equal(got, ref_arr.to_host()), name
             assert np.array_equal(o2["maxmap"].to_host(), o["maxmap"].to_host())
+            # and with the local maxima as lists of the extended tile's non-zero voxels
+            from origin_amd import sparse
+            if sparse.plan(ctx, glr.eshape)[0] > 0:
+                dense = [o2["local_max"].to_host(), o2["local_min"].to_host()]
+                o3 = glr.run(faint, d_mask, None, None, None, local_max="sparse")
+                assert isinstance(o3["local_max"], sparse.SparseCube)
+                assert np.array_equal(o3["local_max"].to_host(), dense[0])
+                assert np.array_equal(o3["local_min"].to_host(), dense[1])
+                res["sparse_tile"] = 1
         if into:   # the tile lives inside the extended buffer
             top, _, left, _ = glr.halos
             faint_host = glr.ext.window(top, top + shape[1], left, left + shape[2])
