@@ -30,7 +30,7 @@ FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
 F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA (no sparsity)
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summaries of this command (tools/collect_profiles.sh), newest
 # first: the traffic figure of the dominant kernel is read from the first one that exists
-PMC_PROFILES = ("r03_pmc_fetch_write.json", "r02_pmc_fetch_write.json")
+PMC_PROFILES = ("r04_pmc_fetch_write.json", "r03_pmc_fetch_write.json", "r02_pmc_fetch_write.json")
 MFMA_FLOP = 32768.0        # one v_mfma_f32_32x32x16_{f16,bf16}: 32 x 32 x 16 x 2
 # kernel classes of the built-in profiler -> kernel names in the rocprofv3 summaries
 PROFILE_KERNELS = {"glr_spectral": ["spectral_mfma2_kernel", "spectral3_kernel"],
@@ -38,7 +38,8 @@ PROFILE_KERNELS = {"glr_spectral": ["spectral_mfma2_kernel", "spectral3_kernel"]
                    "dct_fit": ["dct_moments_kernel"], "dct_plane_sums": ["dct_part_reduce_kernel"],
                    "dct_standardize": ["dct_standardize_kernel"],
                    "pca_deflate_dot": ["deflate_dot_rows_kernel", "deflate_dot_kernel"],
-                   "pca_flush": ["flush_kernel"], "local_max": ["local_max3v_kernel", "local_max3_kernel"]}
+                   "pca_flush": ["flush_kernel"],
+                   "local_max": ["local_max3s_kernel", "local_max3v_kernel", "local_max3_kernel"]}
 
 
 def executed_tflops(mfma_instructions, avg_launch_s):

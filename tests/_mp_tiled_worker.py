@@ -230,7 +230,9 @@ def main():
             assert np.array_equal(o2["maxmap"].to_host(), o["maxmap"].to_host())
             # and with the local maxima as lists of the extended tile's non-zero voxels
             from origin_amd import sparse
-            if sparse.plan(ctx, glr.eshape)[0] > 0:
+            # (run() exchanges the halo: a collective -- every rank takes this branch or none)
+            has = float(sparse.plan(ctx, glr.eshape)[0] > 0)
+            if comm.group.allreduce(np.array([has]), "min")[0] == 1.0:
                 dense = [o2["local_max"].to_host(), o2["local_min"].to_host()]
                 o3 = glr.run(faint, d_mask, None, None, None, local_max="sparse")
                 assert isinstance(o3["local_max"], sparse.SparseCube)

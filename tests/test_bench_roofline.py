@@ -33,7 +33,7 @@ def _count_model(terms=3, K=20, n_narrow=10, Nz=3681, N=600, P=25, num_cu=256):
 
 def _profile_pair():
     """Newest (counter json, kernel stats csv) pair of one round that holds both kernels."""
-    for tag in ("r03", "r02"):
+    for tag in ("r04", "r03", "r02"):
         pj = os.path.join(ROOT, "profiles", f"{tag}_glr_pmc.json")
         pc = os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv")
         if os.path.exists(pj) and os.path.exists(pc):
