@@ -35,6 +35,7 @@
 // accesses otherwise), one field or a mosaic of weighted fields (WEIGHTED); other PSF sizes stay
 // on spatial4x4_kernel / spatial_kernel.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -105,8 +106,15 @@ __device__ __forceinline__ void s2_split(float y, _Float16 &hi, _Float16 &lo) {
 // WEIGHTED: one field of a mosaic (lib_origin.py:1029-1031, :1134-1147): the input is cube * W
 // (W [Ny][Nx], the field's weight map, multiplied in while the tile is staged) and, with accf,
 // the result is added to what the fields before left in `out`.
-template <int P, int TERMS, bool VEC, bool WEIGHTED>
-__global__ __launch_bounds__(512, 1) void spatial2_kernel(const float *__restrict__ A,
+// SOLO (round 4): a block is ONE group of four waves (256 threads, half the LDS) that converts and
+// multiplies its channels one after the other, and a CU holds TWO such blocks.  The two-group
+// block keeps its groups in lock step (one block barrier per phase): while one group runs its MFMA
+// phase (~9.6 k cycles: 1.2 k of loads in front, 6.3 k of k-steps, 1.5 k of scale reduction and
+// stores behind) the other converts (2.2 k) and then WAITS at the barrier -- one channel per 9.6 k
+// cycles and CU, the matrix pipe ~55 % busy.  Two independent blocks drift apart and fill each
+// other's gaps: everything around a block's k-step loop runs beside the other block's MFMAs.
+template <int P, int TERMS, bool VEC, bool WEIGHTED, bool SOLO = false>
+__global__ __launch_bounds__(SOLO ? 256 : 512, SOLO ? 2 : 1) void spatial2_kernel(const float *__restrict__ A,
                                                           const float *__restrict__ W,
                                                           const float *__restrict__ taps, int Nz,
                                                           int Ny, int Nx, int zper, int accf,
@@ -120,7 +128,7 @@ __global__ __launch_bounds__(512, 1) void spatial2_kernel(const float *__restric
   constexpr size_t GB = s2_group_bytes<P, TERMS>();
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2, gw = wave & 3, gt = tid & 255;  // group, wave / thread in group
+  const int grp = SOLO ? 0 : wave >> 2, gw = wave & 3, gt = tid & 255;  // group, wave / thread in group
   char *base = s2_lds + grp * GB;
   char *img_h = base, *img_l = base + (TERMS == 3 ? G::IMG : 0);
   char *tab_h = base + (TERMS == 3 ? 2 : 1) * G::IMG, *tab_l = tab_h + (TERMS == 3 ? G::TAB : 0);
@@ -133,7 +141,7 @@ __global__ __launch_bounds__(512, 1) void spatial2_kernel(const float *__restric
   const int n = lane & 31, h = lane >> 5;
 
   // ---- zero everything once: table rows outside the PSF stay zero for good, image pads finite
-  for (int i = tid; i < (int)(2 * GB / 16); i += 512)
+  for (int i = tid; i < (int)((SOLO ? 1 : 2) * GB / 16); i += (SOLO ? 256 : 512))
     reinterpret_cast<uint4 *>(s2_lds)[i] = make_uint4(0u, 0u, 0u, 0u);
 
   // ---- register staging of this group's NEXT channel: input tile, taps
@@ -348,6 +356,28 @@ __global__ __launch_bounds__(512, 1) void spatial2_kernel(const float *__restric
   // ---- schedule.  Group g takes channels z0 + g + 2 i; in phase p it converts channel i when
   // p = 2 i + g and runs the MFMAs of channel i when p = 2 i + g + 1.  One barrier per phase.
   const int nch = z1 - z0;
+  if constexpr (SOLO) {
+    // one group, every channel of the chunk: convert (tile and taps are in registers / staging),
+    // barrier (image and table complete), request the next channel's tile and taps, MFMAs + stores,
+    // publish the next tile's maximum and taps, barrier (everybody is done reading image and table)
+    __syncthreads();  // zero fill done
+    if (nch > 0) {
+      prefetch(z0);
+      publish(0);
+    }
+    __syncthreads();
+    float inv_s = 1.f;
+    for (int i = 0; i < nch; ++i) {
+      p = i;
+      convert(i & 1, inv_s);
+      __syncthreads();
+      if (i + 1 < nch) prefetch(z0 + i + 1);
+      mfma_phase(z0 + i, inv_s);
+      if (i + 1 < nch) publish((i + 1) & 1);
+      __syncthreads();
+    }
+    return;
+  }
   const int ng = (nch - grp + 1) / 2;  // channels of this group
   __syncthreads();                     // zero fill done
   if (ng > 0) {
@@ -387,6 +417,36 @@ int origin_spatial_mfma_ok(int Ny, int Nx, int P) {
 template <int P, int TERMS, bool VEC, bool WEIGHTED>
 static int s2_launch(origin_ctx *ctx, const float *A, const float *W, const float *taps, int Nz,
                      int Ny, int Nx, int accf, float *out, int ry0, int nry, int rx0, int nrx) {
+  // ORIGIN_GLR_SPATIAL_SOLO=0: the two-group block of rounds 2-3
+  static const bool solo = !(getenv("ORIGIN_GLR_SPATIAL_SOLO") && atoi(getenv("ORIGIN_GLR_SPATIAL_SOLO")) == 0);
+  if (solo) {
+    const size_t lds1 = s2_group_bytes<P, TERMS>();
+    static OriginPerDeviceOnce attr1;
+    ORIGIN_ONCE_PER_DEVICE(ctx, attr1,
+                           ORIGIN_HIP(hipFuncSetAttribute(
+                               (const void *)spatial2_kernel<P, TERMS, VEC, WEIGHTED, true>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1)));
+    if (nry <= 0) ry0 = 0, nry = cdiv(Ny, S2_R);
+    if (nrx <= 0) rx0 = 0, nrx = cdiv(Nx, S2_R);
+    const long regions = (long)nrx * nry;
+    const int slots = 2 * std::max(1, ctx->num_cu);  // two blocks per CU at a time
+    int best_nzb = 1;
+    double best_eff = 0.0;
+    for (int nzb = 1; nzb <= std::max(1, Nz / 16); ++nzb) {
+      const int zp = cdiv(Nz, nzb);
+      const long blocks = regions * cdiv(Nz, zp);
+      const long rounds = (blocks + slots - 1) / slots;
+      // useful channel slots / (rounds x chunk length x block slots), ~2 channels of start-up per block
+      const double eff = (double)regions * Nz / ((double)rounds * slots * (zp + 2));
+      if (eff > best_eff) best_eff = eff, best_nzb = nzb;
+    }
+    const int zper = cdiv(Nz, best_nzb);
+    dim3 grid(nrx, nry, cdiv(Nz, zper));
+    hipLaunchKernelGGL((spatial2_kernel<P, TERMS, VEC, WEIGHTED, true>), grid, dim3(256), lds1,
+                       ctx->stream, A, W, taps, Nz, Ny, Nx, zper, accf, out, ry0, rx0);
+    ORIGIN_LAUNCH_CHECK();
+    return ORIGIN_OK;
+  }
   const size_t lds = 2 * s2_group_bytes<P, TERMS>();
   static OriginPerDeviceOnce attr_once;
   ORIGIN_ONCE_PER_DEVICE(ctx, attr_once,
