@@ -8,7 +8,9 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBNAME = "liborigin_hip.so"
-LIBPATH = os.path.join(HERE, LIBNAME)
+# (ORIGIN_HIP_LIB: another build of the same library -- kernel variants compiled with
+# ORIGIN_HIPCC_FLAGS for A/B timing runs, tools/)
+LIBPATH = os.environ.get("ORIGIN_HIP_LIB") or os.path.join(HERE, LIBNAME)
 
 vp = C.c_void_p
 i32 = C.c_int

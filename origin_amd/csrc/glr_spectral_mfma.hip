@@ -75,6 +75,17 @@ namespace {
 // registers (240 VGPRs) 12.6 ms, three waves per SIMD without it (168 VGPRs) 11.7 ms.
 constexpr bool SM_PREFETCH = MF_WAVES <= 8;
 
+// -DSM_TIMING: clock64 stamps of block (3, 1), every wave, tiles 2..9 of the chunk's FOLD range
+// (tools/sm_phase_times.py; a stamp is an s_memtime round trip: read the numbers as shares)
+#ifdef SM_TIMING
+__device__ long long sm_tim[8 * MF_WAVES * 8];
+#define SM_STAMP(k)                                                                       \
+  if (blockIdx.x == 3 && blockIdx.y == 1 && lane == 0 && sm_tile >= 2 && sm_tile < 10)    \
+  sm_tim[((sm_tile - 2) * MF_WAVES + (threadIdx.x >> 6)) * 8 + (k)] = clock64()
+#else
+#define SM_STAMP(k)
+#endif
+
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -378,7 +389,11 @@ __device__ __forceinline__ void sm_tiles(
   };
   int bmx[6] = {0, 0, 0, 0, 0, 0};  // max |x| of each window block (float bits, wave-uniform)
   int se_cur = 127;                 // exponent field of the scale the fragments are stored under
+  int sm_tile = -1;
+  (void)sm_tile;
   for (int z0 = zc0; z0 < zc1; z0 += 32) {
+    ++sm_tile;
+    SM_STAMP(0);
     // ---- 1/sqrt(den)[slot][z0 .. z0+31] of the interior class -> this wave's LDS table (raw:
     // the power-of-two unscaling is applied to the final max / min).  rdi_s is in processing
     // order [slot][NzP]: element i = lane + 64 q is slot (lane>>5) + 2q, channel lane & 31
@@ -519,6 +534,7 @@ __device__ __forceinline__ void sm_tiles(
       inv = __uint_as_float((unsigned)(254 - se_cur - MF_TAP_SCALE_LOG2) << 23);
     }
 
+    SM_STAMP(1);
     // FOLD: request the next tile's two new blocks now; they land in the wave's staging rows
     // while this tile's pairs run and are picked up behind the second half's pairs
     if constexpr (FOLD) {
@@ -647,12 +663,14 @@ __device__ __forceinline__ void sm_tiles(
         run(p, accX, accY, UpdC{});
         run(p + 1, accY, accX, UpdC{});
       }
+      SM_STAMP(2 + 3 * HALF);
       if constexpr (PODD) {
         run(p, accX, accY, UpdC{});
         sm_drain<FOLD>(accX, fa, fb, st, maskv, ca, cb);
       } else {
         sm_drain<FOLD>(accY, fa, fb, st, maskv, ca, cb);
       }
+      SM_STAMP(3 + 3 * HALF);
 
       // store (mask glue: steps.py:781,788)
       auto store = [&](auto straight_c) {
@@ -698,6 +716,7 @@ __device__ __forceinline__ void sm_tiles(
       };
       if (inside && all_valid) store(std::true_type{});
       else store(std::false_type{});
+      SM_STAMP(4 + 3 * HALF);
     });
   }
 }
@@ -715,35 +734,47 @@ __global__ __launch_bounds__(64 * MF_WAVES, 1) void spectral_mfma2_kernel(
     const int *__restrict__ pinfo, int K, int NP, int Nz, int Ny, int Nx, int P, int zchunk, const uint8_t *__restrict__ mask, float *__restrict__ correl,
     uint8_t *__restrict__ profile, float *__restrict__ correl_min, float *__restrict__ part_max,
     float *__restrict__ part_min, const float *__restrict__ sden, int zf0, int zf1, int nN,
-    long s_first, long s_end, int rx0, int rx1) {
+    long s_first, long s_end_launch, int rx0, int rx1, int cols_per_block) {
   // (s_first, s_end: the spaxels of this launch, in multiples of 32 from the field's first -- a run
   // may be split into row bands; waves hold the same 32 spaxels as in a launch over the field.
   // rx1 > 0: a RECTANGLE instead -- the rows s_first / Nx .. s_end / Nx, columns rx0 .. rx1 - 1 of
   // each; a wave holds 32 consecutive columns of one row)
+  // A block owns cols_per_block COLUMNS (32 spaxels x the chunk's channels) and its waves PULL them
+  // from a counter in LDS (round 4).  With one column per wave -- the form of rounds 2-3 -- the
+  // in-kernel clock stamps (-DSM_TIMING, profiles/r04_sm_phase_times.txt) showed the three waves
+  // of a SIMD taking 23 k / 32 k / 49 k cycles per tile: the issue arbiter serves the oldest wave
+  // first, the first wave of a SIMD is done with its nine tiles when the third has done four, and
+  // its slot stays empty until the block ends (the block holds the CU's LDS) -- 2.1 waves per SIMD
+  // on average, one alone at the end.  Pulled columns go to whoever is free.
   extern __shared__ __align__(16) char sm_lds[];
+  __shared__ int sm_next_col;
   const int Kp = K + (K & 1);  // slots in LDS: an odd K's last profile twice (its pair partner)
   {
     constexpr int PV = MF_PROF_BYTES / 16;
     const int nvec = Kp * PV;
     for (int i = threadIdx.x; i < nvec; i += 64 * MF_WAVES)
       reinterpret_cast<uint4 *>(sm_lds)[i] = atab[i < K * PV ? i : i - PV];
+    if (threadIdx.x == 0) sm_next_col = MF_WAVES;  // (the first MF_WAVES columns: one per wave)
   }
   __syncthreads();
   const long S = (long)Ny * Nx;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, in an SGPR
   const int r = lane & 31, h = lane >> 5;
-  long s_base = s_first + ((long)blockIdx.x * MF_WAVES + wv) * 32;
+  const int zc0 = blockIdx.y * zchunk, zc1 = min(Nz, zc0 + zchunk);
+  for (int col = wv; col < cols_per_block;) {
+  long s_end = s_end_launch;
+  const long w_col = (long)blockIdx.x * cols_per_block + col;
+  long s_base = s_first + w_col * 32;
+  bool have = true;
   if (rx1 > 0) {
     const int wpr = (rx1 - rx0 + 31) / 32;  // waves per row
-    const long w = (long)blockIdx.x * MF_WAVES + wv;
-    const long row = s_first / Nx + w / wpr;
-    if (row >= s_end / Nx) return;  // (whole wave)
-    s_base = row * Nx + rx0 + 32 * (int)(w % wpr);
+    const long row = s_first / Nx + w_col / wpr;
+    have = row < s_end / Nx;
+    s_base = row * Nx + rx0 + 32 * (int)(w_col % wpr);
     s_end = row * Nx + rx1;
   }
-  if (s_base >= s_end) return;  // whole wave; no barrier follows
-  const int zc0 = blockIdx.y * zchunk, zc1 = min(Nz, zc0 + zchunk);
+  if (!have || s_base >= s_end) break;  // (columns are handed out in order: nothing behind this one)
   // A rows: lane r is output channel zi = r & 15 of the pair's profile r >> 4; its fragment of
   // window block b starts at G[31 - zi + 8 h + 16 b]
   const int E0 = 8 * h - (r & 15) + 31;
@@ -801,6 +832,11 @@ __global__ __launch_bounds__(64 * MF_WAVES, 1) void spectral_mfma2_kernel(
       part_min[(long)blockIdx.y * S + sc] = b;
     }
   }
+  // the next column nobody has taken yet (lane 0 asks, the wave follows)
+  int nxt = 0;
+  if (lane == 0) nxt = atomicAdd(&sm_next_col, 1);
+  col = __builtin_amdgcn_readfirstlane(nxt);
+  }  // columns of this block
 }
 
 }  // namespace
@@ -880,15 +916,22 @@ int origin_spectral_mfma_launch(origin_ctx *ctx, int terms, const float *fsf, co
     origin_set_error("spectral MFMA kernel: bad spaxel range");
     return ORIGIN_E_ARG;
   }
-  bx = cdiv(s_count, 32 * MF_WAVES);
+  // columns (32 spaxels x one z chunk) per block: MF_WAVES x SM_COLS_FACTOR, pulled by the waves
+  static const int cols_factor = getenv("ORIGIN_GLR_SPECTRAL_COLS") ? std::max(1, atoi(getenv("ORIGIN_GLR_SPECTRAL_COLS"))) : 3;
+  int cols_per_block = MF_WAVES * cols_factor;
+  long ncols = cdiv(s_count, 32);
   long s_end = s_first + s_count;
   if (rx1 > 0) {  // rectangle: whole rows s_first / Nx .. , columns rx0 .. rx1 - 1
     if (s_first % Nx != 0 || s_count % Nx != 0 || rx0 < 0 || rx0 >= rx1 || rx1 > Nx) {
       origin_set_error("spectral MFMA kernel: bad rectangle");
       return ORIGIN_E_ARG;
     }
-    bx = cdiv((s_count / Nx) * (long)cdiv(rx1 - rx0, 32), MF_WAVES);
+    ncols = (s_count / Nx) * (long)cdiv(rx1 - rx0, 32);
   }
+  // (small launches -- narrow row bands, rectangles: keep every CU busy before sharing columns)
+  while (cols_per_block > MF_WAVES && cdiv(ncols, cols_per_block) * (long)nzm < 2L * ctx->num_cu)
+    cols_per_block -= MF_WAVES;
+  bx = cdiv(ncols, cols_per_block);
   // (part_rows: rows of each partial map when other launches add theirs behind this one's)
   float *pmax = want_maps ? part : nullptr;
   float *pmin = want_maps ? part + (size_t)std::max(nzm, part_rows) * S : nullptr;
@@ -935,7 +978,8 @@ int origin_spectral_mfma_launch(origin_ctx *ctx, int terms, const float *fsf, co
   }
   int a_NP = NP, a_zcm = zcm;
   void *args[] = {&fsf, &a_rden, &rdi_s, &NzP, &a_atab, &pinfo, &K, &a_NP, &Nz, &Ny, &Nx, &P, &a_zcm,
-                  &mask, &correl, &profile, &correl_min, &pmax, &pmin, &sden, &zf0, &zf1, &nN, &s_first, &s_end, &rx0, &rx1};
+                  &mask, &correl, &profile, &correl_min, &pmax, &pmin, &sden, &zf0, &zf1, &nN, &s_first, &s_end, &rx0, &rx1,
+                  &cols_per_block};
   ORIGIN_HIP(hipLaunchKernel(fn, dim3((unsigned)bx, (unsigned)nzm), dim3(64 * MF_WAVES), args,
                              fold ? std::max(lds, lds_fold) : lds, ctx->stream));
   ORIGIN_LAUNCH_CHECK();
@@ -944,3 +988,9 @@ int origin_spectral_mfma_launch(origin_ctx *ctx, int terms, const float *fsf, co
   *pmin_out = pmin;
   return ORIGIN_OK;
 }
+
+#ifdef SM_TIMING
+extern "C" int origin_debug_sm_timing(long long *out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sm_tim), sizeof(long long) * 8 * MF_WAVES * 8);
+}
+#endif

@@ -444,7 +444,11 @@ __device__ __forceinline__ void lm_sparse_march(const float *__restrict__ a,
   if (lane == 0) counts[wave_id] = cnt;
 }
 
-constexpr int LMS_R = 4;  // rows per lane of the sparse pass
+#ifndef LMS_R_N
+#define LMS_R_N 4
+#endif
+constexpr int LMS_R = LMS_R_N;  // rows per lane of the sparse pass (119 / ~160 / ~200 VGPRs at 4 / 6 / 8)
+constexpr int LMS_BLOCKS = LMS_R <= 4 ? 4 : (LMS_R <= 6 ? 3 : 2);  // blocks per CU the registers allow
 
 // 1-D grid of nbx * nzc * 2 blocks.  Workgroups go to the 8 XCDs round robin by their id, and a
 // lane's rows yb - 1 and yb + R are the own rows of lanes nx4 = Nx / 4 flattened positions away --
@@ -454,7 +458,7 @@ constexpr int LMS_R = 4;  // rows per lane of the sparse pass
 // of the (cube, z chunk, spaxel block) order: neighbours in that order run on the same XCD at about
 // the same time and find each other's rows in its L2.
 template <bool HAS_MASK, bool PREFETCH>
-__global__ __launch_bounds__(256, PREFETCH ? 3 : 4) void local_max3s_kernel(const float *__restrict__ a0,
+__global__ __launch_bounds__(256, PREFETCH ? (LMS_BLOCKS > 3 ? 3 : LMS_BLOCKS) : LMS_BLOCKS) void local_max3s_kernel(const float *__restrict__ a0,
                                                           const float *__restrict__ a1,
                                                           const uint8_t *__restrict__ mask, int Nz,
                                                           int Ny, int Nx, int zper, long nbx, int nzc,
