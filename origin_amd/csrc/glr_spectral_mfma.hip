@@ -745,7 +745,8 @@ __global__ __launch_bounds__(64 * MF_WAVES, 1) void spectral_mfma2_kernel(
   // of a SIMD taking 23 k / 32 k / 49 k cycles per tile: the issue arbiter serves the oldest wave
   // first, the first wave of a SIMD is done with its nine tiles when the third has done four, and
   // its slot stays empty until the block ends (the block holds the CU's LDS) -- 2.1 waves per SIMD
-  // on average, one alone at the end.  Pulled columns go to whoever is free.
+  // on average, one alone at the end.  Pulled columns go to whoever is free.  (It evens out the
+  // waves and leaves the kernel's time where it was: see the launch.)
   extern __shared__ __align__(16) char sm_lds[];
   __shared__ int sm_next_col;
   const int Kp = K + (K & 1);  // slots in LDS: an odd K's last profile twice (its pair partner)
@@ -917,7 +918,10 @@ int origin_spectral_mfma_launch(origin_ctx *ctx, int terms, const float *fsf, co
     return ORIGIN_E_ARG;
   }
   // columns (32 spaxels x one z chunk) per block: MF_WAVES x SM_COLS_FACTOR, pulled by the waves
-  static const int cols_factor = getenv("ORIGIN_GLR_SPECTRAL_COLS") ? std::max(1, atoi(getenv("ORIGIN_GLR_SPECTRAL_COLS"))) : 3;
+  // (measured at 3681 x 600 x 600 with 1 / 2 / 3 / 4 / 6 columns per wave: 9.59 / 9.80 / 9.72 / 9.80 /
+  // 11.1 ms -- evening out the waves does not move the kernel: while a SIMD's first wave is gone
+  // the other two run that much faster.  One column per wave, as in rounds 2-3, stays the default)
+  static const int cols_factor = getenv("ORIGIN_GLR_SPECTRAL_COLS") ? std::max(1, atoi(getenv("ORIGIN_GLR_SPECTRAL_COLS"))) : 1;
   int cols_per_block = MF_WAVES * cols_factor;
   long ncols = cdiv(s_count, 32);
   long s_end = s_first + s_count;
