@@ -78,6 +78,7 @@ constexpr bool SM_PREFETCH = MF_WAVES <= 8;
 // -DSM_TIMING: clock64 stamps of block (3, 1), every wave, tiles 2..9 of the chunk's FOLD range
 // (tools/sm_phase_times.py; a stamp is an s_memtime round trip: read the numbers as shares)
 #ifdef SM_TIMING
+__device__ long long sm_wave[4 * MF_WAVES * 4];  // blocks (3..6, 1): per wave start, end, columns taken
 __device__ long long sm_tim[8 * MF_WAVES * 8];
 #define SM_STAMP(k)                                                                       \
   if (blockIdx.x == 3 && blockIdx.y == 1 && lane == 0 && sm_tile >= 2 && sm_tile < 10)    \
@@ -763,6 +764,11 @@ __global__ __launch_bounds__(64 * MF_WAVES, 1) void spectral_mfma2_kernel(
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, in an SGPR
   const int r = lane & 31, h = lane >> 5;
   const int zc0 = blockIdx.y * zchunk, zc1 = min(Nz, zc0 + zchunk);
+#ifdef SM_TIMING
+  const bool sm_rec = blockIdx.x >= 3 && blockIdx.x < 7 && blockIdx.y == 1 && lane == 0;
+  long long sm_ncol = 0;
+  if (sm_rec) sm_wave[((blockIdx.x - 3) * MF_WAVES + wv) * 4 + 0] = clock64();
+#endif
   for (int col = wv; col < cols_per_block;) {
   long s_end = s_end_launch;
   const long w_col = (long)blockIdx.x * cols_per_block + col;
@@ -837,7 +843,16 @@ __global__ __launch_bounds__(64 * MF_WAVES, 1) void spectral_mfma2_kernel(
   int nxt = 0;
   if (lane == 0) nxt = atomicAdd(&sm_next_col, 1);
   col = __builtin_amdgcn_readfirstlane(nxt);
+#ifdef SM_TIMING
+  ++sm_ncol;
+#endif
   }  // columns of this block
+#ifdef SM_TIMING
+  if (sm_rec) {
+    sm_wave[((blockIdx.x - 3) * MF_WAVES + wv) * 4 + 1] = clock64();
+    sm_wave[((blockIdx.x - 3) * MF_WAVES + wv) * 4 + 2] = sm_ncol;
+  }
+#endif
 }
 
 }  // namespace
@@ -996,5 +1011,8 @@ int origin_spectral_mfma_launch(origin_ctx *ctx, int terms, const float *fsf, co
 #ifdef SM_TIMING
 extern "C" int origin_debug_sm_timing(long long *out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sm_tim), sizeof(long long) * 8 * MF_WAVES * 8);
+}
+extern "C" int origin_debug_sm_waves(long long *out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sm_wave), sizeof(long long) * 4 * MF_WAVES * 4);
 }
 #endif

@@ -42,3 +42,13 @@ for w in range(NW):
 m = np.median(np.array(allr), axis=0)
 print("median over waves and tiles:", " ".join(f"{n}={int(v)}" for n, v in zip(names + ["tile"], m)))
 print("a tile is 240 MFMAs = 7 680 matrix-pipe cycles per wave, three waves per SIMD")
+wb = (C.c_longlong * (4 * NW * 4))()
+lib.origin_debug_sm_waves.argtypes = [C.c_void_p]
+print("rc", lib.origin_debug_sm_waves(wb))
+wt = np.array(wb[:], dtype=np.int64).reshape(4, NW, 4)
+for b in range(4):
+    t0 = wt[b, :, 0].min()
+    print(f"block {b + 3}: wave (start, end, columns) relative to the block's first wave:")
+    print("   " + "  ".join(f"w{w}:{int(wt[b, w, 0] - t0)}-{int(wt[b, w, 1] - t0)}/{int(wt[b, w, 2])}" for w in range(NW)))
+    print(f"   block lifetime {int(wt[b, :, 1].max() - t0)}, sum of wave lifetimes / (12 x lifetime) = "
+          f"{float((wt[b, :, 1] - wt[b, :, 0]).sum()) / (NW * float(wt[b, :, 1].max() - t0)):.2f}")
