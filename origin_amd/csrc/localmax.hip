@@ -314,7 +314,7 @@ struct LmPlane {
   float c[R][4];  // the plane's own samples there
 };
 
-template <int SIGN, int R, bool HAS_MASK, bool PREFETCH>
+template <int SIGN, int R, bool HAS_MASK, bool PREFETCH, bool STRIPS>
 __device__ __forceinline__ void lm_sparse_march(const float *__restrict__ a,
                                                 const uint8_t *__restrict__ mask, int Nz, int Ny,
                                                 int Nx, int zper, long long *__restrict__ idx_out,
@@ -323,14 +323,32 @@ __device__ __forceinline__ void lm_sparse_march(const float *__restrict__ a,
                                                 int bzi, long nbx) {
   // (bxi, bzi: this block's position among the nbx spaxel blocks and the z chunks)
   const int nx4 = Nx >> 2, ngrp = (Ny + R - 1) / R;
-  const long total = (long)ngrp * nx4;
   const int lane = threadIdx.x & 63;
-  const long wv = bxi * 4 + (threadIdx.x >> 6);
-  const long t_raw = 62 * wv - 1 + lane;
-  const bool live = lane >= 1 && lane <= 62 && t_raw < total;
-  const long t = min(max(t_raw, 0L), total - 1);
-  const int grp = (int)(t / nx4);
-  const int x4 = (int)(t - (long)grp * nx4);
+  bool live;
+  int grp, x4;
+  if constexpr (STRIPS) {
+    // The four waves of a block take four row groups ONE ABOVE THE OTHER (a strip of 4 R rows) at
+    // the same columns: rows yb - 1 and yb + R of a wave are own rows of its siblings, loaded on the
+    // same CU within the same channel step -- they meet in the CU's L1 / the XCD's L2 instead of
+    // coming from memory twice (the counter passes of the flattened mapping below: 13.9 B per voxel
+    // fetched for 8 read, profiles/r04_pmc_fetch_write.json).  Only a strip's outer two rows are
+    // shared with other blocks: (4 R + 2) / 4 R = 1.125 instead of (R + 2) / R = 1.5 row fetches.
+    // Price: a row is cut into chunks of 62 producing lanes, the last one partly empty.
+    const int nxc = (nx4 + 61) / 62;
+    const int sb = (int)(bxi / nxc), xc = (int)(bxi - (long)sb * nxc);
+    grp = min(4 * sb + (int)(threadIdx.x >> 6), ngrp - 1);
+    const int x_raw = 62 * xc - 1 + lane;
+    live = lane >= 1 && lane <= 62 && x_raw < nx4 && 4 * sb + (int)(threadIdx.x >> 6) < ngrp;
+    x4 = min(max(x_raw, 0), nx4 - 1);
+  } else {
+    const long total = (long)ngrp * nx4;
+    const long wv = bxi * 4 + (threadIdx.x >> 6);
+    const long t_raw = 62 * wv - 1 + lane;
+    live = lane >= 1 && lane <= 62 && t_raw < total;
+    const long t = min(max(t_raw, 0L), total - 1);
+    grp = (int)(t / nx4);
+    x4 = (int)(t - (long)grp * nx4);
+  }
   const int yb = grp * R;
   const int z0 = bzi * zper, z1 = min(Nz, z0 + zper);
   const long S = (long)Ny * Nx;
@@ -457,7 +475,7 @@ constexpr int LMS_BLOCKS = LMS_R <= 4 ? 4 : (LMS_R <= 6 ? 3 : 2);  // blocks per
 // passes: 1.4 x the read bytes).  So the ids are decoded such that an XCD gets a contiguous range
 // of the (cube, z chunk, spaxel block) order: neighbours in that order run on the same XCD at about
 // the same time and find each other's rows in its L2.
-template <bool HAS_MASK, bool PREFETCH>
+template <bool HAS_MASK, bool PREFETCH, bool STRIPS>
 __global__ __launch_bounds__(256, PREFETCH ? (LMS_BLOCKS > 3 ? 3 : LMS_BLOCKS) : LMS_BLOCKS) void local_max3s_kernel(const float *__restrict__ a0,
                                                           const float *__restrict__ a1,
                                                           const uint8_t *__restrict__ mask, int Nz,
@@ -473,10 +491,10 @@ __global__ __launch_bounds__(256, PREFETCH ? (LMS_BLOCKS > 3 ? 3 : LMS_BLOCKS) :
   const int bzi = (int)(t % nzc), cube = (int)(t / nzc);
   const long nwaves = nbx * nzc * 4;
   if (cube == 0)
-    lm_sparse_march<1, LMS_R, HAS_MASK, PREFETCH>(a0, mask, Nz, Ny, Nx, zper, sp.idx0, sp.val0, sp.counts,
+    lm_sparse_march<1, LMS_R, HAS_MASK, PREFETCH, STRIPS>(a0, mask, Nz, Ny, Nx, zper, sp.idx0, sp.val0, sp.counts,
                                         sp.seg_cap, bxi, bzi, nbx);
   else
-    lm_sparse_march<-1, LMS_R, HAS_MASK, PREFETCH>(a1, mask, Nz, Ny, Nx, zper, sp.idx1, sp.val1,
+    lm_sparse_march<-1, LMS_R, HAS_MASK, PREFETCH, STRIPS>(a1, mask, Nz, Ny, Nx, zper, sp.idx1, sp.val1,
                                          sp.counts + nwaves, sp.seg_cap, bxi, bzi, nbx);
 }
 
@@ -649,12 +667,20 @@ struct LmGeom {
   int zp, nzc;
 };
 
+// ORIGIN_LOCALMAX_STRIPS=0: the flattened (row group, column) mapping of the first sparse form
+bool lm_strips() {
+  static const bool on = !(getenv("ORIGIN_LOCALMAX_STRIPS") && atoi(getenv("ORIGIN_LOCALMAX_STRIPS")) == 0);
+  return on;
+}
+
 // the launch geometry of the sparse pass (local_max3s_kernel)
 LmGeom lm_geometry(const origin_ctx *ctx, int Nz, int Ny, int Nx) {
   const int R = LMS_R;
   const long threads = (long)cdiv(Ny, R) * (Nx / 4);
   LmGeom g;
   g.bx = (threads + 4 * 62 - 1) / (4 * 62);  // 62 producing lanes per wave
+  if (lm_strips())  // strips of four row groups x chunks of 62 columns
+    g.bx = (long)cdiv(cdiv(Ny, R), 4) * cdiv(Nx / 4, 62);
   int nzc = (int)(((long)ctx->num_cu * 16 + g.bx - 1) / g.bx);  // ~16 blocks per CU
   nzc = nzc < 1 ? 1 : (nzc > cdiv(Nz, 32) ? cdiv(Nz, 32) : nzc);
   g.zp = cdiv(Nz, nzc);
@@ -712,13 +738,16 @@ int origin_local_max_sparse(origin_ctx *ctx, const float *d_correl, const float 
     // (24 more registers: three waves per SIMD instead of four, twice the loads in flight per wave)
     static const int prefetch = getenv("ORIGIN_LOCALMAX_PREFETCH") ? atoi(getenv("ORIGIN_LOCALMAX_PREFETCH")) : 0;
     const dim3 grid((unsigned)(g.bx * g.nzc * 2));
-#define LM_GO(M, P)                                                                              \
-  hipLaunchKernelGGL((local_max3s_kernel<M, P>), grid, dim3(256), 0, ctx->stream, d_correl,      \
+#define LM_GO(M, P, T)                                                                           \
+  hipLaunchKernelGGL((local_max3s_kernel<M, P, T>), grid, dim3(256), 0, ctx->stream, d_correl,   \
                      d_correl_min, d_mask, Nz, Ny, Nx, g.zp, g.bx, g.nzc, xcd_order, sp)
-    if (d_mask && prefetch) LM_GO(true, true);
-    else if (d_mask) LM_GO(true, false);
-    else if (prefetch) LM_GO(false, true);
-    else LM_GO(false, false);
+    if (lm_strips()) {
+      if (d_mask) LM_GO(true, false, true);
+      else LM_GO(false, false, true);
+    } else if (d_mask && prefetch) LM_GO(true, true, false);
+    else if (d_mask) LM_GO(true, false, false);
+    else if (prefetch) LM_GO(false, true, false);
+    else LM_GO(false, false, false);
 #undef LM_GO
   }
   ORIGIN_LAUNCH_CHECK();
