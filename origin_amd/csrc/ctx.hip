@@ -1,6 +1,10 @@
 // Context, device memory, copies and HIP-event timers of liborigin_hip.so.
+#include <sys/mman.h>
+
 #include <algorithm>
 #include <cstdlib>
+#include <map>
+#include <unordered_map>
 
 #include <functional>
 
@@ -10,6 +14,10 @@
 void origin_host_pool_run(int n, const std::function<void(int)> &task);  // thresh.hip (C++ linkage)
 
 static thread_local char g_err[1024] = "";
+
+static void alloc_cache_release(origin_ctx *ctx, bool destroy);  // (allocation cache, below)
+static void alloc_cache_make(origin_ctx *ctx);
+static size_t alloc_cache_spare(origin_ctx *ctx);
 
 // strided (nz, ny, rowbytes) box copy, device to device; 16 bytes per thread when aligned
 __global__ __launch_bounds__(256) void copy_box_kernel(char *__restrict__ dst, long dpy, long dpz,
@@ -299,6 +307,7 @@ int origin_ctx_create(int device, origin_ctx **out) {
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
   if (ctx->num_cu <= 0) ctx->num_cu = 256;
   if (masked_cus > 0 && masked_cus < ctx->num_cu) ctx->num_cu = masked_cus;  // (grids are sized by it)
+  alloc_cache_make(ctx);
   *out = ctx;
   return ORIGIN_OK;
 }
@@ -330,6 +339,7 @@ int origin_ctx_destroy(origin_ctx *ctx) {
       hipEventDestroy(ctx->cvt_ev[b]);
     }
   }
+  alloc_cache_release(ctx, true);
   if (ctx->aux_scratch) hipFree(ctx->aux_scratch);
   if (ctx->scratch) hipFree(ctx->scratch);
   if (ctx->ctab) hipFree(ctx->ctab);
@@ -377,7 +387,7 @@ int origin_mem_info(origin_ctx *ctx, size_t *free_bytes, size_t *total_bytes) {
   ORIGIN_USE(ctx);
   size_t f = 0, t = 0;
   ORIGIN_HIP(hipMemGetInfo(&f, &t));
-  if (free_bytes) *free_bytes = f;
+  if (free_bytes) *free_bytes = f + alloc_cache_spare(ctx);  // (spare blocks go back when memory runs out)
   if (total_bytes) *total_bytes = t;
   return ORIGIN_OK;
 }
@@ -389,18 +399,113 @@ int origin_stream(origin_ctx *ctx, void **stream) {
   return ORIGIN_OK;
 }
 
+// Blocks of at least 1 MiB that origin_free releases are kept (up to ORIGIN_ALLOC_CACHE_GB, default
+// 96, 0 = off) and handed to the next origin_malloc that asks for their size or up to an eighth
+// less.  The Step seam allocates every output of every step afresh (the reference's steps return
+// new arrays): at 3681 x 600 x 600 that was 27 allocations of up to 5.3 GB at ~40 ms each -- 1.2 s
+// of a 3.2 s pass (tools/e2e_profile.py) -- and a device-wide synchronisation per release.  Reuse
+// is ordered by the context's stream: origin_free makes it wait for the auxiliary and side streams,
+// and every kernel of the library runs on one of the three.
+struct AllocCache {
+  std::mutex mu;
+  std::unordered_map<void *, size_t> live;     // blocks handed out (>= ALLOC_MIN): their sizes
+  std::multimap<size_t, void *> spare;         // released blocks by size
+  size_t spare_bytes = 0, cap_bytes = 0;
+};
+constexpr size_t ALLOC_MIN = (size_t)1 << 20;
+
+static void alloc_cache_make(origin_ctx *ctx) {  // (origin_ctx_create)
+  auto *c = new AllocCache();
+  const char *e = getenv("ORIGIN_ALLOC_CACHE_GB");
+  c->cap_bytes = (size_t)((e ? atof(e) : 96.0) * 1e9);
+  ctx->alloc_cache = c;
+}
+static AllocCache *alloc_cache(origin_ctx *ctx) { return (AllocCache *)ctx->alloc_cache; }
+static size_t alloc_cache_spare(origin_ctx *ctx) {
+  auto *c = alloc_cache(ctx);
+  if (!c) return 0;
+  std::lock_guard<std::mutex> lk(c->mu);
+  return c->spare_bytes;
+}
+
+static void alloc_cache_release(origin_ctx *ctx, bool destroy) {
+  auto *c = (AllocCache *)ctx->alloc_cache;
+  if (!c) return;
+  {
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->spare.empty()) (void)hipStreamSynchronize(ctx->stream);
+    for (auto &kv : c->spare) (void)hipFree(kv.second);
+    c->spare.clear();
+    c->spare_bytes = 0;
+  }
+  if (destroy) {
+    delete c;
+    ctx->alloc_cache = nullptr;
+  }
+}
+
 int origin_malloc(origin_ctx *ctx, size_t bytes, void **d_ptr) {
   ORIGIN_USE(ctx);
   ORIGIN_CHECK_ARG(d_ptr, "d_ptr is null");
   *d_ptr = nullptr;
   if (bytes == 0) bytes = 16;
-  ORIGIN_HIP(hipMalloc(d_ptr, bytes));
+  AllocCache *c = alloc_cache(ctx);
+  if (bytes >= ALLOC_MIN && c->cap_bytes > 0) {
+    std::lock_guard<std::mutex> lk(c->mu);
+    auto it = c->spare.lower_bound(bytes);
+    if (it != c->spare.end() && it->first - bytes <= bytes / 8) {
+      *d_ptr = it->second;
+      c->live[it->second] = it->first;
+      c->spare_bytes -= it->first;
+      c->spare.erase(it);
+      return ORIGIN_OK;
+    }
+  }
+  hipError_t e = hipMalloc(d_ptr, bytes);
+  if (e == hipErrorOutOfMemory && c->spare_bytes > 0) {  // give the spare blocks back and try again
+    (void)hipGetLastError();
+    alloc_cache_release(ctx, false);
+    e = hipMalloc(d_ptr, bytes);
+  }
+  if (e != hipSuccess) {
+    origin_set_error("hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+    return e == hipErrorOutOfMemory ? ORIGIN_E_NOMEM : ORIGIN_E_HIP;
+  }
+  if (bytes >= ALLOC_MIN && c->cap_bytes > 0) {
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->live[*d_ptr] = bytes;
+  }
   return ORIGIN_OK;
 }
 
 int origin_free(origin_ctx *ctx, void *d_ptr) {
   ORIGIN_USE(ctx);
   if (!d_ptr) return ORIGIN_OK;
+  AllocCache *c = alloc_cache(ctx);
+  {
+    std::unique_lock<std::mutex> lk(c->mu);
+    auto it = c->live.find(d_ptr);
+    if (it != c->live.end()) {
+      const size_t sz = it->second;
+      c->live.erase(it);
+      if (c->spare_bytes + sz <= c->cap_bytes) {
+        // whoever gets the block next uses it behind everything enqueued so far, on any stream
+        lk.unlock();
+        if (ctx->aux_stream && ctx->aux_pending) {
+          ORIGIN_HIP(hipStreamWaitEvent(ctx->stream, ctx->aux_join, 0));
+          ctx->aux_pending = false;
+        }
+        if (ctx->side_stream && ctx->side_pending) {
+          int rj = origin_side_join(ctx);
+          if (rj) return rj;
+        }
+        lk.lock();
+        c->spare.emplace(sz, d_ptr);
+        c->spare_bytes += sz;
+        return ORIGIN_OK;
+      }
+    }
+  }
   ORIGIN_HIP(hipStreamSynchronize(ctx->stream));
   ORIGIN_HIP(hipFree(d_ptr));
   return ORIGIN_OK;
@@ -486,6 +591,14 @@ int origin_d2h_f32_as_f64(origin_ctx *ctx, double *h_dst, const float *d_src, si
   ORIGIN_HIP(hipEventSynchronize(ev[0]));
   ORIGIN_HIP(hipEventSynchronize(ev[1]));
   const size_t nch = (n + CH - 1) / CH;
+  // the destination is usually a fresh np.empty: every 4 KiB page of it faults on its first write.
+  // Ask for transparent huge pages on the part that covers whole 2 MiB pages (a hint: ignored where
+  // the system does not offer them)
+  if (n * sizeof(double) >= ((size_t)8 << 20)) {
+    const uintptr_t a = ((uintptr_t)h_dst + (((uintptr_t)2 << 20) - 1)) & ~(((uintptr_t)2 << 20) - 1);
+    const uintptr_t b = ((uintptr_t)(h_dst + n)) & ~(((uintptr_t)2 << 20) - 1);
+    if (b > a) (void)madvise((void *)a, (size_t)(b - a), MADV_HUGEPAGE);
+  }
   auto issue = [&](size_t c) -> int {
     const size_t o = c * CH, m = std::min(CH, n - o);
     ORIGIN_HIP(hipMemcpyAsync(stage[c & 1], d_src + o, m * sizeof(float), hipMemcpyDeviceToHost,
