@@ -445,3 +445,33 @@ def test_glr_rectangles_agree_with_the_whole_run(ctx):
     with pytest.raises(Exception):
         plan.run_rect(d_cube, d_mask, correl, prof_i, cmin, 0, 64, 32, Nx)     # x0 not a multiple of 64
     plan.close()
+
+
+def test_allocation_cache_reuses_released_blocks(ctx):
+    """origin_free keeps blocks of >= 1 MiB for the next origin_malloc of their size (or up to an
+    eighth less); smaller requests get a block of their own; a reused block is ordered behind the
+    work that used it before (same stream): what is written next is what is read back.
+    origin_mem_info counts the kept blocks as free."""
+    n = 1 << 20
+    a = ctx.empty((n,), np.float32)
+    a.fill_bytes(0x3f)
+    p = a.ptr
+    free0, total = ctx.mem_info()
+    a.free()
+    free1, _ = ctx.mem_info()
+    assert free1 >= free0 + 4 * n - (1 << 16)           # the kept block counts as free
+    b = ctx.empty((n,), np.float32)
+    assert b.ptr == p
+    b.upload(np.arange(n, dtype=np.float32))
+    assert np.array_equal(b.to_host(), np.arange(n, dtype=np.float32))
+    b.free()
+    c = ctx.empty((n - 1000,), np.float32)              # within an eighth: the same block
+    assert c.ptr == p
+    c.free()
+    d = ctx.empty((n // 2,), np.float32)                # much smaller: a block of its own
+    assert d.ptr != p
+    small = ctx.empty((1000,), np.float32)              # below 1 MiB: never cached
+    sp = small.ptr
+    small.free()
+    e = ctx.empty((n,), np.float32)
+    assert e.ptr == p and sp != p
