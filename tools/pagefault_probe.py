@@ -2,7 +2,7 @@ import numpy as np, time, os, ctypes as C, sys
 sys.path.insert(0, os.getcwd())
 print("THP enabled:", open("/sys/kernel/mm/transparent_hugepage/enabled").read().strip())
 print("THP defrag:", open("/sys/kernel/mm/transparent_hugepage/defrag").read().strip())
-n = 1325_000_000 // 4
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1325_000_000 // 4
 for rep in range(2):
     a = np.empty(n, np.float64)
     t = time.perf_counter(); a[:] = 1.0; t1 = time.perf_counter() - t
