@@ -793,10 +793,15 @@ def main():
             tt.append(time.perf_counter())
             del f32
             # what the reference's interface promises: float64 host arrays (widened natively)
-            outs = [getattr(o, n_)._data for n_ in names] + [o.maxmap]
+            outs, per_cube = [], []
+            for n_ in names:
+                tq_ = time.perf_counter()
+                outs.append(getattr(o, n_)._data)
+                per_cube.append(round(time.perf_counter() - tq_, 3))
+            outs.append(o.maxmap)
             tt.append(time.perf_counter())
             d = np.diff(tt)
-            cur = dict(h2d=d[0], steps=d[1], d2h_f32=d[2], d2h_f64=d[3],
+            cur = dict(h2d=d[0], steps=d[1], d2h_f32=d[2], d2h_f64=d[3], d2h_f64_per_cube=per_cube,
                        total_f64=d[0] + d[1] + d[3], total_f32=d[0] + d[1] + d[2])
             if best is None or cur["total_f64"] < best["total_f64"]:
                 best = cur
@@ -805,7 +810,8 @@ def main():
         e2e = dict(value=round(vox_e / best["total_f64"], 1), unit="voxels/s",
                    seconds=round(best["total_f64"], 3),
                    value_float32_outputs=round(vox_e / best["total_f32"], 1),
-                   split_seconds={k: round(v, 3) for k, v in best.items()},
+                   split_seconds={k: (round(v, 3) if not isinstance(v, list) else v)
+                                  for k, v in best.items()},
                    split_GBs=dict(h2d=round(9.0 * vox_e / best["h2d"] / 1e9, 1),
                                   d2h_f32=round(12.0 * vox_e / best["d2h_f32"] / 1e9, 1),
                                   d2h_f64_of_device_bytes=round(12.0 * vox_e / best["d2h_f64"] / 1e9, 1)),

@@ -447,11 +447,13 @@ def test_glr_rectangles_agree_with_the_whole_run(ctx):
     plan.close()
 
 
-def test_allocation_cache_reuses_released_blocks(ctx):
+def test_allocation_cache_reuses_released_blocks():
     """origin_free keeps blocks of >= 1 MiB for the next origin_malloc of their size (or up to an
     eighth less); smaller requests get a block of their own; a reused block is ordered behind the
     work that used it before (same stream): what is written next is what is read back.
     origin_mem_info counts the kept blocks as free."""
+    from origin_amd.device import Context
+    ctx = Context(0)      # (a context of its own: its cache holds nothing yet)
     n = 1 << 20
     a = ctx.empty((n,), np.float32)
     a.fill_bytes(0x3f)
@@ -475,3 +477,4 @@ def test_allocation_cache_reuses_released_blocks(ctx):
     small.free()
     e = ctx.empty((n,), np.float32)
     assert e.ptr == p and sp != p
+    ctx.close()
