@@ -412,7 +412,7 @@ class TiledSession:
             sl = (slice(None), slice(t.y0, t.y1), slice(t.x0, t.x1))
             d_raw = ctx.to_device(np.ascontiguousarray(raw[sl]), np.float32)
             d_var = ctx.to_device(np.ascontiguousarray(var[sl]), np.float32)
-            d_mask = ctx.to_device(np.ascontiguousarray(mask[sl]).astype(np.uint8, copy=False))
+            d_mask = ctx.to_device(np.ascontiguousarray(mask[sl]), np.uint8)
             st.update(raw=d_raw, var=d_var, mask=d_mask)
             if comm.device_p2p:
                 pre = pipeline.preprocess(ctx, d_raw, d_var, d_mask, dct_order, dct_approx,
@@ -533,8 +533,7 @@ class TiledSession:
             m = None
             if mask is not None:
                 # the true mask of the whole extended box, straight from the host's copy
-                m = ctx.to_device(np.ascontiguousarray(mask[:, ey0:ey1, ex0:ex1])
-                                  .astype(np.uint8, copy=False))
+                m = ctx.to_device(np.ascontiguousarray(mask[:, ey0:ey1, ex0:ex1]), np.uint8)
                 glr.set_ext_mask(m)
             o = glr.run(None, m, None, None, None, local_max=True, size=size)
             st.update(correl=o["correl"], correl_min=o["correl_min"], profile=o["profile"],

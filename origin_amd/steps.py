@@ -325,7 +325,8 @@ def _inputs_on_device(orig, ctx):
         c['var'] = _wrap(ctx, orig.var)
         m = orig.mask
         m = np.zeros(c['raw'].shape, np.uint8) if m is None or m is np.ma.nomask else m
-        c['mask'] = _wrap(ctx, np.asarray(m, dtype=np.uint8), np.uint8)
+        # (a bool mask goes up as it is: one byte of 0 / 1 per voxel, no host-side copy)
+        c['mask'] = _wrap(ctx, np.asarray(m), np.uint8)
     return c['raw'], c['var'], c['mask']
 
 
