@@ -203,7 +203,18 @@ class TiledCube:
             a, (by, bx), (y0, y1, x0, x1), owned = self.parts[rank]
             ny, nx = y1 - y0, x1 - x0
             if three:
-                blk = a.window(by, by + ny, bx, bx + nx)
+                # the part's box as one contiguous block: crop on the device (one strided copy
+                # kernel), then one large copy through pinned staging -- a strided device-to-host
+                # copy is one hipMemcpy2D per channel
+                if (by, bx) == (0, 0) and a.shape[1:] == (ny, nx):
+                    blk = a.to_host()
+                else:
+                    ctx = self.group.ctxs[rank]
+                    tmp = ctx.empty((a.shape[0], ny, nx), a.dtype)
+                    multigpu._copy_box(ctx, tmp, tmp.shape, (0, 0, 0), a, a.shape, (0, by, bx),
+                                       (a.shape[0], ny, nx))
+                    blk = tmp.to_host()
+                    tmp.free()
                 dst = out[:, y0:y1, x0:x1]
                 if owned is None:
                     dst[...] = convert(blk)
