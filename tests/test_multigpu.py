@@ -189,6 +189,38 @@ def test_owner_tiling_hands_whole_areas_to_ranks():
     assert [t.y1 - t.y0 for t in rb.tiles] == [14, 13, 13] and rb.owned_tile(1).all()
 
 
+def test_owner_tiling_local_regions_read_only_own_spaxels():
+    """``OwnerTiling.local_regions``: a region is flagged only if everything its GLR reads (the
+    region grown by the PSF's reach, clipped to the field) belongs to the rank -- those regions run
+    ahead of the halo exchange (TiledGLR); and ``balance()`` reports what the partition costs."""
+    from origin_amd.multigpu import OwnerTiling
+    rng = np.random.default_rng(4)
+    Ny, Nx, R, reach = 300, 420, 64, 12
+    # four irregular areas: a wavy vertical and a wavy horizontal cut
+    yy, xx = np.mgrid[:Ny, :Nx]
+    amap = 1 + (xx > 200 + 15 * np.sin(yy / 20.0)) + 2 * (yy > 150 + 10 * np.cos(xx / 30.0))
+    for world in (2, 4):
+        tl = OwnerTiling.from_areamap(amap, world, halo=reach + 1)
+        some = 0
+        for r in range(world):
+            (ey0, ey1, ex0, ex1), _ = tl.extended(r)
+            ok = tl.local_regions(r, reach, R)
+            own = tl.owned_ext(r)
+            assert ok.shape == ((ey1 - ey0 + R - 1) // R, (ex1 - ex0 + R - 1) // R)
+            for ry, rx in zip(*np.nonzero(ok)):
+                a, b = R * ry - reach, min(ey1 - ey0, R * ry + R) + reach
+                c, d = R * rx - reach, min(ex1 - ex0, R * rx + R) + reach
+                assert own[max(a, 0):b, max(c, 0):d].all()
+                # nothing it reads lies beyond the box where the field goes on
+                assert (a >= 0 or ey0 == 0) and (c >= 0 or ex0 == 0)
+                assert (b <= ey1 - ey0 or ey1 == Ny) and (d <= ex1 - ex0 or ex1 == Nx)
+                some += 1
+        assert some > 0
+        bal = tl.balance()
+        assert bal["spaxels"] >= 1.0 and bal["box_over_owned"] >= 1.0 and len(bal["owned"]) == world
+    del rng
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_tiled_oracle_on_irregular_areas_equals_untiled_oracle(tmp_path, world):
     """The chain on an IRREGULAR area map (reference steps.py:492-569; golden G10's "many" map):
