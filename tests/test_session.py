@@ -176,6 +176,40 @@ def test_two_contexts_on_one_card_behind_the_step_seam(kind):
 
 
 @pytest.mark.gpu
+def test_tiled_steps_take_cubes_from_elsewhere():
+    """A session reloaded from its files (steps.py:342-352) hands step 4 a cube_std and step 5 a
+    cube_faint that no rank holds: the tiled steps distribute the host cubes over the ranks' boxes
+    and give what the resident chain gives."""
+    from _mp_tiled_worker import field
+    from origin_amd.steps import LazyCube, SimpleOrig
+    os.environ.pop("TILED_FIELD", None)
+    f, raw, var, mask = field()
+    psf = f.PSF.astype(float)
+    a = _chain(SimpleOrig(raw, var, mask, psf, f.profiles, devices=[0, 0]), f.areamap)
+    b = SimpleOrig(raw, var, mask, psf, f.profiles, devices=[0, 0])
+    b.step01_preprocessing()
+    b.step02_areas.set_areamap(f.areamap)
+    b.step03_compute_PCA_threshold()
+    # cube_std as a host array only (what a DataObj holds after a reload), nothing cached
+    host_std = b.cube_std._data.astype(np.float32)
+    b._hip_cache.pop("cube_std")
+    b.steps["preprocessing"].cube_std = LazyCube(host=host_std.astype(np.float64))
+    for st in b._hip_session.rk:
+        st.pop("cube_std", None)
+    b.step04_compute_greedy_PCA()
+    assert np.array_equal(np.asarray(b.mapO2), np.asarray(a.mapO2))
+    assert np.max(np.abs(b.cube_faint._data - a.cube_faint._data)) <= 1e-6
+    host_faint = b.cube_faint._data.copy()
+    b._hip_cache.pop("cube_faint")
+    b.steps["compute_greedy_PCA"].cube_faint = LazyCube(host=host_faint)
+    b.step05_compute_TGLR()
+    assert np.max(np.abs(b.cube_correl._data - a.cube_correl._data)) <= 1e-4
+    assert np.max(np.abs(np.asarray(b.maxmap) - np.asarray(a.maxmap))) <= 1e-4
+    a._hip_session.close()
+    b._hip_session.close()
+
+
+@pytest.mark.gpu
 def test_a_failing_rank_fails_the_step_and_leaves_the_group_usable():
     from _mp_tiled_worker import field
     from origin_amd.session import DeviceGroup
