@@ -393,22 +393,26 @@ def main():
                 ctx.set_pca_tail_hook(None)
         if pca_err is None and hook is not None:
             pca_err = ctx.pop_tail_hook_error()
-        if comm is not None:
-            # every rank learns whether all PCAs and hooks went through BEFORE the collective halo
-            # exchange: a rank that failed would leave the others waiting in it
+        # every rank learns whether all PCAs and hooks went through BEFORE the collective halo
+        # exchange (a rank that failed would leave the others waiting in it) -- but behind the
+        # regions of its own tile that need no halo: a fast rank works on those while it waits for
+        # the slow ones (TiledGLR.run(before_exchange=...))
+        def agree():
             ok = comm.group.allreduce(np.array([0.0 if pca_err is not None else 1.0]), "min")[0]
             if ok != 1.0:
                 glr._early_done = None   # (regions the hook started belong to a step that is over)
                 raise pca_err if pca_err is not None else RuntimeError(
                     "the greedy PCA or its tail hook failed on another rank")
-        elif pca_err is not None:
+        if pca_err is not None:
+            if comm is not None:
+                agree()
             raise pca_err
         t3 = time.perf_counter()
         if world > 1:
             # (no crop: correl / correl_min / profile and the local maxima stay in the tile's
             # halo-extended arrays, out["box"] is the tile inside them)
             lm_form = None if not do_lm else ("sparse" if tiled_sparse else True)
-            out = glr.run(None, mask, None, None, None, local_max=lm_form)
+            out = glr.run(None, mask, None, None, None, local_max=lm_form, before_exchange=agree)
             info["glr_rects"] = {"ahead_of_exchange": len(glr.last_rects[0]),
                                  "behind_exchange": len(glr.last_rects[1]),
                                  "regions_in_pca_tail": glr.last_rects[2]}

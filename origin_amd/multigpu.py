@@ -814,7 +814,8 @@ class TiledGLR:
             self._early_done = ok
         return hook
 
-    def run(self, cube_faint, mask, correl, profile, correl_min, local_max=None, size=3):
+    def run(self, cube_faint, mask, correl, profile, correl_min, local_max=None, size=3,
+            before_exchange=None):
         """Returns the caller's correl / profile / correl_min and the tile's maxmap / minmap.  The
         two maps are DeviceArrays OWNED BY THIS OBJECT and rewritten by the next call: copy them
         (``.to_host()`` / ``.copy()``) to keep them across steps.
@@ -825,6 +826,11 @@ class TiledGLR:
         with ``DeviceArray.window`` or hand kernels the strides); cropping three cubes and
         the two local-maxima cubes on the device is 34 B/voxel of extra traffic per step, more
         than a third of what the whole path moves.
+
+        ``before_exchange``: called (no arguments) right before the collective halo exchange,
+        behind the regions that run ahead of it -- where a caller lets the ranks agree that all of
+        them got this far (a rank whose PCA failed must not leave the others waiting in RCCL)
+        without holding the interior regions of the fast ranks back.
 
         ``local_max``: None, ``True`` (dense, in the extended arrays, with correl=None),
         ``"sparse"`` (the same as lists of the non-zero voxels of the extended cubes:
@@ -866,6 +872,8 @@ class TiledGLR:
                 self.plan.run_rect(self.ext, emask, oc, op, om, y0, y1, x0, x1,
                                    first=(i == 0 and done is None), side=True)
             early = [r for r in early if r is not None]
+            if before_exchange is not None:
+                before_exchange()
             exchange_halo(ctx, self.comm, self.tiling, self.rank, None, self.ext, self._strips)
             for y0, y1, x0, x1 in late:
                 self.plan.run_rect(self.ext, emask, oc, op, om, y0, y1, x0, x1)
@@ -874,6 +882,8 @@ class TiledGLR:
         else:
             # cube_faint None: the greedy PCA wrote this step's tile straight into self.ext's
             # interior
+            if before_exchange is not None:
+                before_exchange()
             exchange_halo(ctx, self.comm, self.tiling, self.rank, cube_faint, self.ext,
                           self._strips)
             o = self.plan.run(self.ext, mask=emask, correl=self.out["correl"],
