@@ -176,6 +176,22 @@ def test_two_contexts_on_one_card_behind_the_step_seam(kind):
 
 
 @pytest.mark.gpu
+def test_three_contexts_on_one_card_irregular_areas():
+    """Three ranks (an odd split: 1 + 2 in the bisection of the areas) on the irregular area map:
+    same checks as with two."""
+    from _mp_tiled_worker import areas_field
+    from origin_amd.steps import SimpleOrig
+    f, raw, var, mask = areas_field()
+    psf = f.PSF.astype(float)
+    one = _chain(SimpleOrig(raw, var, mask, psf, f.profiles), f.areamap)
+    three = _chain(SimpleOrig(raw, var, mask, psf, f.profiles, devices=[0, 0, 0]), f.areamap)
+    sess = three._hip_session
+    assert sess.world == 3 and sorted(sess.p2.balance()["areas_per_rank"]) == [1, 2, 2]
+    _compare(one, three, mask)
+    sess.close()
+
+
+@pytest.mark.gpu
 def test_tiled_steps_take_cubes_from_elsewhere():
     """A session reloaded from its files (steps.py:342-352) hands step 4 a cube_std and step 5 a
     cube_faint that no rank holds: the tiled steps distribute the host cubes over the ranks' boxes
