@@ -182,6 +182,18 @@ def main():
     finally:
         pre_cls.run, thr_cls.run = saved
 
+    # register(devices=[...]): the sessions made afterwards spread their hot steps over those
+    # devices (origin_amd/session.py); the swap itself is the same, and register() resets it
+    assert hip_steps.register(devices=[0, 1]) == list(SIX) and hip_steps._DEFAULT_DEVICES == [0, 1]
+
+    class _O:        # (what _session_of reads of a reference session: its instance dict)
+        pass
+    o_ = _O()
+    assert hip_steps.register() == list(SIX) and hip_steps._DEFAULT_DEVICES is None
+    assert hip_steps._session_of(o_) is None
+    say("register(devices=[0, 1]) keeps the swap and sets the devices of later sessions; "
+        "register() resets them")
+
     hip_steps.unregister()
     assert [getattr(ref, n) for n in SIX] == [before[n] for n in SIX]
     assert [c for c in ref.STEPS if c.__name__ in SIX] == [before[n] for n in SIX]
