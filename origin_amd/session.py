@@ -35,7 +35,7 @@ import threading
 
 import numpy as np
 
-from . import _capi, kernels, multigpu, pipeline
+from . import _capi, kernels, multigpu, pipeline, sparse
 from .device import Context, DeviceArray
 from .pca import GreedyPCA
 
@@ -206,7 +206,9 @@ class TiledCube:
                 # the part's box as one contiguous block: crop on the device (one strided copy
                 # kernel), then one large copy through pinned staging -- a strided device-to-host
                 # copy is one hipMemcpy2D per channel
-                if (by, bx) == (0, 0) and a.shape[1:] == (ny, nx):
+                if hasattr(a, "entries"):      # sparse.SparseCube: zeros + its entries, on the host
+                    blk = a.to_host()[:, by:by + ny, bx:bx + nx]
+                elif (by, bx) == (0, 0) and a.shape[1:] == (ny, nx):
                     blk = a.to_host()
                 else:
                     ctx = self.group.ctxs[rank]
@@ -262,7 +264,8 @@ class TiledCube:
         def one(rank):
             a, (by, bx), (y0, y1, x0, x1), owned = self.parts[rank]
             ctx = self.group.ctxs[rank]
-            m = kernels.zmax_map(ctx, a, None)[by:by + y1 - y0, bx:bx + x1 - x0]
+            full = a.zmax_map(None) if hasattr(a, "entries") else kernels.zmax_map(ctx, a, None)
+            m = full[by:by + y1 - y0, bx:bx + x1 - x0]
             if keep is not None:   # max_z (cube * keep) = keep ? max_z cube : 0
                 m = np.where(np.asarray(keep).reshape(self.shape[1:])[y0:y1, x0:x1] != 0, m, 0.0)
             if owned is None:
@@ -277,7 +280,10 @@ class TiledCube:
         def one(rank):
             ctx = self.group.ctxs[rank]
             k = ctx.to_device(self._keep(rank, keep).reshape(-1))
-            return kernels.count_above(ctx, self.parts[rank][0], thresholds, k)
+            a = self.parts[rank][0]
+            if hasattr(a, "entries"):
+                return a.count_above(thresholds, k)
+            return kernels.count_above(ctx, a, thresholds, k)
         return np.sum(self.group.run(one), axis=0)
 
     def where_above(self, threshold, aux=None):
@@ -286,8 +292,9 @@ class TiledCube:
         def one(rank):
             a, (by, bx), (y0, y1, x0, x1), owned = self.parts[rank]
             ctx = self.group.ctxs[rank]
-            w = kernels.where_above(ctx, a, threshold,
-                                    aux=None if aux is None else aux.parts[rank][0])
+            ax = None if aux is None else aux.parts[rank][0]
+            w = (a.where_above(threshold, aux=ax) if hasattr(a, "entries")
+                 else kernels.where_above(ctx, a, threshold, aux=ax))
             yy, xx = w["y"] - by, w["x"] - bx
             ok = (yy >= 0) & (yy < y1 - y0) & (xx >= 0) & (xx < x1 - x0)
             if owned is not None:
@@ -436,7 +443,8 @@ class TiledSession:
             strips = {}
             e_std = multigpu.exchange_halo(ctx, comm, p1, r, pre["cube_std"], None, strips)
             e_msk = multigpu.exchange_halo(ctx, comm, p1, r, d_mask, None, strips)
-            lmax, lmin = kernels.local_max(ctx, e_std, e_std, e_msk, local_max_size)
+            # (lists of the non-zero voxels where the pass has a sparse form, as on one device)
+            lmax, lmin = sparse.local_max(ctx, e_std, e_std, e_msk, local_max_size)
             st.update(std_lmax=lmax, std_lmin=lmin)
             cont_o2 = kernels.o2test(ctx, pre["cont_dct"]).to_host()
             return dict(ima_std=pre["ima_std"].to_host(), ima_dct=pre["ima_dct"].to_host(),
@@ -546,7 +554,8 @@ class TiledSession:
                 # the true mask of the whole extended box, straight from the host's copy
                 m = ctx.to_device(np.ascontiguousarray(mask[:, ey0:ey1, ex0:ex1]), np.uint8)
                 glr.set_ext_mask(m)
-            o = glr.run(None, m, None, None, None, local_max=True, size=size)
+            lm_form = "sparse" if (int(size) == 3 and sparse.plan(ctx, glr.eshape)[0] > 0) else True
+            o = glr.run(None, m, None, None, None, local_max=lm_form, size=size)
             st.update(correl=o["correl"], correl_min=o["correl_min"], profile=o["profile"],
                       lmax=o["local_max"], lmin=o["local_min"])
             ctx.sync()
