@@ -767,7 +767,11 @@ __global__ __launch_bounds__(64 * MF_WAVES, 1) void spectral_mfma2_kernel(
 #ifdef SM_TIMING
   const bool sm_rec = blockIdx.x >= 3 && blockIdx.x < 7 && blockIdx.y == 1 && lane == 0;
   long long sm_ncol = 0;
-  if (sm_rec) sm_wave[((blockIdx.x - 3) * MF_WAVES + wv) * 4 + 0] = clock64();
+  long long sm_wall0 = 0;
+  if (sm_rec) {
+    sm_wave[((blockIdx.x - 3) * MF_WAVES + wv) * 4 + 0] = clock64();
+    sm_wall0 = wall_clock64();   // (the constant 100 MHz counter: the ratio gives the shader clock)
+  }
 #endif
   for (int col = wv; col < cols_per_block;) {
   long s_end = s_end_launch;
@@ -851,6 +855,7 @@ __global__ __launch_bounds__(64 * MF_WAVES, 1) void spectral_mfma2_kernel(
   if (sm_rec) {
     sm_wave[((blockIdx.x - 3) * MF_WAVES + wv) * 4 + 1] = clock64();
     sm_wave[((blockIdx.x - 3) * MF_WAVES + wv) * 4 + 2] = sm_ncol;
+    sm_wave[((blockIdx.x - 3) * MF_WAVES + wv) * 4 + 3] = wall_clock64() - sm_wall0;
   }
 #endif
 }

@@ -52,3 +52,11 @@ for b in range(4):
     print("   " + "  ".join(f"w{w}:{int(wt[b, w, 0] - t0)}-{int(wt[b, w, 1] - t0)}/{int(wt[b, w, 2])}" for w in range(NW)))
     print(f"   block lifetime {int(wt[b, :, 1].max() - t0)}, sum of wave lifetimes / (12 x lifetime) = "
           f"{float((wt[b, :, 1] - wt[b, :, 0]).sum()) / (NW * float(wt[b, :, 1].max() - t0)):.2f}")
+    dt_ticks = (wt[b, :, 1] - wt[b, :, 0]).astype(float)
+    dt_wall = wt[b, :, 3].astype(float)          # 100 MHz ticks
+    ok = dt_wall > 0
+    if ok.any():
+        mhz = dt_ticks[ok] / dt_wall[ok] * 100.0
+        print(f"   clock64 ticks per microsecond over the waves' lifetimes: {mhz.min():.0f} .. {mhz.max():.0f} "
+              f"(clock64 against the 100 MHz wall clock: the shader clock in MHz if clock64 counts shader cycles); "
+              f"block lifetime {float(wt[b, :, 3].max()) / 100.0:.1f} us")
