@@ -426,6 +426,17 @@ __device__ __forceinline__ double eval_cont(const double (&c)[ORDER + 1], const 
 // cos(a theta) is even about the middle of the cube for even a and odd for odd a, so with
 // E = sum_{a even} c_a cos(a theta_z), O = sum_{a odd} c_a cos(a theta_z) the two values are
 // E + O and E - O -- one table row and ORDER + 1 FMAs for two voxels.
+// 1 / sqrt(var) for the two quotients of the standardisation (steps.py:439-440): v_rsq_f32 (1 ulp;
+// inf -> 0, 0 -> inf, negative -> NaN as the reference's float64 expression gives).  The IEEE
+// sqrtf + division it replaces cost ~20 VALU instructions per voxel of a kernel that issues ~65.
+__device__ __forceinline__ float dct_inv_std(float v) { return __builtin_amdgcn_rsqf(v); }
+
+// element of a row whose base is wave-uniform at a 32-bit byte offset of the lane
+template <typename T>
+__device__ __forceinline__ T &dct_at(T *row, unsigned byte_off) {
+  return *reinterpret_cast<T *>(reinterpret_cast<char *>(const_cast<std::remove_const_t<T> *>(row)) + byte_off);
+}
+
 template <int ORDER>
 __device__ __forceinline__ void eval_cont_pair(const double (&c)[ORDER + 1], const double *ct,
                                                double &front, double &back) {
@@ -683,18 +694,20 @@ __global__ __launch_bounds__(256) void dct_standardize_kernel(
   const int npair = Nz / 2;
   const int p0 = blockIdx.y * zchunk, p1 = min(npair, p0 + zchunk);
   double a_std = 0.0, a_dct = 0.0, a_o2 = 0.0;
-  auto voxel = [&](long idx, double cont, double mean) {
-    const float r = raw[idx];
-    const float v = var[idx];
-    const bool mk = mask[idx] != 0;
-    // std = sqrt(var) (steps.py:439); both quotients share one reciprocal (float32 results
-    // within 2 ulp of the reference's float64 quotient cast to float32)
-    const float rs = 1.0f / sqrtf(v);
+  // addresses: the channel's row base is wave-uniform (scalar registers), the lane adds a 32-bit
+  // offset -- no 64-bit vector arithmetic per access
+  const unsigned so4 = (unsigned)s * 4u, so1 = (unsigned)s;
+  auto voxel = [&](long row, double cont, double mean) {
+    const float r = dct_at(raw + row, so4);
+    const float v = dct_at(var + row, so4);
+    const bool mk = dct_at(mask + row, so1) != 0;
+    // std = sqrt(var) (steps.py:439); both quotients share one reciprocal
+    const float rs = dct_inv_std(v);
     const float t = (float)(((double)r - cont) - mean);  // nanmean over unmasked spaxels (:442)
     const float o = mk ? 0.0f : t * rs;     // data[mask] = 0                (steps.py:446)
     const float cd = (float)cont * rs;      // cont_dct /= std ; astype(f32) (:440, :463)
-    cube_std[idx] = o;
-    if (cont_dct) cont_dct[idx] = cd;
+    dct_at(cube_std + row, so4) = o;
+    if (cont_dct) dct_at(cont_dct + row, so4) = cd;
     a_std += (double)o;
     a_dct += (double)cd;
     a_o2 = fma((double)o, (double)o, a_o2);
@@ -704,11 +717,11 @@ __global__ __launch_bounds__(256) void dct_standardize_kernel(
     const int zb = Nz - 1 - p;
     double cf, cb;
     eval_cont_pair<ORDER>(c, ctab + (long)p * NK, cf, cb);
-    voxel((long)p * S + s, cf, zmean[p]);
-    voxel((long)zb * S + s, cb, zmean[zb]);
+    voxel((long)p * S, cf, zmean[p]);
+    voxel((long)zb * S, cb, zmean[zb]);
   }
   if ((Nz & 1) && blockIdx.y == gridDim.y - 1)
-    voxel((long)npair * S + s, eval_cont<ORDER>(c, ctab + (long)npair * NK), zmean[npair]);
+    voxel((long)npair * S, eval_cont<ORDER>(c, ctab + (long)npair * NK), zmean[npair]);
   if (part) {
     double *p = part + (long)blockIdx.y * 3 * S + s;
     p[0] = a_std;
@@ -738,21 +751,22 @@ __global__ __launch_bounds__(256) void dct_cont_std_kernel(const float *__restri
   const int npair = Nz / 2;  // (mirror pairs, as dct_standardize_kernel: identical values)
   const int p0 = blockIdx.y * zchunk, p1 = min(npair, p0 + zchunk);
   double a_dct = 0.0;
-  auto voxel = [&](long idx, double cont) {
-    const float rs = 1.0f / sqrtf(var[idx]);
+  const unsigned so4 = (unsigned)s * 4u;
+  auto voxel = [&](long row, double cont) {
+    const float rs = dct_inv_std(dct_at(var + row, so4));
     const float cd = (float)cont * rs;
-    cont_dct[idx] = cd;
+    dct_at(cont_dct + row, so4) = cd;
     a_dct += (double)cd;
   };
 #pragma unroll 2
   for (int p = p0; p < p1; ++p) {
     double cf, cb;
     eval_cont_pair<ORDER>(c, ctab + (long)p * NK, cf, cb);
-    voxel((long)p * S + s, cf);
-    voxel((long)(Nz - 1 - p) * S + s, cb);
+    voxel((long)p * S, cf);
+    voxel((long)(Nz - 1 - p) * S, cb);
   }
   if ((Nz & 1) && blockIdx.y == gridDim.y - 1)
-    voxel((long)npair * S + s, eval_cont<ORDER>(c, ctab + (long)npair * NK));
+    voxel((long)npair * S, eval_cont<ORDER>(c, ctab + (long)npair * NK));
   if (part) part[(long)blockIdx.y * S + s] = a_dct;
 }
 

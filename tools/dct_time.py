@@ -21,3 +21,17 @@ def t(f, n=5):
 print("dct_fit (no fold)      %.3f ms" % t(lambda: kernels.dct_fit(ctx, raw, var, mask, 10, False, coef=coef)))
 print("dct_fit_sums (fold)    %.3f ms" % t(lambda: kernels.dct_fit_sums(ctx, raw, var, mask, 10, False, coef=coef, zsum=zs, zcnt=zc)))
 print("dct_resid_sums         %.3f ms" % t(lambda: kernels.dct_resid_sums(ctx, raw, mask, coef, zsum=zs, zcnt=zc)))
+# the whole preprocessing phase with the per-kernel times of the context's profiler
+from origin_amd import pipeline
+for want_cont in (False, True):
+    pipeline.preprocess(ctx, raw, var, mask, want_cont=want_cont); ctx.sync()
+    ctx.prof_reset(); ctx.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        pre = pipeline.preprocess(ctx, raw, var, mask, want_cont=want_cont)
+    ctx.sync()
+    dt = 1e3 * (time.perf_counter() - t0) / 5
+    ctx.prof_enable(False)
+    print("preprocess(want_cont=%s) %.3f ms" % (want_cont, dt),
+          {k: round(v[0] / 5, 3) for k, v in ctx.prof_report().items()})
+    del pre
