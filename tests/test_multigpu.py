@@ -146,6 +146,33 @@ def test_tiled_oracle_equals_untiled_oracle(tmp_path, world, group):
         assert np.max(np.abs(got - want)[(got != 0) & (want != 0)]) <= 1e-9, key
 
 
+def test_eight_rank_band_tiling_oracle_equals_untiled_oracle(tmp_path, monkeypatch):
+    """World size 8 (the node the headline config names): a 3 x 6 grid of areas over bands with
+    different numbers of ranks, so tiles meet neighbours of another band at unaligned cuts.  The
+    data path of bench.py --gpus 8 -- per-channel all-reduce, one-phase halo exchange with corner
+    and partial-edge boxes, extended-tile GLR, local maxima on the tiles -- with the CPU oracle per
+    tile against the untiled oracle."""
+    from oracle import cpu_ref
+    monkeypatch.setenv("TILED_FIELD", "big")
+    from _mp_tiled_worker import field, make_tiling
+    f, raw, var, mask = field()
+    tl = make_tiling(f, 8, raw.shape[1], raw.shape[2])
+    assert len(tl.balance()["ranks_per_band"]) > 1      # bands, not a regular grid
+    tiles = run_ranks("cpu", 8, str(tmp_path / "cpu8"), field="big")
+    ref = cpu_ref.run_chain(raw.astype(float), var.astype(float), mask, f.PSF.astype(float), None,
+                            f.profiles, f.areamap, f.nbAreas)
+    shape = raw.shape
+    for key, rk in (("cube_std", "cube_std"), ("cube_faint", "cube_faint"),
+                    ("correl", "cube_correl"), ("correl_min", "cube_correl_min")):
+        got = stitch(tiles, key, shape)
+        assert np.max(np.abs(got - ref[rk])) <= 1e-9 * max(1.0, np.max(np.abs(ref[rk]))), key
+    assert np.array_equal(stitch(tiles, "mapO2", shape[1:]), ref["mapO2"])
+    lmax, lmin = cpu_ref.compute_local_max(ref["cube_correl"], ref["cube_correl_min"], mask, 3)
+    for key, want in (("local_max", lmax), ("local_min", lmin)):
+        got = stitch(tiles, key, shape)
+        assert np.array_equal(got != 0, want != 0), key
+
+
 def test_owner_tiling_hands_whole_areas_to_ranks():
     """OwnerTiling on the reference-made irregular area map of golden G10: areas are never
     split, label 0 goes with its nearest area, the column plan of every rank is the mirror of its
@@ -366,6 +393,30 @@ def test_tiled_hip_interior_regions_ahead_of_the_halo_exchange(tmp_path, world, 
     # the seventh digit of the O2 values -- the Freedman-Diaconis bin count steps -- and the
     # float64 oracle takes 6 iterations there where the device's fp32 cube takes 8.  The oracle
     # comparisons of the tiled path are the tests above, on the field where it is not.)
+
+
+@pytest.mark.gpu
+def test_tiled_hip_five_ranks_in_bands(tmp_path, monkeypatch):
+    """Five ranks on the 3 x 6 grid of areas: a band of two ranks above a band of three, tiles that
+    meet their neighbours at unaligned cuts (150 against 100 / 200), corner and partial-edge boxes
+    in the halo plan -- the shape of the 8-GPU tilings -- through the HIP path on one shared GPU,
+    against the single-context run."""
+    monkeypatch.setenv("TILED_FIELD", "big")
+    from _mp_tiled_worker import field, make_tiling
+    f, raw, var, mask = field()
+    tl = make_tiling(f, 5, raw.shape[1], raw.shape[2])
+    assert tl.balance()["ranks_per_band"] == [2, 3]
+    tiles = run_ranks("gpu", 5, str(tmp_path / "gpu5"))
+    single = run_ranks("gpu", 1, str(tmp_path / "one"))
+    shape = raw.shape
+    for key, tol in (("cube_std", 1e-6), ("cube_faint", 1e-5), ("correl", 1e-4),
+                     ("correl_min", 1e-4)):
+        got, one = stitch(tiles, key, shape), stitch(single, key, shape)
+        assert np.max(np.abs(got - one)) <= tol, (key, float(np.max(np.abs(got - one))))
+    assert np.array_equal(stitch(tiles, "mapO2", shape[1:]), stitch(single, "mapO2", shape[1:]))
+    for key in ("local_max", "local_min"):
+        got, one = stitch(tiles, key, shape), stitch(single, key, shape)
+        assert np.mean((got != 0) != (one != 0)) <= 1e-4, key
 
 
 @pytest.mark.gpu
