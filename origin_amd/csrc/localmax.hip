@@ -308,13 +308,30 @@ __device__ __forceinline__ float lm_ext3(float a, float b, float c) {
   return d;
 }
 
-template <int R>
+template <int R, int NC>
 struct LmPlane {
-  float p[R][4];  // 3 x 3 extrema of the lane's R x 4 outputs in this plane
-  float c[R][4];  // the plane's own samples there
+  float p[R][NC];  // 3 x 3 extrema of the lane's R x NC outputs in this plane
+  float c[R][NC];  // the plane's own samples there
 };
 
-template <int SIGN, int R, bool HAS_MASK, bool PREFETCH, bool STRIPS>
+// NC consecutive samples of a row as one load (16 / 8 / 4 bytes per lane)
+template <int NC>
+__device__ __forceinline__ void lm_load_row(const char *p, float (&v)[NC]) {
+  if constexpr (NC == 4) {
+    const float4 q = *reinterpret_cast<const float4 *>(p);
+    v[0] = q.x, v[1] = q.y, v[2] = q.z, v[3] = q.w;
+  } else if constexpr (NC == 2) {
+    const float2 q = *reinterpret_cast<const float2 *>(p);
+    v[0] = q.x, v[1] = q.y;
+  } else {
+    v[0] = *reinterpret_cast<const float *>(p);
+  }
+}
+
+// NC: samples per lane and row (a wave's row segment is 64 NC samples, 62 NC of them outputs); R rows
+// per lane: R + 2 rows are read for R rows of outputs, so the same register budget (R NC outputs per
+// lane) spent on fewer columns and more rows reads less twice.
+template <int SIGN, int R, int NC, bool HAS_MASK, bool PREFETCH, bool STRIPS>
 __device__ __forceinline__ void lm_sparse_march(const float *__restrict__ a,
                                                 const uint8_t *__restrict__ mask, int Nz, int Ny,
                                                 int Nx, int zper, long long *__restrict__ idx_out,
@@ -322,7 +339,7 @@ __device__ __forceinline__ void lm_sparse_march(const float *__restrict__ a,
                                                 int *__restrict__ counts, int seg_cap, long bxi,
                                                 int bzi, long nbx) {
   // (bxi, bzi: this block's position among the nbx spaxel blocks and the z chunks)
-  const int nx4 = Nx >> 2, ngrp = (Ny + R - 1) / R;
+  const int nx4 = Nx / NC, ngrp = (Ny + R - 1) / R;   // (nx4: lane positions per row)
   const int lane = threadIdx.x & 63;
   bool live;
   int grp, x4;
@@ -356,7 +373,7 @@ __device__ __forceinline__ void lm_sparse_march(const float *__restrict__ a,
   unsigned roff[R + 2];  // byte offsets of rows yb - 1 .. yb + R (clamped) at this lane's float4
 #pragma unroll
   for (int r = 0; r < R + 2; ++r)
-    roff[r] = 4u * (unsigned)((long)min(max(yb - 1 + r, 0), Ny - 1) * Nx + 4 * x4);
+    roff[r] = 4u * (unsigned)((long)min(max(yb - 1 + r, 0), Ny - 1) * Nx + NC * x4);
   // rows of the lane's group that exist, and the lane produces at all
   unsigned long long okrow[R];   // lanes whose output row r exists (scalar register pairs)
 #pragma unroll
@@ -364,7 +381,7 @@ __device__ __forceinline__ void lm_sparse_march(const float *__restrict__ a,
   const unsigned lane_lo = lane < 32 ? 1u << lane : 0u, lane_hi = lane < 32 ? 0u : 1u << (lane - 32);
 
   // the R + 2 rows of plane z around the lane's outputs
-  auto fetch = [&](int z, float4 (&v)[R + 2]) {
+  auto fetch = [&](int z, float (&v)[R + 2][NC]) {
     const char *pz = reinterpret_cast<const char *>(a + (long)min(max(z, 0), Nz - 1) * S);
 #pragma unroll
     for (int r = 0; r < R + 2; ++r) {
@@ -372,37 +389,40 @@ __device__ __forceinline__ void lm_sparse_march(const float *__restrict__ a,
       // 32-bit lane offset" is one addressing mode; hoisted, each row costs a 64-bit VGPR pair)
       unsigned o = roff[r];
       asm volatile("" : "+v"(o));
-      v[r] = *reinterpret_cast<const float4 *>(pz + o);
+      lm_load_row<NC>(pz + o, v[r]);
     }
   };
-  float4 vnext[R + 2];   // PREFETCH: the rows of the plane after next, requested a channel ahead
-  auto plane = [&](int z, LmPlane<R> &o) {
-    float4 v[R + 2];
+  float vnext[R + 2][NC];   // PREFETCH: the rows of the plane after next, requested a channel ahead
+  auto plane = [&](int z, LmPlane<R, NC> &o) {
+    float v[R + 2][NC];
     if constexpr (PREFETCH) {
 #pragma unroll
-      for (int r = 0; r < R + 2; ++r) v[r] = vnext[r];
+      for (int r = 0; r < R + 2; ++r)
+#pragma unroll
+        for (int e = 0; e < NC; ++e) v[r][e] = vnext[r][e];
       fetch(z + 1, vnext);
     } else {
       fetch(z, v);
     }
-    float xm[R + 2][4];
+    float xm[R + 2][NC];
 #pragma unroll
     for (int r = 0; r < R + 2; ++r) {
       // (mov_dpp without an `old` operand: lanes 0 / 63 get zeros, and they produce no output)
-      float l = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v[r].w), 0x138, 0xF, 0xF, true));
-      float rr = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v[r].x), 0x130, 0xF, 0xF, true));
-      l = first ? v[r].x : l;   // at a row's ends the window is clamped to the row
-      rr = last ? v[r].w : rr;
-      xm[r][0] = lm_ext3<SIGN>(l, v[r].x, v[r].y);
-      xm[r][1] = lm_ext3<SIGN>(v[r].x, v[r].y, v[r].z);
-      xm[r][2] = lm_ext3<SIGN>(v[r].y, v[r].z, v[r].w);
-      xm[r][3] = lm_ext3<SIGN>(v[r].z, v[r].w, rr);
+      float l = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v[r][NC - 1]), 0x138, 0xF, 0xF, true));
+      float rr = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v[r][0]), 0x130, 0xF, 0xF, true));
+      l = first ? v[r][0] : l;   // at a row's ends the window is clamped to the row
+      rr = last ? v[r][NC - 1] : rr;
+#pragma unroll
+      for (int e = 0; e < NC; ++e)
+        xm[r][e] = lm_ext3<SIGN>(e == 0 ? l : v[r][e - 1], v[r][e], e == NC - 1 ? rr : v[r][e + 1]);
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o.p[r][e] = lm_ext3<SIGN>(xm[r][e], xm[r + 1][e], xm[r + 2][e]);
-      o.c[r][0] = v[r + 1].x, o.c[r][1] = v[r + 1].y, o.c[r][2] = v[r + 1].z, o.c[r][3] = v[r + 1].w;
+      for (int e = 0; e < NC; ++e) {
+        o.p[r][e] = lm_ext3<SIGN>(xm[r][e], xm[r + 1][e], xm[r + 2][e]);
+        o.c[r][e] = v[r + 1][e];
+      }
     }
   };
 
@@ -412,13 +432,13 @@ __device__ __forceinline__ void lm_sparse_march(const float *__restrict__ a,
   char *seg_val = reinterpret_cast<char *>(val_out + wave_id * seg_cap);
   int cnt = 0;  // entries of this wave's segment so far (wave-uniform)
   // channel z: extrema of planes z - 1 (pa), z (pb), z + 1 (pc, made here); centre = plane z
-  auto step = [&](int z, const LmPlane<R> &pa, const LmPlane<R> &pb, LmPlane<R> &pc) {
+  auto step = [&](int z, const LmPlane<R, NC> &pa, const LmPlane<R, NC> &pb, LmPlane<R, NC> &pc) {
     plane(z + 1, pc);
-    const long zbase = (long)z * S + (long)yb * Nx + 4 * x4;
+    const long zbase = (long)z * S + (long)yb * Nx + NC * x4;
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
+      for (int e = 0; e < NC; ++e) {
         const float m = lm_ext3<SIGN>(pa.p[r][e], pb.p[r][e], pc.p[r][e]);
         // one v_cmp into a scalar register pair, the rest of the test on the scalar unit (a bool
         // that goes through __ballot() costs two more VALU instructions per output: the compiler
@@ -445,7 +465,7 @@ __device__ __forceinline__ void lm_sparse_march(const float *__restrict__ a,
         }
       }
   };
-  LmPlane<R> A, B, C;
+  LmPlane<R, NC> A, B, C;
   if constexpr (PREFETCH) fetch(z0 - 1, vnext);
   plane(z0 - 1, A);
   plane(z0, B);
@@ -465,8 +485,22 @@ __device__ __forceinline__ void lm_sparse_march(const float *__restrict__ a,
 #ifndef LMS_R_N
 #define LMS_R_N 4
 #endif
-constexpr int LMS_R = LMS_R_N;  // rows per lane of the sparse pass (119 / ~160 / ~200 VGPRs at 4 / 6 / 8)
-constexpr int LMS_BLOCKS = LMS_R <= 4 ? 4 : (LMS_R <= 6 ? 3 : 2);  // blocks per CU the registers allow
+#ifndef LMS_NC_N
+#define LMS_NC_N 2
+#endif
+// Measured at 3681 x 600 x 600 (tools/localmax_sparse_time.py, R x NC: ms): 4 x 4 (119 VGPRs, four waves
+// per SIMD) 3.76; 8 x 2 (the same registers, 1.25 instead of 1.5 row fetches per row of outputs) 3.76;
+// 6 x 2 3.42; 5 x 2 3.51; 4 x 2 (72 VGPRs, seven waves per SIMD) 3.36; 2 x 4 3.65; 3 x 2 3.76; 4 x 1 3.77;
+// 12 x 2 and 16 x 1 (spills) 5.1 / 4.5.  Rows fetched twice do not show; waves in flight do.
+constexpr int LMS_R = LMS_R_N;    // rows per lane of the sparse pass
+constexpr int LMS_NC = LMS_NC_N;  // samples per lane and row (4, 2 or 1)
+static_assert(LMS_NC == 4 || LMS_NC == 2 || LMS_NC == 1, "samples per lane and row");
+#ifdef LMS_BLOCKS_N
+constexpr int LMS_BLOCKS = LMS_BLOCKS_N;
+#else
+constexpr int LMS_BLOCKS =   // blocks per CU the registers allow
+    LMS_R * LMS_NC <= 8 ? 6 : (LMS_R * LMS_NC <= 16 ? 4 : (LMS_R * LMS_NC <= 24 ? 3 : 2));
+#endif
 
 // 1-D grid of nbx * nzc * 2 blocks.  Workgroups go to the 8 XCDs round robin by their id, and a
 // lane's rows yb - 1 and yb + R are the own rows of lanes nx4 = Nx / 4 flattened positions away --
@@ -491,10 +525,10 @@ __global__ __launch_bounds__(256, PREFETCH ? (LMS_BLOCKS > 3 ? 3 : LMS_BLOCKS) :
   const int bzi = (int)(t % nzc), cube = (int)(t / nzc);
   const long nwaves = nbx * nzc * 4;
   if (cube == 0)
-    lm_sparse_march<1, LMS_R, HAS_MASK, PREFETCH, STRIPS>(a0, mask, Nz, Ny, Nx, zper, sp.idx0, sp.val0, sp.counts,
+    lm_sparse_march<1, LMS_R, LMS_NC, HAS_MASK, PREFETCH, STRIPS>(a0, mask, Nz, Ny, Nx, zper, sp.idx0, sp.val0, sp.counts,
                                         sp.seg_cap, bxi, bzi, nbx);
   else
-    lm_sparse_march<-1, LMS_R, HAS_MASK, PREFETCH, STRIPS>(a1, mask, Nz, Ny, Nx, zper, sp.idx1, sp.val1,
+    lm_sparse_march<-1, LMS_R, LMS_NC, HAS_MASK, PREFETCH, STRIPS>(a1, mask, Nz, Ny, Nx, zper, sp.idx1, sp.val1,
                                          sp.counts + nwaves, sp.seg_cap, bxi, bzi, nbx);
 }
 
@@ -679,11 +713,11 @@ bool lm_strips() {
 // the launch geometry of the sparse pass (local_max3s_kernel)
 LmGeom lm_geometry(const origin_ctx *ctx, int Nz, int Ny, int Nx) {
   const int R = LMS_R;
-  const long threads = (long)cdiv(Ny, R) * (Nx / 4);
+  const long threads = (long)cdiv(Ny, R) * (Nx / LMS_NC);
   LmGeom g;
   g.bx = (threads + 4 * 62 - 1) / (4 * 62);  // 62 producing lanes per wave
   if (lm_strips())  // strips of four row groups x chunks of 62 columns
-    g.bx = (long)cdiv(cdiv(Ny, R), 4) * cdiv(Nx / 4, 62);
+    g.bx = (long)cdiv(cdiv(Ny, R), 4) * cdiv(Nx / LMS_NC, 62);
   int nzc = (int)(((long)ctx->num_cu * 16 + g.bx - 1) / g.bx);  // ~16 blocks per CU
   nzc = nzc < 1 ? 1 : (nzc > cdiv(Nz, 32) ? cdiv(Nz, 32) : nzc);
   g.zp = cdiv(Nz, nzc);
@@ -704,7 +738,7 @@ int origin_local_max_sparse_plan(origin_ctx *ctx, int Nz, int Ny, int Nx, long *
   *nseg = g.bx * g.nzc * 4;
   // a wave sees zp channels of 62 lanes x 16 outputs; white noise has one 3x3x3 maximum in 27
   // voxels, a smoothed cube one in ~70: room for one in 8
-  const long per_wave = (long)g.zp * 62 * 4 * LMS_R;
+  const long per_wave = (long)g.zp * 62 * LMS_NC * LMS_R;
   long cap = (per_wave / 8 + 63) / 64 * 64;
   *seg_cap = (int)(cap < 256 ? 256 : cap);
   return ORIGIN_OK;
@@ -727,7 +761,7 @@ int origin_local_max_sparse(origin_ctx *ctx, const float *d_correl, const float 
   sp.idx0 = d_idx_max, sp.val0 = d_val_max, sp.idx1 = d_idx_min, sp.val1 = d_val_min;
   sp.counts = d_counts, sp.seg_cap = seg_cap;
   ProfScope ps(ctx, K_LOCAL_MAX);
-  if (getenv("ORIGIN_LOCALMAX_SPARSE_V1") && LMS_R == 4)   // the first form (same segments)
+  if (getenv("ORIGIN_LOCALMAX_SPARSE_V1") && LMS_R == 4 && LMS_NC == 4)   // the first form (same segments)
     hipLaunchKernelGGL((local_max3v_kernel<2, 4, true>), dim3((unsigned)g.bx, g.nzc), dim3(256), 0,
                        ctx->stream, d_correl, d_correl_min, d_mask, Nz, Ny, Nx, g.zp, 1.0f,
                        (float *)nullptr, (float *)nullptr, sp);
