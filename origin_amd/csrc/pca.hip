@@ -3064,7 +3064,9 @@ int origin_pca_run_into(origin_ctx *ctx, const float *d_X, float *d_F, int Nz, l
       ProfScope ps(ctx, K_PCA_FLUSH, 2);
       // (Round 3 measured two more forms of this pass at 3681 x 600 x 600 and dropped them: the
       // cube's memory order with one pass per area present in a wave, 3.39 ms; two / four spaxels
-      // per lane so that one LDS read of U serves several products, 3.0 / 3.8 ms; this form 2.83.)
+      // per lane so that one LDS read of U serves several products, 3.0 / 3.8 ms; this form 2.83.
+      // Round 4: 16 / 24 / 8 channels per block instead of 32 (80 / 96 / 64 VGPRs, six / five / eight
+      // waves per SIMD): 3.01 / 2.93 / 3.61 ms against 3.04 in the same session -- not occupancy.)
       const int nxb = cdiv(nsmax, 256), nzb = cdiv(Nz, FLUSH_ZB);
       long nsum_f = 0;
       for (int k2 = 0; k2 < nf; ++k2) nsum_f += fd[(size_t)2 * nf + k2];
